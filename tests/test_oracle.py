@@ -1,0 +1,156 @@
+"""CPU tests: the oracle (numpy + C restatements) against the committed golden vectors, closed
+forms and algebraic properties.  The reference holds no test on this path, so
+these are the pins the parity claims rest on."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import gp_oracle as go
+
+SK = ["sk_se_iso_n256_d3", "sk_se_ard_n2_d1", "sk_se_ard_n15_d3", "sk_se_ard_n134_d6", "sk_se_ard_n256_d6"]
+CLOSED = ["closed_n1_se", "closed_n2_rbfbrownian"]
+
+
+def rel(a, b, floor=1e-300):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+@pytest.mark.parametrize("name", SK + CLOSED)
+def test_numpy_oracle_vs_golden(name):
+    g = load_golden(name)
+    f = go.fit(int(g["kernel_id"]), g["theta"], g["X"], g["y"])
+    mu, var = go.predict(f, g["Xs"], include_noise=False)
+    scale = max(float(np.max(np.abs(g["mean"]))), 1e-300)
+    assert np.max(np.abs(mu - g["mean"])) / scale < 1e-9
+    assert rel(var, g["var_latent"], 1e-12) < 1e-7
+    assert abs(f.logml - float(g["logml"])) <= 1e-10 * abs(float(g["logml"]))
+    if "alpha" in g:
+        assert np.max(np.abs(f.alpha - g["alpha"])) / np.max(np.abs(g["alpha"])) < 1e-7
+
+
+@pytest.mark.parametrize("name", SK + CLOSED)
+def test_c_oracle_vs_golden(name, oracle_c):
+    g = load_golden(name)
+    rc, mu, var, logml, alpha, jit = oracle_c(int(g["kernel_id"]), g["theta"], g["X"], g["y"], g["Xs"], False)
+    assert rc == 0 and jit == 0.0
+    scale = max(float(np.max(np.abs(g["mean"]))), 1e-300)
+    assert np.max(np.abs(mu - g["mean"])) / scale < 1e-9
+    assert rel(var, g["var_latent"], 1e-12) < 1e-7
+    assert abs(logml - float(g["logml"])) <= 1e-10 * abs(float(g["logml"]))
+
+
+@pytest.mark.parametrize("name", ["slipval_window_rbfbrownian", "synth_window_rbfbrownian"])
+def test_slip_node_callback_golden(name, oracle_c):
+    g = load_golden(name)
+    mean, sigma = go.slip_node_callback(g["time_array"], g["slip_array"], g["theta"])
+    assert mean.shape == (599,) and sigma.shape == (599,)     # gap-free window -> 599
+    np.testing.assert_allclose(mean, g["mean"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(sigma, g["sigma"], rtol=1e-12)
+    # the C restatement reproduces the node output through the same split/grid/slice
+    X, Y, xtr, ytr = go.slip_node_split(g["time_array"], g["slip_array"])
+    grid = go.slip_node_grid(X)[len(X):]
+    rc, mu, var, _, _, _ = oracle_c(2, g["theta"], xtr, ytr[:, 0], grid[:, None], True)
+    assert rc == 0
+    assert np.max(np.abs(mu - g["mean"])) / np.max(np.abs(g["mean"])) < 1e-8
+    np.testing.assert_allclose(2 * np.sqrt(var), g["sigma"], rtol=1e-8)
+
+
+def test_split_and_grid_semantics():
+    t = np.arange(11, 160, dtype=float)            # 149 ticks
+    X, Y, xtr, ytr = go.slip_node_split(t, np.zeros_like(t))
+    assert len(xtr) == int(0.9 * 149) == 134
+    grid = go.slip_node_grid(X)
+    assert grid[0] == 11 and grid[-1] == 159 + 599 and len(grid) == 149 + 599
+    assert grid[len(X)] == 160                      # index slicing == first tick after the window
+    # a window with a gap is still INDEX-sliced (gp_slip_node.py:59-61), so output starts earlier in time
+    tg = np.concatenate([np.arange(11, 100), np.arange(110, 170)]).astype(float)
+    Xg = tg.reshape(-1, 1)
+    gg = go.slip_node_grid(Xg)
+    assert gg[len(tg)] == 11 + len(tg) < tg.max() + 1
+
+
+def test_properties_random():
+    rng = np.random.default_rng(5)
+    for kid, d in [(0, 2), (1, 4), (2, 1)]:
+        N, M = 60, 17
+        if kid == 2:
+            X = np.sort(rng.uniform(5, 300, (N, 1)), 0)
+            Xs = rng.uniform(5, 900, (M, 1))
+            theta = np.array([0.7, 20.0, 0.02, 0.01])
+        else:
+            X, Xs = rng.normal(size=(N, d)), rng.normal(size=(M, d))
+            theta = np.concatenate([[1.1], rng.uniform(0.5, 2, 1 if kid == 0 else d), [0.05]])
+        y = rng.normal(size=N)
+        f = go.fit(kid, theta, X, y, want_inverse=True)
+        Ky = go.kernel_K(kid, theta, X) + (theta[-1] + go.GPY_DIAG_EPS) * np.eye(N)
+        assert np.allclose(f.L @ f.L.T, Ky, rtol=1e-12, atol=1e-12)
+        assert np.allclose(Ky @ f.alpha, y, rtol=1e-9, atol=1e-9)
+        mu, var = go.predict(f, Xs)
+        mu2, var2 = go.predict(f, Xs, via_inverse=True)      # literal GPy form
+        assert np.allclose(mu, mu2) and np.allclose(var, var2, rtol=1e-8)
+        assert np.all(var >= theta[-1])
+        perm = rng.permutation(N)
+        fp = go.fit(kid, theta, X[perm], y[perm])
+        mup, varp = go.predict(fp, Xs)
+        assert np.allclose(mu, mup, rtol=1e-8, atol=1e-10) and np.allclose(var, varp, rtol=1e-8)
+        assert abs(f.logml - fp.logml) < 1e-8 * abs(f.logml)
+
+
+def test_limits():
+    # noise -> inf : mu -> 0, var -> k** + noise
+    X = np.linspace(0, 1, 9)[:, None]
+    y = np.sin(3 * X[:, 0])
+    th = np.array([1.0, 0.5, 1e12])
+    f = go.fit(0, th, X, y)
+    mu, var = go.predict(f, np.array([[0.3]]))
+    assert abs(mu[0]) < 1e-10 and abs(var[0] - (1.0 + 1e12)) / 1e12 < 1e-12
+    # Brownian prior variance grows linearly with |x*| far from the data
+    th = np.array([0.8, 2.0, 0.05, 0.01])
+    f = go.fit(2, th, np.array([[10.0], [11.0], [12.0]]), np.array([0.1, 0.0, -0.1]))
+    _, v = go.predict(f, np.array([[500.0], [1000.0]]), include_noise=False)
+    assert np.allclose(v, 0.8 * 0.05 * np.array([500.0, 1000.0]), rtol=1e-9)
+
+
+def test_jitchol_policy():
+    A = np.array([[1.0, 1.0 + 1e-9], [1.0 + 1e-9, 1.0]])       # indefinite by 1e-9
+    L, jitter, tries = go.jitchol(A)
+    assert tries >= 1 and jitter == pytest.approx(1e-6 * 10 ** (tries - 1))
+    with pytest.raises(np.linalg.LinAlgError):
+        go.jitchol(np.array([[1.0, 2.0], [2.0, -1.0]]))
+
+
+def test_c_oracle_jitter_and_failure(oracle_c):
+    # duplicate inputs + zero noise: singular up to the 1e-8 GPy epsilon -> still factorises
+    X = np.array([[0.0], [0.0], [1.0]])
+    rc, mu, var, logml, alpha, jit = oracle_c(0, [1.0, 1.0, 0.0], X, np.array([1.0, 1.0, 0.0]), np.array([[0.5]]))
+    assert rc == 0 and math.isfinite(logml)
+    rc, *_ = oracle_c(0, [1.0, 1.0, -2.0], X, np.array([1.0, 1.0, 0.0]), np.array([[0.5]]))
+    assert rc > 0                                               # negative noise: not PD, info returned
+
+
+def test_lookahead_golden():
+    g = load_golden("lookahead_restated")
+    H = go.unpack_H(g["HvecData"], True)
+    np.testing.assert_array_equal(H, g["H_client"])
+    assert not np.array_equal(H, g["H_true"])                  # the r*4+c quirk loses information
+    fired, cmd, i, xy = go.predict_stop(g["mean"], g["sigma"], g["PvecData"], g["QvecData"], g["STMvecData"], H,
+                                        g["PosData"], float(g["arrival_time"]), float(g["now"]))
+    assert fired == bool(g["fired"]) and i == int(g["i"])
+    assert cmd == pytest.approx(float(g["stop_cmd"]), rel=1e-12)
+    assert xy == pytest.approx(float(g["xy_err"]), rel=1e-10)
+    # late result -> immediate 0.5 s stop (gp_predictor.cpp:107-111)
+    fired, cmd, *_ = go.predict_stop(g["mean"], g["sigma"], g["PvecData"], g["QvecData"], g["STMvecData"], H,
+                                     g["PosData"], 0.0, 1e6)
+    assert fired and cmd == 0.5
+
+
+def test_llh_to_enu():
+    g = load_golden("llh_to_enu_restated")
+    np.testing.assert_allclose(go.llh_to_enu(*g["llh"]), g["enu"], rtol=1e-12, atol=1e-9)
+    e = go.llh_to_enu(*go.INIT_LLH)
+    assert np.linalg.norm(e) < 5.0       # the YAML origin LLH and ECEF agree to a few metres
+    up = go.llh_to_enu(go.INIT_LLH[0], go.INIT_LLH[1], go.INIT_LLH[2] + 10.0)
+    assert abs((up - e)[2] - 10.0) < 1e-6

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz (run in the BUILD container only; needs scikit-learn and
+/root/reference for slipVal.csv).  The fixtures are data: inputs + expected outputs.
+
+Sources of the expected values, per fixture `source` field:
+  sklearn  -- scikit-learn GaussianProcessRegressor(optimizer=None): an implementation independent
+              of oracle/ (the reference cites scikit-learn kernels, `Kernel Selection/README.md:9`)
+  closed   -- closed-form N=1 / N=2 answers evaluated with python floats
+  restated -- oracle/gp_oracle.py outputs (regression vectors for the GPy-only RBF x Brownian kernel
+              and for the GpPredictor look-ahead; PARITY UNPINNED vs GPy itself)
+"""
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import gp_oracle as go  # noqa: E402
+import corenav_gp_amd.synth as synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+REF_CSV = "/root/reference/core_navigation/script/slipVal.csv"
+
+
+def sklearn_case(name, kid, X, y, Xs, theta):
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel
+    d = X.shape[1]
+    ell = theta[1] if kid == go.KERNEL_SE_ISO else np.asarray(theta[1:1 + d])
+    kern = ConstantKernel(theta[0], "fixed") * RBF(ell, "fixed")
+    gpr = GaussianProcessRegressor(kern, alpha=theta[-1] + go.GPY_DIAG_EPS, optimizer=None,
+                                   normalize_y=False).fit(X, y)
+    mu, sd = gpr.predict(Xs, return_std=True)
+    lml = gpr.log_marginal_likelihood_value_
+    # cross-check the restatement against sklearn before writing anything
+    f = go.fit(kid, theta, X, y)
+    omu, ovar = go.predict(f, Xs, include_noise=False)
+    e_mu = np.max(np.abs(omu - mu)) / max(np.max(np.abs(mu)), 1e-300)
+    e_var = np.max(np.abs(ovar - sd ** 2) / np.maximum(sd ** 2, 1e-12))
+    e_l = abs(f.logml - lml) / abs(lml)
+    print(f"{name}: oracle vs sklearn  mean {e_mu:.2e}  var {e_var:.2e}  logml {e_l:.2e}")
+    assert e_mu < 1e-9 and e_var < 1e-7 and e_l < 1e-11, name
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), source="sklearn", kernel_id=kid,
+                        theta=np.asarray(theta, dtype=np.float64), X=X, y=y, Xs=Xs, mean=mu,
+                        var_latent=sd ** 2, logml=lml, alpha=gpr.alpha_)
+
+
+def closed_forms():
+    # N = 1, SE-iso: mu = k* y/(s+n), var = s - k*^2/(s+n), logML = -0.5 y^2/(s+n) - 0.5 log(s+n) - 0.5 log 2pi
+    s, ell, n = 1.7, 0.8, 0.3
+    x, y, xs = 0.4, -0.6, 1.1
+    neff = n + go.GPY_DIAG_EPS
+    ks = s * math.exp(-0.5 * ((x - xs) / ell) ** 2)
+    mu = ks * y / (s + neff)
+    var = s - ks * ks / (s + neff)
+    lml = -0.5 * y * y / (s + neff) - 0.5 * math.log(s + neff) - 0.5 * math.log(2 * math.pi)
+    np.savez_compressed(os.path.join(OUT, "closed_n1_se.npz"), source="closed", kernel_id=0,
+                        theta=np.array([s, ell, n]), X=np.array([[x]]), y=np.array([y]),
+                        Xs=np.array([[xs]]), mean=np.array([mu]), var_latent=np.array([var]), logml=lml)
+    # N = 2, RBF x Brownian (the reference kernel), explicit 2x2 inverse
+    sr, l, sb, n = 0.9, 5.0, 0.05, 0.01
+    x1, x2, xs = 12.0, 15.0, 20.0
+    y1, y2 = 0.07, -0.02
+    neff = n + go.GPY_DIAG_EPS
+    k = lambda a, b: sr * math.exp(-0.5 * (a - b) ** 2 / l ** 2) * sb * min(abs(a), abs(b))
+    a11, a12, a22 = k(x1, x1) + neff, k(x1, x2), k(x2, x2) + neff
+    det = a11 * a22 - a12 * a12
+    i11, i12, i22 = a22 / det, -a12 / det, a11 / det
+    k1, k2 = k(x1, xs), k(x2, xs)
+    mu = k1 * (i11 * y1 + i12 * y2) + k2 * (i12 * y1 + i22 * y2)
+    var = k(xs, xs) - (k1 * (i11 * k1 + i12 * k2) + k2 * (i12 * k1 + i22 * k2))
+    quad = y1 * (i11 * y1 + i12 * y2) + y2 * (i12 * y1 + i22 * y2)
+    lml = -0.5 * quad - 0.5 * math.log(det) - math.log(2 * math.pi)
+    np.savez_compressed(os.path.join(OUT, "closed_n2_rbfbrownian.npz"), source="closed", kernel_id=2,
+                        theta=np.array([sr, l, sb, n]), X=np.array([[x1], [x2]]), y=np.array([y1, y2]),
+                        Xs=np.array([[xs]]), mean=np.array([mu]), var_latent=np.array([var]), logml=lml)
+
+
+def slipval_window():
+    """The only real slip series in the reference (core_navigation/script/slipVal.csv, 199 rows
+    time_s, slip @ 0.1 s).  Stored as data: tick = round(10 t), the first 149 rows form one
+    recording window (CoreNav.cpp:270-288)."""
+    raw = np.loadtxt(REF_CSV, delimiter=",")
+    ticks = np.round(raw[:, 0] * 10.0)
+    slip = raw[:, 1]
+    t, s = ticks[:149], slip[:149]
+    theta = np.array([0.5, 30.0, 0.01, 0.002])
+    mean, sigma = go.slip_node_callback(t, s, theta)
+    X, Y, xtr, ytr = go.slip_node_split(t, s)
+    f = go.fit(go.KERNEL_RBF_BROWNIAN, theta, xtr, ytr[:, 0])
+    np.savez_compressed(os.path.join(OUT, "slipval_window_rbfbrownian.npz"), source="restated", kernel_id=2,
+                        theta=theta, time_array=t, slip_array=s, mean=mean, sigma=sigma, logml=f.logml,
+                        alpha=f.alpha, all_ticks=ticks, all_slip=slip)
+    print("slipVal window: n", len(t), "ntrain", len(xtr), "M_out", len(mean), "logml", f.logml)
+
+
+def restated_cases():
+    t, s = synth.reference_window(149, tick0=11, seed=synth.SEED_BASE)
+    theta = np.array([0.5, 30.0, 0.01, 0.002])
+    mean, sigma = go.slip_node_callback(t, s, theta)
+    np.savez_compressed(os.path.join(OUT, "synth_window_rbfbrownian.npz"), source="restated", kernel_id=2,
+                        theta=theta, time_array=t, slip_array=s, mean=mean, sigma=sigma)
+    # look-ahead golden (gp_predictor.cpp:58-130) on a synthetic but plausible filter state
+    rng = np.random.default_rng(synth.SEED_BASE + 99)
+    A = rng.normal(0, 1e-3, (15, 15))
+    A[6:8, :] *= 1e-7                                      # lat/lon rows are in radians
+    A[:, 6:8] *= 1e-2
+    STM = np.eye(15) + A * 0.02
+    STM[6:9, 3:6] += np.diag([1.6e-9, 2.0e-9, -0.02])     # position <- velocity coupling (rad, rad, m)
+    P = np.diag(np.concatenate([np.full(3, 1e-6), np.full(3, 2e-3), [1e-15, 1e-15, 0.04], np.full(6, 1e-8)]))
+    Q = np.diag(np.concatenate([np.full(3, 1e-9), np.full(3, 3e-5), [4e-19, 6e-19, 1e-6], np.full(6, 1e-12)]))
+    H = np.zeros((4, 15))
+    H[0, 3], H[1, 2], H[2, 4], H[3, 5] = 1.0, 1.0, 1.0, 1.0
+    H += rng.normal(0, 1e-3, H.shape)
+    pos = np.array(go.INIT_LLH) + np.array([1e-6, -2e-6, 1.5])
+    packed = go.pack_set_stopping(P, Q, STM, H, pos)
+    Hc = go.unpack_H(packed["HvecData"], True)
+    fired, cmd, i, xy, trace = go.predict_stop(mean, sigma, P, Q, STM, Hc, pos, arrival_time=100.0, now=100.25,
+                                               return_trace=True)
+    print("look-ahead: fired", fired, "cmd", cmd, "i", i, "xy", xy)
+    np.savez_compressed(os.path.join(OUT, "lookahead_restated.npz"), source="restated", mean=mean, sigma=sigma,
+                        PvecData=packed["PvecData"], QvecData=packed["QvecData"], STMvecData=packed["STMvecData"],
+                        HvecData=packed["HvecData"], PosData=packed["PosData"], H_true=H, H_client=Hc,
+                        arrival_time=100.0, now=100.25, fired=fired, stop_cmd=cmd, i=i, xy_err=xy, trace=trace)
+    e = go.llh_to_enu(*(np.array(go.INIT_LLH) + np.array([2e-6, 3e-6, 4.0])))
+    np.savez_compressed(os.path.join(OUT, "llh_to_enu_restated.npz"), source="restated",
+                        llh=np.array(go.INIT_LLH) + np.array([2e-6, 3e-6, 4.0]), enu=e)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    closed_forms()
+    # cfg1-like (N=256,d=3 SE-iso) and smaller ARD cases, all against scikit-learn
+    kid, X, y, Xs, th, _ = synth.config(1, M=64)
+    sklearn_case("sk_se_iso_n256_d3", kid, X[0], y[0], Xs[0], th[0])
+    for n, d, m, tag in [(2, 1, 5, "n2_d1"), (15, 3, 9, "n15_d3"), (134, 6, 48, "n134_d6"), (256, 6, 64, "n256_d6")]:
+        Xn, yn, Xsn = synth.window(n, d, m, seed=synth.SEED_BASE + 10 * n + d)
+        theta = synth.theta_for(go.KERNEL_SE_ARD, d, yn if n > 2 else np.array([0.3, -0.2]))
+        sklearn_case(f"sk_se_ard_{tag}", go.KERNEL_SE_ARD, Xn, yn, Xsn, theta)
+    slipval_window()
+    restated_cases()
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden bytes:", tot)
+
+
+if __name__ == "__main__":
+    main()
