@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- GP-fits/s of the slip-GP hot path on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic slip windows: `--batch`
+independent fixed-theta fits (Gram + Cholesky + solve + predictive mean/variance + log marginal
+likelihood, M = 599 test points) per GPU, inputs already resident in HBM.  At N = 1 the workload is
+BASELINE configs[1] (N = 2048, d = 6, ARD, fp64).  Multi-GPU: one process per GPU (torchrun), fits
+sharded across ranks with no data-path collective; RCCL only gathers per-fit summaries.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix (= vector) peak; absent from the local
+                               # guide, re-measured by tools/mfma_peak (see DESIGN.md "Measurement")
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+M_TEST = 599                   # gp_slip_node.py:45,59: arange(min, max+600)[n:] -> 599 points
+
+
+def fit_flops(N, d, M):
+    """Algorithmic flops of one fit: F_chol and F_fit."""
+    f_chol = N ** 3 / 3.0
+    f_fit = f_chol + M * N ** 2 + 2 * N ** 2 + (3 * d + 2) * (N * (N + 1) / 2 + M * N) + 4 * M * N
+    return f_chol, f_fit
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="independent fits per GPU per step")
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3])
+    ap.add_argument("--n", type=int, default=None, help="override window length N")
+    ap.add_argument("--cpu-sample", type=int, default=6, help="fits timed on the host for cpu_baseline")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import corenav_gp_amd.engine as engine
+    import corenav_gp_amd.synth as synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B = args.batch
+    # every rank owns its own shard of windows (weak scaling: per-GPU work fixed)
+    kid, X, y, Xs, th, dts = synth.config(args.config, batch=B, N=args.n, M=M_TEST)
+    if rank > 0:   # different trajectories per rank, same shapes
+        X = np.roll(X, rank, axis=0) + 0.0
+        rng = np.random.default_rng(synth.SEED_BASE + 7919 * rank)
+        y = y + rng.normal(0, 1e-3, y.shape)
+    _, N, d = X.shape
+    dtype = engine.F64 if dts == "f64" else engine.F32
+    tdt = torch.float64 if dts == "f64" else torch.float32
+    nth = th.shape[1]
+    thp = np.zeros((B, engine.MAX_THETA))
+    thp[:, :nth] = th
+
+    dX = torch.from_numpy(np.ascontiguousarray(X.transpose(0, 2, 1))).to(dev, tdt)     # [B][d][N]
+    dXs = torch.from_numpy(np.ascontiguousarray(Xs.transpose(0, 2, 1))).to(dev, tdt)   # [B][d][M]
+    dy = torch.from_numpy(y).to(dev, tdt)
+    dth = torch.from_numpy(thp).to(dev, torch.float64)
+    dmean = torch.empty((B, M_TEST), device=dev, dtype=tdt)
+    dvar = torch.empty((B, M_TEST), device=dev, dtype=tdt)
+    dlogml = torch.empty(B, device=dev, dtype=torch.float64)
+    dinfo = torch.zeros(B, device=dev, dtype=torch.int32)
+
+    ctx = engine.Context(device=local, max_n=N, max_m=M_TEST, max_d=d, max_batch=B, dtype=dtype)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.fit_predict_batch_device(B, N, d, M_TEST, kid, dX.data_ptr(), dy.data_ptr(), dXs.data_ptr(),
+                                     dth.data_ptr(), 0, True, dmean.data_ptr(), dvar.data_ptr(), dlogml.data_ptr(),
+                                     dinfo.data_ptr(), stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert int(dinfo.abs().sum().item()) == 0, "a fit reported a non-positive pivot"
+
+    # per-fit summaries gathered over RCCL (the only collective on the path: SURVEY.md 8e)
+    summ = torch.stack([dlogml, dvar.to(torch.float64).max(1).values], 1)
+    if world > 1:
+        allsum = [torch.empty_like(summ) for _ in range(world)]
+        dist.all_gather(allsum, summ)
+        summ = torch.cat(allsum, 0)
+
+    # ---- roofline of the dominant kernel (k_update: trailing syrk/gemm + Gram), HIP events per launch
+    ctx.profile_enable(True)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    upd = prof["update"]
+    achieved = upd["flops"] / (upd["ms"] * 1e-3) / 1e12 if upd["ms"] > 0 else 0.0
+    peak = FP64_MFMA_PEAK_TFLOPS if dts == "f64" else FP32_MFMA_PEAK_TFLOPS
+
+    if rank == 0:
+        fits = B * world * args.steps
+        f_chol, f_fit = fit_flops(N, d, M_TEST)
+        value = fits / dt
+        out = {
+            "metric": "GP-fits/s", "value": value, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dts, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: batch of independent fixed-theta GP fits, "
+                                   f"N={N} d={d} M={M_TEST} kernel={'SE-ARD' if kid == 1 else 'SE-iso'} {dts}",
+                       "fits_per_gpu_per_step": B, "N": N, "d": d, "M": M_TEST,
+                       "fit_tflops": value * f_fit / 1e12, "cholesky_roofline_frac": value * f_chol / 1e12 / world / peak,
+                       "inputs": "resident in HBM"},
+            "roofline": {"bound": "mfma", "kernel": "k_update (syrk/gemm trailing update + fused Gram)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "avg_launch_ms": upd["ms"] / max(upd["launches"], 1),
+                         "launches": upd["launches"]},
+            "kernel_ms_per_step": {k: v["ms"] / 2 for k, v in prof.items()},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(kid, X, y, Xs, th, args.cpu_sample, dmean, dvar, dlogml, f_fit)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(kid, X, y, Xs, th, nsample, dmean, dvar, dlogml, f_fit):
+    """The C oracle ('port' of the reference arithmetic, single thread like the reference's catkin
+    build) timed on this box's host cores on a bounded sample of the same windows; its outputs also
+    check the timed GPU outputs."""
+    import ctypes
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "libgp_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(so)
+    dp = ctypes.POINTER(ctypes.c_double)
+    n = min(nsample, X.shape[0])
+    N, d = X.shape[1:]
+    M = Xs.shape[1]
+    gm, gv, gl = dmean.cpu().numpy().astype(np.float64), dvar.cpu().numpy().astype(np.float64), dlogml.cpu().numpy()
+    worst = 0.0
+    t0 = time.perf_counter()
+    for b in range(n):
+        mean, var, logml, jit = np.zeros(M), np.zeros(M), np.zeros(1), np.zeros(1)
+        p = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
+        Xb, yb, Xsb, thb = (np.ascontiguousarray(a[b], dtype=np.float64) for a in (X, y, Xs, th))
+        rc = lib.oracle_fit_predict(kid, p(thb), N, d, p(Xb), p(yb), M, p(Xsb), 1, p(mean), p(var), p(logml), None,
+                                    None, p(jit))
+        assert rc == 0
+        worst = max(worst, float(np.max(np.abs(gm[b] - mean)) / np.max(np.abs(mean))),
+                    float(np.max(np.abs(gv[b] - var) / var)), abs(gl[b] - logml[0]) / abs(logml[0]))
+    el = time.perf_counter() - t0
+    return {"value": n / el, "unit": "fits/s", "cores": 1, "kind": "port",
+            "sample": f"{n} of the step's windows through oracle/gp_oracle.c (gcc -O3 -march=native, 1 thread), "
+                      f"{el:.1f} s; {n / el * f_fit / 1e9:.2f} GFLOP/s",
+            "gpu_vs_oracle_max_rel_err": worst, "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,590 @@
+// cgp_engine.hip -- context, launch schedule and the C ABI of include/corenav_gp.h.
+// Host side of the slip-GP hot path; the arithmetic is in cgp_kernels.hpp (HIP, gfx950 only).
+// There is no CPU fallback anywhere in this file: without a usable device cgp_create returns NULL.
+#include "../../include/corenav_gp.h"
+#include "cgp_kernels.hpp"
+#include "gp_predictor_core.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace cgp;
+
+static_assert(CGP_MAX_D == MAXD, "header / kernel MAXD mismatch");
+static_assert(CGP_MAX_THETA == MAX_THETA, "header / kernel MAX_THETA mismatch");
+
+namespace {
+
+struct ProfRec {
+  int kernel;
+  hipEvent_t a, b;
+  double flops;
+};
+
+}  // namespace
+
+struct cgp_ctx {
+  int device = 0, dtype = CGP_F64;
+  int max_n = 0, max_m = 0, max_d = 0, max_batch = 0;
+  int NTmax = 0, ETmax = 0, ld = 0;
+  size_t esz = 8;
+  hipStream_t stream = nullptr;
+  // device buffers
+  void *Lw = nullptr, *Dinv = nullptr, *dX = nullptr, *dXs = nullptr, *dy = nullptr;
+  void *dmean = nullptr, *dvar = nullptr, *dalpha = nullptr;
+  double *dtheta = nullptr, *djitter = nullptr, *dlogml = nullptr;
+  int *dinfo = nullptr;
+  size_t lw_stride = 0, dinv_stride = 0, alpha_stride = 0;
+  // state of the last single fit (cgp_fit -> cgp_predict)
+  bool have_fit = false;
+  int fN = 0, fd = 0, fkernel = 0;
+  double ftheta[CGP_MAX_THETA] = {0};
+  double fjitter = 0.0;
+  // profiling
+  bool prof = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  double prof_ms[CGP_PROF_KERNELS] = {0}, prof_flops[CGP_PROF_KERNELS] = {0};
+  long long prof_n[CGP_PROF_KERNELS] = {0};
+  std::string err;
+};
+
+namespace {
+
+inline int ntheta(int kid, int d) { return kid == CGP_KERNEL_SE_ISO ? 3 : (kid == CGP_KERNEL_SE_ARD ? d + 2 : 4); }
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+bool hip_ok(cgp_ctx *c, hipError_t e, const char *what) {
+  if (e == hipSuccess) return true;
+  if (c) c->err = std::string(what) + ": " + hipGetErrorString(e);
+  return false;
+}
+#define HIP_TRY(ctx, expr)                                   \
+  do {                                                       \
+    if (!hip_ok((ctx), (expr), #expr)) return CGP_EHIP;      \
+  } while (0)
+
+hipEvent_t get_event(cgp_ctx *c) {
+  if (!c->pool.empty()) {
+    hipEvent_t e = c->pool.back();
+    c->pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct Launcher {
+  cgp_ctx *c;
+  hipStream_t s;
+  int pending = -1;
+  void begin(int kernel, double flops) {
+    if (!c->prof) return;
+    ProfRec r{kernel, get_event(c), get_event(c), flops};
+    (void)hipEventRecord(r.a, s);
+    c->recs.push_back(r);
+    pending = (int)c->recs.size() - 1;
+  }
+  void end() {
+    if (!c->prof || pending < 0) return;
+    (void)hipEventRecord(c->recs[pending].b, s);
+    pending = -1;
+  }
+};
+
+template <typename T> int set_lds_attrs() {
+  static bool done = false;
+  if (done) return 0;
+  const int upd = 4 * KT * LDST * (int)sizeof(T);
+  const int tile = TS * LDA_P * (int)sizeof(T);
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trsm<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
+  done = true;
+  return 0;
+}
+
+// Algorithmic flops of the update launches of block step k (DESIGN.md "Kernels"): lower-trapezoid
+// entries of block column k times a 2*(k*128)-flop inner product, plus (3d+2) per Gram entry.
+double update_flops(int N, int M, int d, int k, bool in_rows, int batch) {
+  const double w = std::min(TS, N - k * TS);
+  const double rows_in = in_rows ? ((double)(N - k * TS) * w - w * (w - 1) / 2.0) : 0.0;
+  const double rows_ex = (double)(M + 1) * w;
+  return batch * ((rows_in + rows_ex) * 2.0 * (double)(k * TS) + (3.0 * d + 2.0) * (rows_in + (double)M * w));
+}
+double trsm_flops(int N, int M, int k, bool in_rows, int batch) {
+  const double w = std::min(TS, N - k * TS);
+  const double rows = (in_rows ? std::max(0, N - (k + 1) * TS) : 0) + (M + 1);
+  return batch * rows * w * w;  // w^2/2 multiply-adds per row
+}
+
+// Enqueue the whole schedule for `batch` fits on stream s.  in_rows = false: predict after fit.
+template <typename T>
+int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha, hipStream_t s) {
+  if (set_lds_attrs<T>() != 0) {
+    c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+    return CGP_EHIP;
+  }
+  Launcher L{c, s};
+  a.rows_from_extra = in_rows ? 0 : 1;
+  const int upd_lds = 4 * KT * LDST * (int)sizeof(T);
+  const int tile_lds = TS * LDA_P * (int)sizeof(T);
+  if (in_rows) HIP_TRY(c, hipMemsetAsync(a.info, 0, sizeof(int) * batch, s));
+  for (int k = 0; k < a.NT; ++k) {
+    const int gx_u = (in_rows ? a.NT - k : 0) + a.ET;
+    L.begin(0, update_flops(a.N, a.M, a.d, k, in_rows, batch));
+    hipLaunchKernelGGL(k_update<T>, dim3(gx_u, batch), dim3(256), upd_lds, s, a, k);
+    L.end();
+    if (in_rows) {
+      L.begin(1, batch * (double)TS * TS * TS / 3.0);
+      hipLaunchKernelGGL(k_potf2<T>, dim3(batch), dim3(256), tile_lds, s, a, k);
+      L.end();
+    }
+    const int gx_t = (in_rows ? a.NT - k - 1 : 0) + a.ET;
+    L.begin(2, trsm_flops(a.N, a.M, k, in_rows, batch));
+    hipLaunchKernelGGL(k_trsm<T>, dim3(gx_t, batch), dim3(256), tile_lds, s, a, k);
+    L.end();
+  }
+  L.begin(3, batch * (4.0 * a.M * a.N + 2.0 * a.N));
+  hipLaunchKernelGGL(k_finalize<T>, dim3(cdiv(a.M, 64) + 1, batch), dim3(256), 0, s, a, in_rows ? 1 : 0);
+  L.end();
+  if (want_alpha) {
+    L.begin(4, batch * (double)a.N * a.N);
+    hipLaunchKernelGGL(k_alpha<T>, dim3(batch), dim3(256), (a.NT * TS + TS) * sizeof(double), s, a);
+    L.end();
+  }
+  HIP_TRY(c, hipGetLastError());
+  return CGP_OK;
+}
+
+int run(cgp_ctx *c, const FitArgs &a, int batch, bool in_rows, bool want_alpha, hipStream_t s) {
+  return c->dtype == CGP_F64 ? run_schedule<double>(c, a, batch, in_rows, want_alpha, s)
+                             : run_schedule<float>(c, a, batch, in_rows, want_alpha, s);
+}
+
+FitArgs base_args(cgp_ctx *c, int N, int d, int M, int kid, int include_noise) {
+  FitArgs a{};
+  a.Lw = c->Lw;
+  a.lw_stride = c->lw_stride;
+  a.ld = c->ld;
+  a.Dinv = c->Dinv;
+  a.dinv_stride = c->dinv_stride;
+  a.alpha = c->dalpha;
+  a.alpha_stride = c->alpha_stride;
+  a.N = N;
+  a.d = d;
+  a.M = M;
+  a.NT = cdiv(N, TS);
+  a.ET = cdiv(M + 1, TS);
+  a.kernel_id = kid;
+  a.include_noise = include_noise;
+  return a;
+}
+
+int check_shape(const cgp_ctx *c, int batch, int N, int d, int M, int kid) {
+  if (!c) return CGP_EINVAL;
+  if (batch < 1 || N < 1 || d < 1 || M < 0) return CGP_EINVAL;
+  if (kid < 0 || kid > 2) return CGP_EINVAL;
+  if (kid == CGP_KERNEL_RBF_BROWNIAN && d != 1) return CGP_EINVAL;
+  if (batch > c->max_batch || N > c->max_n || M > c->max_m || d > c->max_d) return CGP_ECAPACITY;
+  return CGP_OK;
+}
+
+// (n, d) row-major fp64  ->  SoA [d][n] in the device dtype, staged in `tmp`
+void pack_soa(const double *src, int n, int d, int dtype, std::vector<char> &tmp, size_t off_elems) {
+  if (dtype == CGP_F64) {
+    double *o = reinterpret_cast<double *>(tmp.data()) + off_elems;
+    for (int q = 0; q < d; ++q)
+      for (int i = 0; i < n; ++i) o[(size_t)q * n + i] = src[(size_t)i * d + q];
+  } else {
+    float *o = reinterpret_cast<float *>(tmp.data()) + off_elems;
+    for (int q = 0; q < d; ++q)
+      for (int i = 0; i < n; ++i) o[(size_t)q * n + i] = (float)src[(size_t)i * d + q];
+  }
+}
+void pack_vec(const double *src, size_t n, int dtype, std::vector<char> &tmp, size_t off_elems) {
+  if (dtype == CGP_F64) memcpy(reinterpret_cast<double *>(tmp.data()) + off_elems, src, n * sizeof(double));
+  else {
+    float *o = reinterpret_cast<float *>(tmp.data()) + off_elems;
+    for (size_t i = 0; i < n; ++i) o[i] = (float)src[i];
+  }
+}
+void unpack_vec(const std::vector<char> &tmp, size_t off_elems, size_t n, int dtype, double *dst) {
+  if (dtype == CGP_F64) memcpy(dst, reinterpret_cast<const double *>(tmp.data()) + off_elems, n * sizeof(double));
+  else {
+    const float *o = reinterpret_cast<const float *>(tmp.data()) + off_elems;
+    for (size_t i = 0; i < n; ++i) dst[i] = (double)o[i];
+  }
+}
+
+// mean of diag(Ky) for GPy's jitter policy (jitchol: jitter = diagA.mean() * 1e-6)
+double mean_diag(int kid, const double *theta, int d, const double *X, int N) {
+  const double noise = theta[ntheta(kid, d) - 1] + 1e-8;
+  if (kid != CGP_KERNEL_RBF_BROWNIAN) return theta[0] + noise;
+  double s = 0;
+  for (int i = 0; i < N; ++i) s += std::fabs(X[i]);
+  return theta[0] * theta[2] * s / N + noise;
+}
+
+int upload_theta(cgp_ctx *c, const double *theta, int theta_stride, int nth, int batch, hipStream_t s,
+                 std::vector<double> &stage) {
+  stage.assign((size_t)batch * CGP_MAX_THETA, 0.0);
+  for (int b = 0; b < batch; ++b)
+    for (int q = 0; q < nth; ++q) stage[(size_t)b * CGP_MAX_THETA + q] = theta[(size_t)b * theta_stride + q];
+  HIP_TRY(c, hipMemcpyAsync(c->dtheta, stage.data(), stage.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  return CGP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cgp_abi_version(void) { return 1; }
+
+const char *cgp_strerror(int code) {
+  switch (code) {
+    case CGP_OK: return "ok";
+    case CGP_EINVAL: return "invalid argument";
+    case CGP_ENOMEM: return "out of device memory";
+    case CGP_EHIP: return "HIP runtime error (see cgp_last_error)";
+    case CGP_ESTATE: return "no fitted model in this context";
+    case CGP_ENODEVICE: return "no usable gfx950 device";
+    case CGP_ECAPACITY: return "problem exceeds the context capacity given to cgp_create";
+    default: return code > 0 ? "matrix not positive definite after the jitter policy (value = failing pivot)" : "unknown error";
+  }
+}
+
+const char *cgp_last_error(const cgp_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+double cgp_last_jitter(const cgp_ctx *ctx) { return ctx ? ctx->fjitter : 0.0; }
+
+cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, int dtype) {
+  if (max_n < 1 || max_m < 0 || max_d < 1 || max_d > CGP_MAX_D || max_batch < 1) return nullptr;
+  if (dtype != CGP_F64 && dtype != CGP_F32) return nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  cgp_ctx *c = new cgp_ctx();
+  c->device = device;
+  c->dtype = dtype;
+  c->esz = dtype == CGP_F64 ? 8 : 4;
+  c->max_n = max_n;
+  c->max_m = max_m;
+  c->max_d = max_d;
+  c->max_batch = max_batch;
+  c->NTmax = cdiv(max_n, TS);
+  c->ETmax = cdiv(max_m + 1, TS);
+  c->ld = (c->NTmax + c->ETmax) * TS;
+  c->lw_stride = (size_t)c->ld * c->NTmax * TS;
+  c->dinv_stride = (size_t)c->NTmax * 8 * DB * DB;
+  c->alpha_stride = (size_t)c->NTmax * TS;
+  const size_t B = max_batch;
+  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipMalloc(&c->Lw, B * c->lw_stride * c->esz) == hipSuccess;
+  ok = ok && hipMalloc(&c->Dinv, B * c->dinv_stride * c->esz) == hipSuccess;
+  ok = ok && hipMalloc(&c->dX, B * max_d * max_n * c->esz) == hipSuccess;
+  ok = ok && hipMalloc(&c->dXs, B * max_d * (size_t)std::max(max_m, 1) * c->esz) == hipSuccess;
+  ok = ok && hipMalloc(&c->dy, B * max_n * c->esz) == hipSuccess;
+  ok = ok && hipMalloc(&c->dmean, B * (size_t)std::max(max_m, 1) * c->esz) == hipSuccess;
+  ok = ok && hipMalloc(&c->dvar, B * (size_t)std::max(max_m, 1) * c->esz) == hipSuccess;
+  ok = ok && hipMalloc(&c->dalpha, B * c->alpha_stride * c->esz) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->dtheta, B * CGP_MAX_THETA * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->djitter, B * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->dlogml, B * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->dinfo, B * sizeof(int)) == hipSuccess;
+  if (!ok) {
+    cgp_destroy(c);
+    return nullptr;
+  }
+  return c;
+}
+
+void cgp_destroy(cgp_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto &r : c->recs) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  for (auto e : c->pool) (void)hipEventDestroy(e);
+  void *bufs[] = {c->Lw, c->Dinv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo};
+  for (void *p : bufs)
+    if (p) (void)hipFree(p);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int cgp_profile_enable(cgp_ctx *c, int on) {
+  if (!c) return CGP_EINVAL;
+  c->prof = on != 0;
+  return CGP_OK;
+}
+
+int cgp_profile_read(cgp_ctx *c, double ms[CGP_PROF_KERNELS], double flops[CGP_PROF_KERNELS],
+                     long long launches[CGP_PROF_KERNELS]) {
+  if (!c) return CGP_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (auto &r : c->recs) {
+    HIP_TRY(c, hipEventSynchronize(r.b));
+    float t = 0;
+    HIP_TRY(c, hipEventElapsedTime(&t, r.a, r.b));
+    c->prof_ms[r.kernel] += t;
+    c->prof_flops[r.kernel] += r.flops;
+    c->prof_n[r.kernel] += 1;
+    c->pool.push_back(r.a);
+    c->pool.push_back(r.b);
+  }
+  c->recs.clear();
+  for (int i = 0; i < CGP_PROF_KERNELS; ++i) {
+    if (ms) ms[i] = c->prof_ms[i];
+    if (flops) flops[i] = c->prof_flops[i];
+    if (launches) launches[i] = c->prof_n[i];
+    c->prof_ms[i] = c->prof_flops[i] = 0;
+    c->prof_n[i] = 0;
+  }
+  return CGP_OK;
+}
+
+int cgp_fit_predict_batch_device(cgp_ctx *c, int batch, int N, int d, int M, int kid, const void *dX,
+                                 const void *dy, const void *dXs, const double *dtheta, const double *djitter,
+                                 int include_noise, void *dmean, void *dvar, double *dlogml, int *dinfo,
+                                 void *hip_stream) {
+  int rc = check_shape(c, batch, N, d, M, kid);
+  if (rc != CGP_OK) return rc;
+  if (!dX || !dy || !dtheta || !dlogml || !dinfo || (M > 0 && (!dXs || !dmean || !dvar))) return CGP_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  FitArgs a = base_args(c, N, d, M, kid, include_noise);
+  a.X = dX;
+  a.Xs = dXs;
+  a.y = dy;
+  a.theta = dtheta;
+  a.jitter = djitter;
+  a.mean = dmean;
+  a.var = dvar;
+  a.logml = dlogml;
+  a.info = dinfo;
+  c->have_fit = false;
+  return run(c, a, batch, true, false, hip_stream ? (hipStream_t)hip_stream : c->stream);
+}
+
+int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, const double *X, const double *y,
+                          const double *Xs, const double *theta, int theta_stride, int include_noise,
+                          double *mean, double *var, double *logml, int *info) {
+  int rc = check_shape(c, batch, N, d, M, kid);
+  if (rc != CGP_OK) return rc;
+  if (!X || !y || !theta || (M > 0 && (!Xs || !mean || !var))) return CGP_EINVAL;
+  const int nth = ntheta(kid, d);
+  if (theta_stride < nth) return CGP_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const int dt = c->dtype;
+  const size_t esz = c->esz;
+  std::vector<char> hx((size_t)batch * d * N * esz), hy((size_t)batch * N * esz),
+      hxs((size_t)batch * d * std::max(M, 1) * esz);
+  for (int b = 0; b < batch; ++b) {
+    pack_soa(X + (size_t)b * N * d, N, d, dt, hx, (size_t)b * d * N);
+    pack_vec(y + (size_t)b * N, N, dt, hy, (size_t)b * N);
+    if (M > 0) pack_soa(Xs + (size_t)b * M * d, M, d, dt, hxs, (size_t)b * d * M);
+  }
+  std::vector<double> hth, hjit(batch, 0.0);
+  HIP_TRY(c, hipMemcpyAsync(c->dX, hx.data(), hx.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemcpyAsync(c->dy, hy.data(), hy.size(), hipMemcpyHostToDevice, s));
+  if (M > 0) HIP_TRY(c, hipMemcpyAsync(c->dXs, hxs.data(), hxs.size(), hipMemcpyHostToDevice, s));
+  rc = upload_theta(c, theta, theta_stride, nth, batch, s, hth);
+  if (rc != CGP_OK) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->djitter, 0, sizeof(double) * batch, s));
+  rc = cgp_fit_predict_batch_device(c, batch, N, d, M, kid, c->dX, c->dy, c->dXs, c->dtheta, c->djitter,
+                                    include_noise, c->dmean, c->dvar, c->dlogml, c->dinfo, s);
+  if (rc != CGP_OK) return rc;
+  std::vector<int> hinfo(batch, 0);
+  HIP_TRY(c, hipMemcpyAsync(hinfo.data(), c->dinfo, sizeof(int) * batch, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  // GPy jitchol policy for the fits that failed: jitter = mean(diag) * 1e-6 * 10^k, k = 0..4,
+  // re-submitted one fit at a time (rare path) into the same device slots.
+  for (int b = 0; b < batch; ++b) {
+    if (hinfo[b] == 0) continue;
+    double jit = mean_diag(kid, theta + (size_t)b * theta_stride, d, X + (size_t)b * N * d, N) * 1e-6;
+    for (int attempt = 0; attempt < 5 && hinfo[b] != 0; ++attempt, jit *= 10.0) {
+      HIP_TRY(c, hipMemcpyAsync(c->djitter + b, &jit, sizeof(double), hipMemcpyHostToDevice, s));
+      rc = cgp_fit_predict_batch_device(
+          c, 1, N, d, M, kid, (char *)c->dX + (size_t)b * d * N * esz, (char *)c->dy + (size_t)b * N * esz,
+          (char *)c->dXs + (size_t)b * d * M * esz, c->dtheta + (size_t)b * CGP_MAX_THETA, c->djitter + b,
+          include_noise, (char *)c->dmean + (size_t)b * M * esz, (char *)c->dvar + (size_t)b * M * esz,
+          c->dlogml + b, c->dinfo + b, s);
+      if (rc != CGP_OK) return rc;
+      HIP_TRY(c, hipMemcpyAsync(&hinfo[b], c->dinfo + b, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_TRY(c, hipStreamSynchronize(s));
+      hjit[b] = jit;
+    }
+  }
+  c->fjitter = hjit[0];
+  std::vector<char> hm((size_t)batch * std::max(M, 1) * esz), hv((size_t)batch * std::max(M, 1) * esz);
+  if (M > 0) {
+    HIP_TRY(c, hipMemcpyAsync(hm.data(), c->dmean, (size_t)batch * M * esz, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hv.data(), c->dvar, (size_t)batch * M * esz, hipMemcpyDeviceToHost, s));
+  }
+  std::vector<double> hl(batch);
+  HIP_TRY(c, hipMemcpyAsync(hl.data(), c->dlogml, sizeof(double) * batch, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (M > 0) {
+    unpack_vec(hm, 0, (size_t)batch * M, dt, mean);
+    unpack_vec(hv, 0, (size_t)batch * M, dt, var);
+  }
+  int first = 0;
+  for (int b = 0; b < batch; ++b) {
+    if (logml) logml[b] = hl[b];
+    if (info) info[b] = hinfo[b];
+    if (first == 0 && hinfo[b] != 0) first = hinfo[b];
+  }
+  return first;
+}
+
+int cgp_fit(cgp_ctx *c, const double *X, const double *y, int N, int d, int kid, const double *theta, double *logml) {
+  int rc = check_shape(c, 1, N, d, 0, kid);
+  if (rc != CGP_OK) return rc;
+  if (!X || !y || !theta) return CGP_EINVAL;
+  const int nth = ntheta(kid, d);
+  int info = 0;
+  double l = 0;
+  rc = cgp_fit_predict_batch(c, 1, N, d, 0, kid, X, y, nullptr, theta, nth, 0, nullptr, nullptr, &l, &info);
+  if (rc < 0) return rc;
+  c->have_fit = (info == 0);
+  c->fN = N;
+  c->fd = d;
+  c->fkernel = kid;
+  memcpy(c->ftheta, theta, sizeof(double) * nth);
+  if (logml) *logml = l;
+  return info;
+}
+
+int cgp_predict(cgp_ctx *c, const double *Xs, int M, int include_noise, double *mean, double *var) {
+  if (!c || !Xs || !mean || !var || M < 1) return CGP_EINVAL;
+  if (!c->have_fit) return CGP_ESTATE;
+  if (M > c->max_m) return CGP_ECAPACITY;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t esz = c->esz;
+  std::vector<char> hxs((size_t)c->fd * M * esz);
+  pack_soa(Xs, M, c->fd, c->dtype, hxs, 0);
+  HIP_TRY(c, hipMemcpyAsync(c->dXs, hxs.data(), hxs.size(), hipMemcpyHostToDevice, s));
+  FitArgs a = base_args(c, c->fN, c->fd, M, c->fkernel, include_noise);
+  a.X = c->dX;
+  a.Xs = c->dXs;
+  a.y = c->dy;
+  a.theta = c->dtheta;
+  a.jitter = c->djitter;
+  a.mean = c->dmean;
+  a.var = c->dvar;
+  a.logml = c->dlogml;
+  a.info = c->dinfo;
+  int rc = run(c, a, 1, false, false, s);
+  if (rc != CGP_OK) return rc;
+  std::vector<char> hm((size_t)M * esz), hv((size_t)M * esz);
+  HIP_TRY(c, hipMemcpyAsync(hm.data(), c->dmean, hm.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(hv.data(), c->dvar, hv.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  unpack_vec(hm, 0, M, c->dtype, mean);
+  unpack_vec(hv, 0, M, c->dtype, var);
+  return CGP_OK;
+}
+
+int cgp_get_alpha(cgp_ctx *c, double *alpha) {
+  if (!c || !alpha) return CGP_EINVAL;
+  if (!c->have_fit) return CGP_ESTATE;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  // z is the y row of the factor panel; it sits at extra row index M of the LAST run.  Re-run the
+  // y row alone (M = 0) so its position is known, then back-substitute.
+  FitArgs a = base_args(c, c->fN, c->fd, 0, c->fkernel, 0);
+  a.X = c->dX;
+  a.Xs = c->dXs;
+  a.y = c->dy;
+  a.theta = c->dtheta;
+  a.jitter = c->djitter;
+  a.mean = c->dmean;
+  a.var = c->dvar;
+  a.logml = c->dlogml;
+  a.info = c->dinfo;
+  int rc = run(c, a, 1, false, true, s);
+  if (rc != CGP_OK) return rc;
+  std::vector<char> h((size_t)c->fN * c->esz);
+  HIP_TRY(c, hipMemcpyAsync(h.data(), c->dalpha, h.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  unpack_vec(h, 0, c->fN, c->dtype, alpha);
+  return CGP_OK;
+}
+
+int cgp_get_factor(cgp_ctx *c, double *L) {
+  if (!c || !L) return CGP_EINVAL;
+  if (!c->have_fit) return CGP_ESTATE;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int N = c->fN;
+  std::vector<char> h((size_t)N * N * c->esz);
+  // columns 0..N-1, rows 0..N-1 of the column-major panel -> dense (N x N) column-major staging
+  HIP_TRY(c, hipMemcpy2DAsync(h.data(), (size_t)N * c->esz, c->Lw, (size_t)c->ld * c->esz, (size_t)N * c->esz, N,
+                              hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      double v = 0;
+      if (j <= i) v = c->dtype == CGP_F64 ? reinterpret_cast<double *>(h.data())[(size_t)j * N + i]
+                                          : (double)reinterpret_cast<float *>(h.data())[(size_t)j * N + i];
+      L[(size_t)i * N + j] = v;
+    }
+  return CGP_OK;
+}
+
+int cgp_slip_node_callback(cgp_ctx *c, const double *time_array, const double *slip_array, int n, int kid,
+                           const double *theta, double *mean, double *sigma, int cap, int *m_out) {
+  if (!c || !time_array || !slip_array || !theta || !mean || !sigma || n < 2 || cap < 0) return CGP_EINVAL;
+  // gp_slip_node.py:27-29  per = 0.9 ; x_train = X[:int(per*len(X))]
+  const int ntr = (int)(0.9 * (double)n);
+  if (ntr < 1) return CGP_EINVAL;
+  // gp_slip_node.py:45  X_ = np.arange(X.min(), X.max() + 600, 1)
+  double xmin = time_array[0], xmax = time_array[0];
+  for (int i = 1; i < n; ++i) {
+    xmin = std::min(xmin, time_array[i]);
+    xmax = std::max(xmax, time_array[i]);
+  }
+  const long long glen = (long long)std::ceil((xmax + 600.0 - xmin) / 1.0);
+  // gp_slip_node.py:59-61  means[len(X):]  (index slice)
+  const long long mo = std::max(0LL, glen - n);
+  if (m_out) *m_out = (int)mo;
+  const int M = (int)std::min<long long>(mo, cap);
+  if (M == 0) return CGP_OK;
+  std::vector<double> xs(M), var(M);
+  for (int m = 0; m < M; ++m) xs[m] = xmin + (double)(n + m);
+  int rc = cgp_fit(c, time_array, slip_array, ntr, 1, kid, theta, nullptr);
+  if (rc != CGP_OK) return rc;
+  rc = cgp_predict(c, xs.data(), M, 1, mean, var.data());
+  if (rc != CGP_OK) return rc;
+  for (int m = 0; m < M; ++m) sigma[m] = 2.0 * std::sqrt(var[m]);  // gp_slip_node.py:61
+  return CGP_OK;
+}
+
+int cgp_llh_to_enu(double lat, double lon, double h, const double init_llh[3], const double init_ecef[3], double enu[3]) {
+  if (!init_llh || !init_ecef || !enu) return CGP_EINVAL;
+  corenav::llh_to_enu(lat, lon, h, init_llh, init_ecef, enu);
+  return CGP_OK;
+}
+
+int cgp_predict_stop(const double *mean, const double *sigma, int M, const double *P, const double *Q,
+                     const double *STM, const double *Hvec, const double pos_llh[3], double arrival_time, double now,
+                     double threshold, int h_bug_compatible, const double init_llh[3], const double init_ecef[3],
+                     int *fired, double *stop_cmd, int *i_out, double *xy_err) {
+  if (!mean || !sigma || M < 0 || !P || !Q || !STM || !Hvec || !pos_llh || !init_llh || !init_ecef) return CGP_EINVAL;
+  corenav::StopPrediction r = corenav::predict_stop(mean, sigma, M, P, Q, STM, Hvec, pos_llh, arrival_time, now,
+                                                    threshold, h_bug_compatible != 0, init_llh, init_ecef);
+  if (fired) *fired = r.fired ? 1 : 0;
+  if (stop_cmd) *stop_cmd = r.stop_cmd;
+  if (i_out) *i_out = r.i;
+  if (xy_err) *xy_err = r.xy_err;
+  return CGP_OK;
+}
+
+}  // extern "C"

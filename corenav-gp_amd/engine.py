@@ -1,0 +1,204 @@
+"""ctypes binding of include/corenav_gp.h (libcorenav_gp.so).  This is the reference-side stub
+INTEGRATION.md shows for gp_slip_node.py; there is no CPU fallback -- a missing library or a
+missing GPU raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+KERNEL_SE_ISO, KERNEL_SE_ARD, KERNEL_RBF_BROWNIAN = 0, 1, 2
+F64, F32 = 0, 1
+MAX_D = 8
+MAX_THETA = MAX_D + 2
+PROF_KERNELS = 5
+PROF_NAMES = ("update", "potf2", "trsm", "finalize", "alpha")
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcorenav_gp.so")
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+
+_SIGS = {
+    "cgp_create": (_vp, [ctypes.c_int] * 6),
+    "cgp_destroy": (None, [_vp]),
+    "cgp_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "cgp_last_error": (ctypes.c_char_p, [_vp]),
+    "cgp_abi_version": (ctypes.c_int, []),
+    "cgp_fit": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp]),
+    "cgp_predict": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
+    "cgp_get_alpha": (ctypes.c_int, [_vp, _dp]),
+    "cgp_get_factor": (ctypes.c_int, [_vp, _dp]),
+    "cgp_last_jitter": (ctypes.c_double, [_vp]),
+    "cgp_slip_node_callback": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
+                                              ctypes.c_int, _ip]),
+    "cgp_fit_predict_batch": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5 + [_dp, _dp, _dp, _dp, ctypes.c_int,
+                                                                          ctypes.c_int, _dp, _dp, _dp, _ip]),
+    "cgp_fit_predict_batch_device": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5 + [_vp, _vp, _vp, _vp, _vp,
+                                                                                 ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "cgp_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "cgp_profile_read": (ctypes.c_int, [_vp, _dp, _dp, ctypes.POINTER(ctypes.c_longlong)]),
+    "cgp_llh_to_enu": (ctypes.c_int, [ctypes.c_double] * 3 + [_dp, _dp, _dp]),
+    "cgp_predict_stop": (ctypes.c_int, [_dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_double,
+                                        ctypes.c_double, ctypes.c_double, ctypes.c_int, _dp, _dp, _ip, _dp, _ip, _dp]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def load():
+    """Loads libcorenav_gp.so and binds every symbol of include/corenav_gp.h (raises if missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+class CgpError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = load().cgp_strerror(code).decode()
+        super().__init__(f"cgp error {code}: {msg}" + (f" [{detail}]" if detail else ""))
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Context:
+    """One engine context (= one GPU, one stream).  Not thread-safe."""
+
+    def __init__(self, device=0, max_n=2048, max_m=640, max_d=MAX_D, max_batch=1, dtype=F64):
+        self.lib = load()
+        self.dtype = dtype
+        self.h = self.lib.cgp_create(device, max_n, max_m, max_d, max_batch, dtype)
+        if not self.h:
+            raise RuntimeError("cgp_create failed: no usable gfx950 device or out of device memory "
+                               "(the engine has no CPU fallback)")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cgp_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise CgpError(rc, self.lib.cgp_last_error(self.h).decode())
+        return rc
+
+    # -- single window -------------------------------------------------------------------------
+    def fit(self, X, y, kernel_id, theta):
+        X = _d(X)
+        if X.ndim == 1:
+            X = X[:, None]
+        y, theta = _d(y).reshape(-1), _d(theta)
+        logml = ctypes.c_double(0.0)
+        rc = self._chk(self.lib.cgp_fit(self.h, _p(X), _p(y), X.shape[0], X.shape[1], kernel_id, _p(theta),
+                                        ctypes.byref(logml)))
+        self._n = X.shape[0]
+        return rc, logml.value
+
+    def predict(self, Xs, include_noise=True):
+        Xs = _d(Xs)
+        if Xs.ndim == 1:
+            Xs = Xs[:, None]
+        M = Xs.shape[0]
+        mean, var = np.empty(M), np.empty(M)
+        self._chk(self.lib.cgp_predict(self.h, _p(Xs), M, int(include_noise), _p(mean), _p(var)))
+        return mean, var
+
+    def alpha(self):
+        a = np.empty(self._n)
+        self._chk(self.lib.cgp_get_alpha(self.h, _p(a)))
+        return a
+
+    def factor(self):
+        L = np.empty((self._n, self._n))
+        self._chk(self.lib.cgp_get_factor(self.h, _p(L)))
+        return L
+
+    def last_jitter(self):
+        return self.lib.cgp_last_jitter(self.h)
+
+    def slip_node_callback(self, time_array, slip_array, theta, kernel_id=KERNEL_RBF_BROWNIAN, cap=4096):
+        t, s, theta = _d(time_array).reshape(-1), _d(slip_array).reshape(-1), _d(theta)
+        mean, sigma = np.empty(cap), np.empty(cap)
+        m_out = ctypes.c_int(0)
+        rc = self._chk(self.lib.cgp_slip_node_callback(self.h, _p(t), _p(s), len(t), kernel_id, _p(theta), _p(mean),
+                                                       _p(sigma), cap, ctypes.byref(m_out)))
+        if rc > 0:
+            raise CgpError(rc)
+        m = min(m_out.value, cap)
+        return mean[:m].copy(), sigma[:m].copy()
+
+    # -- batch, host buffers -------------------------------------------------------------------
+    def fit_predict_batch(self, X, y, Xs, theta, kernel_id, include_noise=True):
+        X, y, Xs, theta = _d(X), _d(y), _d(Xs), _d(theta)
+        B, N, d = X.shape
+        M = Xs.shape[1]
+        mean, var = np.empty((B, M)), np.empty((B, M))
+        logml, info = np.empty(B), np.zeros(B, dtype=np.int32)
+        rc = self._chk(self.lib.cgp_fit_predict_batch(self.h, B, N, d, M, kernel_id, _p(X), _p(y), _p(Xs), _p(theta),
+                                                      theta.shape[1], int(include_noise), _p(mean), _p(var),
+                                                      _p(logml), info.ctypes.data_as(_ip)))
+        return rc, mean, var, logml, info
+
+    # -- batch, device pointers (ints) on a caller stream ------------------------------------------
+    def fit_predict_batch_device(self, B, N, d, M, kernel_id, dX, dy, dXs, dtheta, djitter, include_noise, dmean,
+                                 dvar, dlogml, dinfo, stream=0):
+        return self._chk(self.lib.cgp_fit_predict_batch_device(self.h, B, N, d, M, kernel_id, dX, dy, dXs, dtheta,
+                                                               djitter or None, int(include_noise), dmean, dvar,
+                                                               dlogml, dinfo, stream or None))
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.cgp_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        ms, fl = np.zeros(PROF_KERNELS), np.zeros(PROF_KERNELS)
+        n = np.zeros(PROF_KERNELS, dtype=np.int64)
+        self._chk(self.lib.cgp_profile_read(self.h, _p(ms), _p(fl), n.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
+        return {PROF_NAMES[i]: {"ms": float(ms[i]), "flops": float(fl[i]), "launches": int(n[i])}
+                for i in range(PROF_KERNELS)}
+
+
+INIT_LLH = (0.693457963620326, -1.39498384275845, 334.993517334743)   # init_params.yaml:13-16
+INIT_ECEF = (859153.0153, -4836303.7266, 4055378.501)                  # init_params.yaml:9-12
+
+
+def llh_to_enu(lat, lon, h, init_llh=INIT_LLH, init_ecef=INIT_ECEF):
+    out = np.empty(3)
+    rc = load().cgp_llh_to_enu(lat, lon, h, _p(_d(init_llh)), _p(_d(init_ecef)), _p(out))
+    if rc:
+        raise CgpError(rc)
+    return out
+
+
+def predict_stop(mean, sigma, PvecData, QvecData, STMvecData, HvecData, pos_llh, arrival_time=0.0, now=0.0,
+                 threshold=3.0, h_bug_compatible=True, init_llh=INIT_LLH, init_ecef=INIT_ECEF):
+    mean, sigma = _d(mean), _d(sigma)
+    fired, i = ctypes.c_int(0), ctypes.c_int(0)
+    cmd, xy = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    rc = load().cgp_predict_stop(_p(mean), _p(sigma), len(mean), _p(_d(PvecData)), _p(_d(QvecData)),
+                                 _p(_d(STMvecData)), _p(_d(HvecData)), _p(_d(pos_llh)), arrival_time, now, threshold,
+                                 int(h_bug_compatible), _p(_d(init_llh)), _p(_d(init_ecef)), ctypes.byref(fired),
+                                 ctypes.byref(cmd), ctypes.byref(i), ctypes.byref(xy))
+    if rc:
+        raise CgpError(rc)
+    return bool(fired.value), cmd.value, i.value, xy.value

@@ -1,0 +1,188 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+the oracle on the same seeded inputs, against the committed golden fixtures, and through
+size-independent properties at BASELINE.json's full sizes.  Tolerances are north_star's:
+1e-6 relative in fp64, 1e-3 in fp32."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import gp_oracle as go
+import corenav_gp_amd.synth as synth
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-6   # BASELINE.json north_star: "within 1e-6 relative fp64"
+TOL32 = 1e-3   # "(1e-3 fp32)"
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import corenav_gp_amd.engine as e
+    e.load()      # raises if libcorenav_gp.so is missing: no fallback
+    return e
+
+
+def relmax(a, b):
+    """max |a-b| / max|b| : error relative to the vector's scale (means cross zero)."""
+    return float(np.max(np.abs(np.asarray(a) - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def releach(a, b):
+    return float(np.max(np.abs(np.asarray(a) - b) / np.abs(b)))
+
+
+def check_fit_predict(engine, kid, theta, X, y, Xs, dtype, tol, include_noise=True):
+    N, d = X.shape
+    ctx = engine.Context(max_n=N, max_m=max(Xs.shape[0], 1), max_d=d, max_batch=1, dtype=dtype)
+    rc, logml = ctx.fit(X, y, kid, theta)
+    assert rc == 0
+    mean, var = ctx.predict(Xs, include_noise)
+    f = go.fit(kid, theta, X, y)
+    omu, ovar = go.predict(f, Xs, include_noise)
+    assert relmax(mean, omu) < tol
+    assert releach(var, ovar) < tol
+    assert abs(logml - f.logml) <= tol * abs(f.logml)
+    return ctx, f
+
+
+SK = ["sk_se_iso_n256_d3", "sk_se_ard_n2_d1", "sk_se_ard_n15_d3", "sk_se_ard_n134_d6", "sk_se_ard_n256_d6",
+      "closed_n1_se", "closed_n2_rbfbrownian"]
+
+
+@pytest.mark.parametrize("name", SK)
+def test_golden_fp64(engine, name):
+    g = load_golden(name)
+    X, y, Xs = g["X"], g["y"], g["Xs"]
+    ctx = engine.Context(max_n=X.shape[0], max_m=Xs.shape[0], max_d=X.shape[1])
+    rc, logml = ctx.fit(X, y, int(g["kernel_id"]), g["theta"])
+    assert rc == 0
+    mean, var = ctx.predict(Xs, include_noise=False)
+    assert relmax(mean, g["mean"]) < TOL64
+    assert np.max(np.abs(var - g["var_latent"]) / np.maximum(g["var_latent"], 1e-12)) < TOL64
+    assert abs(logml - float(g["logml"])) <= TOL64 * abs(float(g["logml"]))
+    if "alpha" in g:
+        assert relmax(ctx.alpha(), g["alpha"]) < TOL64
+
+
+@pytest.mark.parametrize("name", ["slipval_window_rbfbrownian", "synth_window_rbfbrownian"])
+def test_node_callback_golden(engine, name):
+    """The reference operating point: n = 149 ticks -> 134 training points, RBF x Brownian, d = 1,
+    599 published predictions (gp_slip_node.py:16-63)."""
+    g = load_golden(name)
+    ctx = engine.Context(max_n=256, max_m=1024, max_d=1)
+    mean, sigma = ctx.slip_node_callback(g["time_array"], g["slip_array"], g["theta"])
+    assert mean.shape == (599,) and sigma.shape == (599,)
+    assert relmax(mean, g["mean"]) < TOL64
+    assert releach(sigma, g["sigma"]) < TOL64
+
+
+def test_node_mirror_class(engine):
+    from corenav_gp_amd import gp_slip_node as node
+    g = load_golden("synth_window_rbfbrownian")
+    got = []
+    n = node.GpSlipNode(theta=g["theta"], publisher=got.append)
+    out = n.callback(node.GP_Input(g["time_array"], g["slip_array"]))
+    assert len(got) == 1 and got[0] is out
+    assert relmax(out.mean, g["mean"]) < TOL64 and releach(out.sigma, g["sigma"]) < TOL64
+    assert node.SUB_TOPIC == "/core_nav/core_nav/gp_input" and node.PUB_TOPIC == "/core_nav/core_nav/gp_result"
+
+
+@pytest.mark.parametrize("N,d,M,kid", [(1, 1, 1, 0), (2, 1, 3, 2), (15, 1, 20, 2), (127, 3, 5, 1), (128, 3, 130, 1),
+                                       (129, 2, 127, 0), (134, 1, 748, 2), (300, 6, 64, 1), (513, 8, 257, 1)])
+def test_ragged_shapes_fp64(engine, N, d, M, kid):
+    """Edge shapes: below / at / above the 128 tile, N = 1, the 16-sample minimum window, max d."""
+    rng = np.random.default_rng(100 * N + d)
+    if kid == 2:
+        X = (11 + np.arange(N, dtype=float))[:, None]
+        Xs = (11 + N + np.arange(M, dtype=float))[:, None]
+        theta = np.array([0.5, 30.0, 0.01, 0.002])
+    else:
+        X, Xs = rng.normal(size=(N, d)), rng.normal(size=(M, d))
+        theta = np.concatenate([[0.8], rng.uniform(0.6, 2.0, 1 if kid == 0 else d), [0.02]])
+    y = 0.1 * np.sin(np.arange(N) / 7.0) + 0.03 * rng.normal(size=N)
+    check_fit_predict(engine, kid, theta, X, y, Xs, engine.F64, TOL64)
+
+
+def test_factor_and_alpha_properties(engine):
+    kid, X, y, Xs, th, _ = synth.config(1)       # N=256 d=3 SE-iso (configs[0])
+    ctx, f = check_fit_predict(engine, kid, th[0], X[0], y[0], Xs[0], engine.F64, TOL64)
+    L = ctx.factor()
+    Ky = go.kernel_K(kid, th[0], X[0]) + (th[0][-1] + 1e-8) * np.eye(256)
+    assert np.max(np.abs(L @ L.T - Ky)) < 1e-12 * np.max(np.abs(Ky)) * 256
+    assert np.allclose(np.triu(L, 1), 0.0)
+    a = ctx.alpha()
+    assert relmax(a, f.alpha) < TOL64
+    assert np.max(np.abs(Ky @ a - y[0])) < 1e-8
+
+
+def test_config2_full_size_fp64(engine):
+    """BASELINE configs[1]: single GP fit N=2048 d=6 ARD fp64, M=599 -- oracle comparison plus
+    size-independent properties (L L^T = Ky through alpha, var >= noise, logML identity)."""
+    kid, X, y, Xs, th, _ = synth.config(2)
+    ctx, f = check_fit_predict(engine, kid, th[0], X[0], y[0], Xs[0], engine.F64, TOL64)
+    a = ctx.alpha()
+    Ky = go.kernel_K(kid, th[0], X[0]) + (th[0][-1] + 1e-8) * np.eye(2048)
+    assert np.max(np.abs(Ky @ a - y[0])) < 1e-7 * np.max(np.abs(y[0]))
+    mean, var = ctx.predict(Xs[0], include_noise=True)
+    assert np.all(var >= th[0][-1])
+    mean2, var2 = ctx.predict(Xs[0][::-1].copy(), include_noise=True)   # permutation of the test set
+    assert relmax(mean2[::-1], mean) < 1e-12 and releach(var2[::-1], var) < 1e-12
+
+
+def test_batch_matches_single_and_oracle(engine):
+    kid, X, y, Xs, th, _ = synth.config(2, batch=3, N=384)
+    ctx = engine.Context(max_n=384, max_m=599, max_d=6, max_batch=3)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not info.any()
+    for b in range(3):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        assert relmax(mean[b], omu) < TOL64 and releach(var[b], ovar) < TOL64
+        assert abs(logml[b] - f.logml) <= TOL64 * abs(f.logml)
+    # bitwise reproducibility of the batched path vs a batch of one (same kernels, same order)
+    ctx1 = engine.Context(max_n=384, max_m=599, max_d=6, max_batch=1)
+    rc, m1, v1, l1, _ = ctx1.fit_predict_batch(X[1:2], y[1:2], Xs[1:2], th[1:2], kid)
+    assert np.array_equal(m1[0], mean[1]) and np.array_equal(v1[0], var[1]) and l1[0] == logml[1]
+
+
+def test_config3_fp32_batch(engine):
+    """BASELINE configs[2] shape (N=1024 d=6 fp32), small batch; fp32 tolerance 1e-3."""
+    kid, X, y, Xs, th, _ = synth.config(3, batch=2)
+    ctx = engine.Context(max_n=1024, max_m=599, max_d=6, max_batch=2, dtype=engine.F32)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not info.any()
+    for b in range(2):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        assert relmax(mean[b], omu) < TOL32 and releach(var[b], ovar) < TOL32
+        assert abs(logml[b] - f.logml) <= TOL32 * abs(f.logml)
+
+
+def test_jitter_policy_and_failure(engine):
+    """GPy jitchol: a matrix that is not PD gets mean(diag)*1e-6*10^k; hopeless input returns info."""
+    X = np.zeros((40, 1))
+    X[:, 0] = np.repeat(np.arange(20.0), 2)              # duplicated inputs -> rank-deficient K
+    y = np.sin(X[:, 0])
+    theta = np.array([1.0, 3.0, -1e-8 - 2e-7])           # noise + 1e-8 = -2e-7: slightly indefinite
+    ctx = engine.Context(max_n=64, max_m=8, max_d=1)
+    rc, logml = ctx.fit(X, y, 0, theta)
+    try:
+        f = go.fit(0, theta, X, y)
+        assert rc == 0
+        assert ctx.last_jitter() == pytest.approx(f.jitter, rel=1e-12) and f.jitter > 0
+    except np.linalg.LinAlgError:
+        assert rc > 0
+    rc, _ = ctx.fit(X, y, 0, np.array([1.0, 3.0, -5.0]))   # hopeless: info > 0 after 5 retries
+    assert rc > 0
+    with pytest.raises(engine.CgpError):
+        ctx.predict(np.zeros((2, 1)))                      # no fitted model -> CGP_ESTATE
+
+
+def test_argument_errors(engine):
+    ctx = engine.Context(max_n=64, max_m=8, max_d=2)
+    with pytest.raises(engine.CgpError) as ei:
+        ctx.fit(np.zeros((65, 1)), np.zeros(65), 0, np.array([1.0, 1.0, 0.1]))
+    assert ei.value.code == -6
+    with pytest.raises(engine.CgpError) as ei:
+        ctx.fit(np.zeros((8, 2)), np.zeros(8), 2, np.array([1.0, 1.0, 0.1, 0.1]))   # Brownian needs d == 1
+    assert ei.value.code == -1

@@ -1,0 +1,95 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/corenav_gp.h declares, and
+the host-side (non-GPU) entry points -- GpPredictor look-ahead, llh_to_enu, argument checking --
+match the oracle.  No GPU compute is attempted here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from oracle import gp_oracle as go
+
+engine = pytest.importorskip("corenav_gp_amd.engine")
+if not os.path.exists(engine.LIB_PATH):
+    import __graft_entry__ as ge
+    ge.build()
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "corenav_gp.h")).read()
+    declared = set(re.findall(r"\b(cgp_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"cgp_ctx"}
+    lib = engine.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in corenav_gp.h but not exported"
+    assert declared == set(engine.EXPORTS), declared ^ set(engine.EXPORTS)
+    assert lib.cgp_abi_version() == 1
+
+
+def test_no_device_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.Context()
+
+
+def test_strerror():
+    lib = engine.load()
+    assert lib.cgp_strerror(0) == b"ok"
+    assert b"positive definite" in lib.cgp_strerror(17)
+    assert b"invalid" in lib.cgp_strerror(-1)
+
+
+def test_llh_to_enu_matches_oracle():
+    g = load_golden("llh_to_enu_restated")
+    np.testing.assert_allclose(engine.llh_to_enu(*g["llh"]), g["enu"], rtol=1e-12, atol=1e-9)
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        llh = np.array(go.INIT_LLH) + rng.normal(0, [1e-5, 1e-5, 30.0])
+        np.testing.assert_allclose(engine.llh_to_enu(*llh), go.llh_to_enu(*llh), rtol=1e-11, atol=1e-8)
+
+
+@pytest.mark.parametrize("bug", [True, False])
+def test_predict_stop_matches_oracle(bug):
+    g = load_golden("lookahead_restated")
+    H = go.unpack_H(g["HvecData"], bug) if bug else g["H_true"]
+    hvec = g["HvecData"] if bug else g["H_true"].reshape(60)
+    exp = go.predict_stop(g["mean"], g["sigma"], g["PvecData"], g["QvecData"], g["STMvecData"], H, g["PosData"],
+                          float(g["arrival_time"]), float(g["now"]))
+    got = engine.predict_stop(g["mean"], g["sigma"], g["PvecData"], g["QvecData"], g["STMvecData"], hvec,
+                              g["PosData"], float(g["arrival_time"]), float(g["now"]), h_bug_compatible=bug)
+    assert got[0] == exp[0] and got[2] == exp[2]
+    assert got[1] == pytest.approx(exp[1], rel=1e-12)
+    assert got[3] == pytest.approx(exp[3], rel=1e-9)
+    if bug:
+        assert got[2] == int(g["i"]) and got[1] == pytest.approx(float(g["stop_cmd"]), rel=1e-12)
+
+
+def test_predict_stop_edge_cases():
+    g = load_golden("lookahead_restated")
+    args = (g["PvecData"], g["QvecData"], g["STMvecData"], g["HvecData"], g["PosData"])
+    # empty horizon: loop body never runs (gp_predictor.cpp:64), nothing published
+    fired, cmd, i, xy = engine.predict_stop(np.zeros(0), np.zeros(0), *args)
+    assert not fired and i == 0
+    # late result -> immediate stop 0.5 s (gp_predictor.cpp:107-111)
+    fired, cmd, i, xy = engine.predict_stop(g["mean"], g["sigma"], *args, arrival_time=0.0, now=1e6)
+    assert fired and cmd == 0.5
+    # huge threshold: never fires, consumes the whole horizon
+    fired, cmd, i, xy = engine.predict_stop(g["mean"], g["sigma"], *args, threshold=1e9)
+    assert not fired and i == len(g["mean"])
+    exp = go.predict_stop(g["mean"], g["sigma"], g["PvecData"], g["QvecData"], g["STMvecData"],
+                          go.unpack_H(g["HvecData"]), g["PosData"], threshold=1e9)
+    assert xy == pytest.approx(exp[3], rel=1e-8)
+
+
+def test_synth_generator_is_deterministic():
+    import corenav_gp_amd.synth as synth
+    k1 = synth.config(2, batch=2, N=256)
+    k2 = synth.config(2, batch=2, N=256)
+    for a, b in zip(k1[1:5], k2[1:5]):
+        np.testing.assert_array_equal(a, b)
+    assert k1[1].shape == (2, 256, 6) and k1[3].shape == (2, 599, 6)
+    t, s = synth.reference_window()
+    assert len(t) == 149 and np.all(np.diff(t) == 1) and np.all(np.abs(s) < 1)
