@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--n", type=int, default=None, help="override window length N")
     ap.add_argument("--cpu-sample", type=int, default=6, help="fits timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--streams", type=int, default=4, help="worker streams the batch is spread over")
     args = ap.parse_args()
 
     import torch
@@ -85,6 +86,7 @@ def main():
     dinfo = torch.zeros(B, device=dev, dtype=torch.int32)
 
     ctx = engine.Context(device=local, max_n=N, max_m=M_TEST, max_d=d, max_batch=B, dtype=dtype)
+    ctx.set_streams(args.streams)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -142,7 +144,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": dts, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: batch of independent fixed-theta GP fits, "
                                    f"N={N} d={d} M={M_TEST} kernel={'SE-ARD' if kid == 1 else 'SE-iso'} {dts}",
-                       "fits_per_gpu_per_step": B, "N": N, "d": d, "M": M_TEST,
+                       "fits_per_gpu_per_step": B, "streams": args.streams, "N": N, "d": d, "M": M_TEST,
                        "fit_tflops": value * f_fit / 1e12, "cholesky_roofline_frac": value * f_chol / 1e12 / world / peak,
                        "inputs": "resident in HBM"},
             "roofline": {"bound": "mfma", "kernel": "k_update (syrk/gemm trailing update + fused Gram)",

@@ -33,12 +33,18 @@ struct cgp_ctx {
   int NTmax = 0, ETmax = 0, ld = 0;
   size_t esz = 8;
   hipStream_t stream = nullptr;
+  // worker streams: a batch is cut into groups whose schedules run concurrently, so the
+  // one-workgroup-per-fit potf2 launches of one group overlap the MFMA launches of the others
+  static constexpr int kMaxStreams = 8;
+  hipStream_t wstream[kMaxStreams] = {nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr};
+  int nstreams = 4;
   // device buffers
-  void *Lw = nullptr, *Dinv = nullptr, *dX = nullptr, *dXs = nullptr, *dy = nullptr;
+  void *Lw = nullptr, *Winv = nullptr, *dX = nullptr, *dXs = nullptr, *dy = nullptr;
   void *dmean = nullptr, *dvar = nullptr, *dalpha = nullptr;
   double *dtheta = nullptr, *djitter = nullptr, *dlogml = nullptr;
   int *dinfo = nullptr;
-  size_t lw_stride = 0, dinv_stride = 0, alpha_stride = 0;
+  size_t lw_stride = 0, winv_stride = 0, alpha_stride = 0;
   // state of the last single fit (cgp_fit -> cgp_predict)
   bool have_fit = false;
   int fN = 0, fd = 0, fkernel = 0;
@@ -97,14 +103,18 @@ struct Launcher {
   }
 };
 
+template <typename T> constexpr int upd_lds_bytes() { return 4 * KT * LDST * (int)sizeof(T); }
+template <typename T> constexpr int potf2_lds_bytes() {
+  return (TS * LDP + 8 * DB * DB + 4 * DB * DB) * (int)sizeof(T) + 16;
+}
+
 template <typename T> int set_lds_attrs() {
   static bool done = false;
   if (done) return 0;
-  const int upd = 4 * KT * LDST * (int)sizeof(T);
-  const int tile = TS * LDA_P * (int)sizeof(T);
+  const int upd = upd_lds_bytes<T>(), tile = potf2_lds_bytes<T>();
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trsm<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trmm<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
   done = true;
   return 0;
 }
@@ -123,42 +133,93 @@ double trsm_flops(int N, int M, int k, bool in_rows, int batch) {
   return batch * rows * w * w;  // w^2/2 multiply-adds per row
 }
 
-// Enqueue the whole schedule for `batch` fits on stream s.  in_rows = false: predict after fit.
+// Offsets every per-fit pointer of `a` by g0 fits (group view of a batch).
+template <typename T> FitArgs group_view(const FitArgs &a, int g0) {
+  FitArgs v = a;
+  auto adv = [](const void *p, size_t elems) -> const void * {
+    return p ? static_cast<const void *>(static_cast<const T *>(p) + elems) : nullptr;
+  };
+  v.Lw = const_cast<void *>(adv(a.Lw, (size_t)g0 * a.lw_stride));
+  v.Winv = const_cast<void *>(adv(a.Winv, (size_t)g0 * a.winv_stride));
+  v.X = adv(a.X, (size_t)g0 * a.d * a.N);
+  v.Xs = adv(a.Xs, (size_t)g0 * a.d * a.M);
+  v.y = adv(a.y, (size_t)g0 * a.N);
+  v.mean = const_cast<void *>(adv(a.mean, (size_t)g0 * a.M));
+  v.var = const_cast<void *>(adv(a.var, (size_t)g0 * a.M));
+  v.alpha = const_cast<void *>(adv(a.alpha, (size_t)g0 * a.alpha_stride));
+  v.theta = a.theta + (size_t)g0 * MAX_THETA;
+  v.jitter = a.jitter ? a.jitter + g0 : nullptr;
+  v.logml = a.logml ? a.logml + g0 : nullptr;
+  v.info = a.info ? a.info + g0 : nullptr;
+  return v;
+}
+
+// Enqueue the whole schedule for `batch` fits.  The batch is cut into up to c->nstreams contiguous
+// groups, one worker stream each, forked from / joined to the caller's stream `s` with events; the
+// launches are issued step-interleaved so every stream always has work queued.
+// in_rows = false: predict after fit (only the extra row tiles).
 template <typename T>
 int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha, hipStream_t s) {
   if (set_lds_attrs<T>() != 0) {
     c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
     return CGP_EHIP;
   }
-  Launcher L{c, s};
   a.rows_from_extra = in_rows ? 0 : 1;
-  const int upd_lds = 4 * KT * LDST * (int)sizeof(T);
-  const int tile_lds = TS * LDA_P * (int)sizeof(T);
-  if (in_rows) HIP_TRY(c, hipMemsetAsync(a.info, 0, sizeof(int) * batch, s));
+  const int upd_lds = upd_lds_bytes<T>();
+  const int tile_lds = potf2_lds_bytes<T>();
+  int G = std::max(1, std::min(std::min(c->nstreams, (int)cgp_ctx::kMaxStreams), batch));
+  if (c->prof || !in_rows) G = 1;  // per-kernel timing wants isolated launches
+  std::vector<FitArgs> ga(G);
+  std::vector<int> gb(G);
+  std::vector<hipStream_t> gs(G);
+  for (int g = 0, g0 = 0; g < G; ++g) {
+    gb[g] = batch / G + (g < batch % G ? 1 : 0);
+    ga[g] = group_view<T>(a, g0);
+    gs[g] = (G == 1) ? s : c->wstream[g];
+    g0 += gb[g];
+  }
+  if (G > 1) {
+    HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+    for (int g = 0; g < G; ++g) HIP_TRY(c, hipStreamWaitEvent(gs[g], c->ev_fork, 0));
+  }
+  std::vector<Launcher> L;
+  for (int g = 0; g < G; ++g) L.push_back(Launcher{c, gs[g]});
+  if (in_rows)
+    for (int g = 0; g < G; ++g) HIP_TRY(c, hipMemsetAsync(ga[g].info, 0, sizeof(int) * gb[g], gs[g]));
   for (int k = 0; k < a.NT; ++k) {
     const int gx_u = (in_rows ? a.NT - k : 0) + a.ET;
-    L.begin(0, update_flops(a.N, a.M, a.d, k, in_rows, batch));
-    hipLaunchKernelGGL(k_update<T>, dim3(gx_u, batch), dim3(256), upd_lds, s, a, k);
-    L.end();
-    if (in_rows) {
-      L.begin(1, batch * (double)TS * TS * TS / 3.0);
-      hipLaunchKernelGGL(k_potf2<T>, dim3(batch), dim3(256), tile_lds, s, a, k);
-      L.end();
-    }
     const int gx_t = (in_rows ? a.NT - k - 1 : 0) + a.ET;
-    L.begin(2, trsm_flops(a.N, a.M, k, in_rows, batch));
-    hipLaunchKernelGGL(k_trsm<T>, dim3(gx_t, batch), dim3(256), tile_lds, s, a, k);
-    L.end();
+    for (int g = 0; g < G; ++g) {
+      L[g].begin(0, update_flops(a.N, a.M, a.d, k, in_rows, gb[g]));
+      hipLaunchKernelGGL(k_update<T>, dim3(gx_u, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
+      L[g].end();
+      if (in_rows) {
+        L[g].begin(1, gb[g] * (double)TS * TS * TS / 3.0);
+        hipLaunchKernelGGL(k_potf2<T>, dim3(gb[g]), dim3(256), tile_lds, gs[g], ga[g], k);
+        L[g].end();
+      }
+      L[g].begin(2, trsm_flops(a.N, a.M, k, in_rows, gb[g]));
+      hipLaunchKernelGGL(k_trmm<T>, dim3(gx_t, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
+      L[g].end();
+    }
   }
-  L.begin(3, batch * (4.0 * a.M * a.N + 2.0 * a.N));
-  hipLaunchKernelGGL(k_finalize<T>, dim3(cdiv(a.M, 64) + 1, batch), dim3(256), 0, s, a, in_rows ? 1 : 0);
-  L.end();
-  if (want_alpha) {
-    L.begin(4, batch * (double)a.N * a.N);
-    hipLaunchKernelGGL(k_alpha<T>, dim3(batch), dim3(256), (a.NT * TS + TS) * sizeof(double), s, a);
-    L.end();
+  for (int g = 0; g < G; ++g) {
+    L[g].begin(3, gb[g] * (4.0 * a.M * a.N + 2.0 * a.N));
+    hipLaunchKernelGGL(k_finalize<T>, dim3(cdiv(a.M, 64) + 1, gb[g]), dim3(256), 0, gs[g], ga[g], in_rows ? 1 : 0);
+    L[g].end();
+    if (want_alpha) {
+      L[g].begin(4, gb[g] * (double)a.N * a.N);
+      hipLaunchKernelGGL(k_alpha<T>, dim3(gb[g]), dim3(256), (a.NT * TS + TS) * sizeof(double), gs[g], ga[g]);
+      L[g].end();
+    }
   }
   HIP_TRY(c, hipGetLastError());
+  if (G > 1) {
+    for (int g = 0; g < G; ++g) {
+      HIP_TRY(c, hipEventRecord(c->ev_join[g], gs[g]));
+      HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[g], 0));
+    }
+  }
   return CGP_OK;
 }
 
@@ -172,8 +233,8 @@ FitArgs base_args(cgp_ctx *c, int N, int d, int M, int kid, int include_noise) {
   a.Lw = c->Lw;
   a.lw_stride = c->lw_stride;
   a.ld = c->ld;
-  a.Dinv = c->Dinv;
-  a.dinv_stride = c->dinv_stride;
+  a.Winv = c->Winv;
+  a.winv_stride = c->winv_stride;
   a.alpha = c->dalpha;
   a.alpha_stride = c->alpha_stride;
   a.N = N;
@@ -280,12 +341,17 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   c->ETmax = cdiv(max_m + 1, TS);
   c->ld = (c->NTmax + c->ETmax) * TS;
   c->lw_stride = (size_t)c->ld * c->NTmax * TS;
-  c->dinv_stride = (size_t)c->NTmax * 8 * DB * DB;
+  c->winv_stride = (size_t)c->NTmax * TS * TS;
   c->alpha_stride = (size_t)c->NTmax * TS;
   const size_t B = max_batch;
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {
+    ok = ok && hipStreamCreateWithFlags(&c->wstream[i], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
+  }
+  ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc(&c->Lw, B * c->lw_stride * c->esz) == hipSuccess;
-  ok = ok && hipMalloc(&c->Dinv, B * c->dinv_stride * c->esz) == hipSuccess;
+  ok = ok && hipMalloc(&c->Winv, B * c->winv_stride * c->esz) == hipSuccess;
   ok = ok && hipMalloc(&c->dX, B * max_d * max_n * c->esz) == hipSuccess;
   ok = ok && hipMalloc(&c->dXs, B * max_d * (size_t)std::max(max_m, 1) * c->esz) == hipSuccess;
   ok = ok && hipMalloc(&c->dy, B * max_n * c->esz) == hipSuccess;
@@ -312,11 +378,25 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Dinv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
+  for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {
+    if (c->wstream[i]) {
+      (void)hipStreamSynchronize(c->wstream[i]);
+      (void)hipStreamDestroy(c->wstream[i]);
+    }
+    if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+int cgp_set_streams(cgp_ctx *c, int n) {
+  if (!c || n < 1 || n > cgp_ctx::kMaxStreams) return CGP_EINVAL;
+  c->nstreams = n;
+  return CGP_OK;
 }
 
 int cgp_profile_enable(cgp_ctx *c, int on) {

@@ -11,8 +11,8 @@
 // This replaces GPy's kern.K / jitchol(dpotrf) / dpotrs / dpotri / predict chain that
 // gp_slip_node.py:31-49 reaches with three kernels per 128-column block step:
 //   k_update : S(i,k) = Gram(i,k) - sum_{j<k} L(i,j) L(k,j)^T     fp64/fp32 MFMA 16x16x4, LDS-tiled
-//   k_potf2  : S(k,k) = L(k,k) L(k,k)^T  + inverses of its eight 16x16 diagonal blocks
-//   k_trsm   : L(i,k) = S(i,k) L(k,k)^-T   (blocked substitution)
+//   k_potf2  : S(k,k) = L(k,k) L(k,k)^T  and  W_k = L(k,k)^-1        one workgroup per fit, LDS-resident
+//   k_trmm   : L(i,k) = S(i,k) W_k^T                                   triangular MFMA product
 // and k_finalize for mean / variance / log marginal likelihood, k_alpha for alpha = L^-T z.
 //
 // Storage: Lw is column-major, leading dimension ld (multiple of 128), one slab per fit.
@@ -31,7 +31,7 @@ constexpr int LDST = 144;  // LDS row stride of a staged chunk (elements): (144*
 constexpr int DB = 16;     // diagonal sub-block of potf2 / trsm
 constexpr int MAXD = 8;
 constexpr int MAX_THETA = MAXD + 2;
-constexpr int LDA_P = TS + 1;  // padded LDS leading dimension of the potf2 / trsm tile
+constexpr int LDP = TS + 2;   // LDS leading dimension of the potf2 tile (2-way conflicts at most)
 
 enum { K_SE_ISO = 0, K_SE_ARD = 1, K_RBF_BROWNIAN = 2 };
 
@@ -44,8 +44,8 @@ struct FitArgs {
   const void *y;         // [batch][N]
   const double *theta;   // [batch][MAX_THETA]
   const double *jitter;  // [batch] or nullptr
-  void *Dinv;            // [batch][NTmax][8][16*16]
-  size_t dinv_stride;    // elements per fit
+  void *Winv;            // [batch][NTmax][128*128]  W_k = L(k,k)^-1, column-major, lower triangular
+  size_t winv_stride;    // elements per fit
   int *info;             // [batch]
   void *mean, *var;      // [batch][M]
   double *logml;         // [batch]
@@ -87,18 +87,28 @@ __device__ __forceinline__ int row_tile_of(int t, int first_in, int NT, int rows
   return (t < nin) ? first_in + t : NT + (t - nin);
 }
 
+// readlane for scalars of either precision (lane index must be wave-uniform)
+__device__ __forceinline__ float rdlane(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ double rdlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 // --------------------------------------------------------------------------------------------------
-// Covariance entry.  SE kernels get inputs pre-divided by the length-scales (xr, xc are scaled);
-// RBF x Brownian follows GPy's r^2 = x^2 + x'^2 - 2xx' clipped at 0 (diag forced to 0) on raw x.
+// Covariance entry on zero-padded MAXD-vectors.  SE kernels get inputs pre-divided by the
+// length-scales; RBF x Brownian follows GPy's r^2 = x^2 + x'^2 - 2xx' clipped at 0 (auto-covariance
+// diagonal forced to 0) on the raw tick value.
 // --------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ T cov_entry(int kid, int d, const T *xr, int rs, const T *xc, int cs, T amp,
-                                       T inv_ell, T amp_b, bool same) {
+__device__ __forceinline__ T cov_entry(int kid, const T *xr, const T *xc, T amp, T inv_ell, T amp_b, bool same) {
   if (kid != K_RBF_BROWNIAN) {
     T d2 = 0;
-#pragma unroll 1
-    for (int q = 0; q < d; ++q) {
-      const T df = xr[q * rs] - xc[q * cs];
+#pragma unroll
+    for (int q = 0; q < MAXD; ++q) {
+      const T df = xr[q] - xc[q];
       d2 += df * df;
     }
     return amp * Prec<T>::exp_(T(-0.5) * d2);
@@ -115,44 +125,35 @@ __device__ __forceinline__ T cov_entry(int kid, int d, const T *xr, int rs, cons
 }
 
 // --------------------------------------------------------------------------------------------------
-// k_update: S(rt, k) = Gram(rt, k) - sum_{j < k} L(rt, j) L(k, j)^T   (a2 gram + a3 syrk/gemm + a8)
-// grid (row tiles, batch), 256 threads = 4 waves as 2 (rows) x 2 (cols), each wave a 64x64 block
-// of 4x4 MFMA 16x16x4 accumulators.  MFMA "A" operand = rows of tile k (S columns), "B" operand =
-// rows of tile rt (S rows): lane&15 then runs along S rows, which are contiguous in memory.
+// The MFMA inner loop shared by k_update and k_trmm:
+//   acc[i][j] (+)= sum_q  Cop[cl][q] * Rop[rl][q]      over nchunk chunks of KT columns
+// Rop = "row panel" (128 rows x K), Cop = "column panel" (128 rows x K), both column-major in global
+// memory (K runs along columns, leading dimensions ldR / ldC).  256 threads = 4 waves as 2x2, each
+// wave owns a 64x64 block of the 128x128 result as 4x4 MFMA 16x16x4 accumulators:
+//   acc[i][j][reg] = C[row = wr*64 + j*16 + (lane&15)][col = wc*64 + i*16 + drow(lane,reg)]
+// (MFMA "A" operand = Cop, "B" operand = Rop, so lane&15 runs along result rows, which are
+// contiguous in the column-major destination).  Chunks are staged global -> registers -> LDS with
+// one chunk of prefetch; LDS rows are padded to LDST so the four k-groups of an operand read fall in
+// disjoint bank halves.  TRI: Cop is lower-triangular in (cl, q) (a 128x128 inverse factor), so
+// 16-column fragments whose every entry has q > cl are skipped (half the MFMAs).
 // --------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_update(FitArgs p, int k) {
+template <typename T, bool TRI>
+__device__ __forceinline__ void mfma_panel_loop(typename Prec<T>::acc_t (&acc)[4][4], const T *gR, size_t ldR,
+                                                const T *gC, size_t ldC, int nchunk, T *smem, int tid) {
   using P = Prec<T>;
-  using acc_t = typename P::acc_t;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T *smem = reinterpret_cast<T *>(smem_raw);
-  // layout: buf[2] x { rowsChunk[KT][LDST], colsChunk[KT][LDST] }
+  using vec8 = T __attribute__((ext_vector_type(8)));
   constexpr int CH = KT * LDST;
-
-  const int b = blockIdx.y;
-  const int rt = row_tile_of(blockIdx.x, k, p.NT, p.rows_from_extra);
-  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
-  const int ld = p.ld;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int l15 = lane & 15, lq = lane >> 4;
-
-  acc_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-
-  const int nchunk = (k * TS) / KT;
-  // staging map: thread -> (column sc of the chunk, 8 consecutive rows from sr)
-  const int sc = tid >> 4, sr = (tid & 15) * 8;
-  const T *gR = Lw + (size_t)rt * TS + sr;  // rows of tile rt
-  const T *gC = Lw + (size_t)k * TS + sr;   // rows of tile k
-  using vec8 = T __attribute__((ext_vector_type(8)));
+  const int sc = tid >> 4, sr = (tid & 15) * 8;  // staging: column sc of the chunk, rows sr..sr+7
+  gR += sr;
+  gC += sr;
   vec8 pr, pc;
   if (nchunk > 0) {
-    pr = *reinterpret_cast<const vec8 *>(gR + (size_t)sc * ld);
-    pc = *reinterpret_cast<const vec8 *>(gC + (size_t)sc * ld);
+    pr = *reinterpret_cast<const vec8 *>(gR + (size_t)sc * ldR);
+    pc = *reinterpret_cast<const vec8 *>(gC + (size_t)sc * ldC);
     *reinterpret_cast<vec8 *>(smem + sc * LDST + sr) = pr;
     *reinterpret_cast<vec8 *>(smem + CH + sc * LDST + sr) = pc;
   }
@@ -160,24 +161,26 @@ __global__ __launch_bounds__(256, 2) void k_update(FitArgs p, int k) {
   for (int c = 0; c < nchunk; ++c) {
     const T *cur = smem + (c & 1) * 2 * CH;
     if (c + 1 < nchunk) {
-      const size_t off = (size_t)((c + 1) * KT + sc) * ld;
-      pr = *reinterpret_cast<const vec8 *>(gR + off);
-      pc = *reinterpret_cast<const vec8 *>(gC + off);
+      pr = *reinterpret_cast<const vec8 *>(gR + (size_t)((c + 1) * KT + sc) * ldR);
+      pc = *reinterpret_cast<const vec8 *>(gC + (size_t)((c + 1) * KT + sc) * ldC);
     }
 #pragma unroll
     for (int ks = 0; ks < KT / 4; ++ks) {
       T fa[4], fb[4];
-      const T *ra = cur + CH + (ks * 4 + lq) * LDST + wc * 64 + l15;  // tile-k rows  -> S columns
-      const T *rb = cur + (ks * 4 + lq) * LDST + wr * 64 + l15;       // tile-rt rows -> S rows
+      const T *ra = cur + CH + (ks * 4 + lq) * LDST + wc * 64 + l15;  // column panel -> result columns
+      const T *rb = cur + (ks * 4 + lq) * LDST + wr * 64 + l15;       // row panel    -> result rows
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         fa[i] = ra[i * 16];
         fb[i] = rb[i * 16];
       }
+      const int q0 = c * KT + ks * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        if (TRI && q0 > wc * 64 + i * 16 + 15) continue;  // wave-uniform: whole fragment is zero
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = P::mfma(fa[i], fb[j], acc[i][j]);
+      }
     }
     if (c + 1 < nchunk) {
       T *nxt = smem + ((c + 1) & 1) * 2 * CH;
@@ -186,33 +189,67 @@ __global__ __launch_bounds__(256, 2) void k_update(FitArgs p, int k) {
     }
     __syncthreads();
   }
+}
+
+// --------------------------------------------------------------------------------------------------
+// k_update: S(rt, k) = Gram(rt, k) - sum_{j < k} L(rt, j) L(k, j)^T   (a2 gram + a3 syrk/gemm + a8)
+// grid (row tiles, batch).  The Gram tile is evaluated from the inputs in the epilogue, so Ky and
+// K* never exist in HBM.
+// --------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_update(FitArgs p, int k) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+
+  const int b = blockIdx.y;
+  const int rt = row_tile_of(blockIdx.x, k, p.NT, p.rows_from_extra);
+  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const int ld = p.ld;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l15 = lane & 15;
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+  mfma_panel_loop<T, false>(acc, Lw + (size_t)rt * TS, (size_t)ld, Lw + (size_t)k * TS, (size_t)ld,
+                            (k * TS) / KT, smem, tid);
 
   // ---- epilogue: Gram tile from the inputs, S = G - acc ----
   const double *th = p.theta + (size_t)b * MAX_THETA;
   const int kid = p.kernel_id, d = p.d, N = p.N, M = p.M;
   const bool extra = rt >= p.NT;
-  T *xr = smem;             // [d][128] rows of this tile (training rows or test rows)
-  T *xc = smem + MAXD * TS; // [d][128] columns = training rows of tile k
-  T *yc = smem + 2 * MAXD * TS;  // [128] y of tile k columns (only for the y row)
+  T *xr = smem;                    // [128][MAXD] rows of this tile (training or test points), zero padded
+  T *xc = smem + TS * MAXD;        // [128][MAXD] columns = training points of tile k
+  T *yc = smem + 2 * TS * MAXD;    // [128] y of the tile-k columns (only the y row uses it)
   const T *Xb = reinterpret_cast<const T *>(p.X) + (size_t)b * d * N;
   const T *Xsb = reinterpret_cast<const T *>(p.Xs) + (size_t)b * d * M;
   const T *yb = reinterpret_cast<const T *>(p.y) + (size_t)b * N;
-  for (int idx = tid; idx < d * TS; idx += 256) {
+  for (int idx = tid; idx < MAXD * TS; idx += 256) {
     const int q = idx >> 7, r = idx & 127;
-    T sc_q = T(1);
-    if (kid == K_SE_ISO) sc_q = T(1.0 / th[1]);
-    else if (kid == K_SE_ARD) sc_q = T(1.0 / th[1 + q]);
-    const int gc = k * TS + r;
-    xc[q * TS + r] = (gc < N) ? Xb[(size_t)q * N + gc] * sc_q : T(0);
-    T v = T(0);
-    if (!extra) {
-      const int gr = rt * TS + r;
-      if (gr < N) v = Xb[(size_t)q * N + gr] * sc_q;
-    } else {
-      const int e = (rt - p.NT) * TS + r;
-      if (e < M) v = Xsb[(size_t)q * M + e] * sc_q;
+    T vc = T(0), vr = T(0);
+    if (q < d) {
+      T sc_q = T(1);
+      if (kid == K_SE_ISO) sc_q = T(1.0 / th[1]);
+      else if (kid == K_SE_ARD) sc_q = T(1.0 / th[1 + q]);
+      const int gc = k * TS + r;
+      if (gc < N) vc = Xb[(size_t)q * N + gc] * sc_q;
+      if (!extra) {
+        const int gr = rt * TS + r;
+        if (gr < N) vr = Xb[(size_t)q * N + gr] * sc_q;
+      } else {
+        const int e = (rt - p.NT) * TS + r;
+        if (e < M) vr = Xsb[(size_t)q * M + e] * sc_q;
+      }
     }
-    xr[q * TS + r] = v;
+    xc[r * MAXD + q] = vc;
+    xr[r * MAXD + q] = vr;
   }
   if (tid < TS) {
     const int gc = k * TS + tid;
@@ -225,175 +262,246 @@ __global__ __launch_bounds__(256, 2) void k_update(FitArgs p, int k) {
   const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
   const T diag_add = T(th[nth - 1] + 1e-8 + (p.jitter ? p.jitter[b] : 0.0));
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rl = wr * 64 + j * 16 + l15;  // local S row
-    const int grow = extra ? (rt - p.NT) * TS + rl : rt * TS + rl;
+  for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int r = 0; r < 4; ++r) {
+      const int cl = wc * 64 + i * 16 + P::drow(lane, r);  // local result column
+      const int gcol = k * TS + cl;
+      T xcol[MAXD];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cl = wc * 64 + i * 16 + P::drow(lane, r);  // local S column
-        const int gcol = k * TS + cl;
-        T g;
+      for (int q = 0; q < MAXD; ++q) xcol[q] = xc[cl * MAXD + q];
+      const T ycl = yc[cl];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rl = wr * 64 + j * 16 + l15;  // local result row
+        const int grow = extra ? (rt - p.NT) * TS + rl : rt * TS + rl;
+        T xrow[MAXD];
+#pragma unroll
+        for (int q = 0; q < MAXD; ++q) xrow[q] = xr[rl * MAXD + q];
+        T g = cov_entry<T>(kid, xrow, xcol, amp, inv_ell, amp_b, !extra && grow == gcol);
         if (!extra) {
           if (grow < N && gcol < N) {
-            g = cov_entry<T>(kid, d, xr + rl, TS, xc + cl, TS, amp, inv_ell, amp_b, grow == gcol);
             if (grow == gcol) g += diag_add;
           } else {
             g = (grow == gcol) ? T(1) : T(0);  // identity padding keeps the factor well defined
           }
         } else {
           if (gcol >= N || grow > M) g = T(0);
-          else if (grow == M) g = yc[cl];
-          else g = cov_entry<T>(kid, d, xr + rl, TS, xc + cl, TS, amp, inv_ell, amp_b, false);
+          else if (grow == M) g = ycl;
         }
         Lw[(size_t)gcol * ld + (size_t)rt * TS + rl] = g - acc[i][j][r];
       }
+      __builtin_amdgcn_sched_barrier(0);  // keep the 16 column points from being software-pipelined into spills
     }
   }
 }
 
 // --------------------------------------------------------------------------------------------------
-// k_potf2: factor the 128x128 diagonal tile in LDS (a3 "potf2_diag") and invert its eight 16x16
-// diagonal blocks for k_trsm.  One workgroup per fit.  info = first non-positive pivot (1-based).
+// k_trmm: L(rt, k) = S(rt, k) W_k^T with W_k = L(k,k)^-1 from k_potf2 (a3 "trsm_panel" and, for the
+// extra tiles, a8 "trsm_var", done as a triangular MFMA product instead of a substitution).
+// grid (row tiles below k, batch).  In place: a workgroup reads only its own tile before writing it.
+// --------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_trmm(FitArgs p, int k) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  const int b = blockIdx.y;
+  const int rt = row_tile_of(blockIdx.x, k + 1, p.NT, p.rows_from_extra);
+  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const int ld = p.ld;
+  const T *Wk = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * TS * TS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l15 = lane & 15;
+  acc_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+  T *tile = Lw + (size_t)(k * TS) * ld + (size_t)rt * TS;
+  mfma_panel_loop<T, true>(acc, tile, (size_t)ld, Wk, (size_t)TS, TS / KT, smem, tid);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rl = wr * 64 + j * 16 + l15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cl = wc * 64 + i * 16 + P::drow(lane, r);
+        tile[(size_t)cl * ld + rl] = acc[i][j][r];
+      }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// k_potf2: factor the 128x128 diagonal tile (a3 "potf2_diag") and invert the factor, one workgroup
+// per fit, everything resident in LDS:
+//   for each 16-column panel:  (a) wave 0 factors the 16x16 diagonal block and inverts it in
+//       registers (lane = row, v_readlane broadcasts, no barriers);
+//       (b) panel rows below  P = A Dinv^T          -- MFMA 16x16x4, one 16-row block per wave-slot
+//       (c) trailing update   C -= P P^T            -- MFMA, lower block pairs round-robin over waves
+//   then (d) W = L^-1 by block levels (MFMA), kept transposed in the unused upper triangle.
+// LDS tile is column-major with leading dimension LDP.  info = first non-positive pivot (1-based).
 // --------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_potf2(FitArgs p, int k) {
   using P = Prec<T>;
+  using acc_t = typename P::acc_t;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T *A = reinterpret_cast<T *>(smem_raw);  // A[r * LDA_P + c]
-  const int b = blockIdx.x, tid = threadIdx.x;
+  T *At = reinterpret_cast<T *>(smem_raw);  // element (r, c) at At[c * LDP + r]
+  T *Dv = At + TS * LDP;                     // Dv[jb][q][x] = Dinv_jb[x][q]
+  T *Ts = Dv + 8 * DB * DB;                  // per-wave 16x16 scratch
+  int *flag = reinterpret_cast<int *>(Ts + 4 * DB * DB);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
   T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
   const int ld = p.ld;
   T *tile = Lw + (size_t)(k * TS) * ld + (size_t)k * TS;
   for (int idx = tid; idx < TS * TS; idx += 256) {
     const int c = idx >> 7, r = idx & 127;
-    A[r * LDA_P + c] = tile[(size_t)c * ld + r];
+    At[c * LDP + r] = tile[(size_t)c * ld + r];
   }
-  int bad = 0;
+  if (tid == 0) *flag = 0;
+  __syncthreads();
+
   for (int jb = 0; jb < TS / DB; ++jb) {
     const int j0 = jb * DB;
-    for (int j = j0; j < j0 + DB; ++j) {
-      __syncthreads();
-      T ajj = A[j * LDA_P + j];
-      if (!(ajj > T(0))) {
-        if (bad == 0) bad = k * TS + j + 1;
-        ajj = T(1);
+    if (wave == 0) {
+      // (a) lane holds row (lane & 15) of the diagonal block (replicated over the four 16-lane groups)
+      T a[DB], rinv[DB];
+#pragma unroll
+      for (int c = 0; c < DB; ++c) a[c] = At[(j0 + c) * LDP + j0 + l15];
+      int bad = 0;
+#pragma unroll
+      for (int j = 0; j < DB; ++j) {
+        T dj = rdlane(a[j], j);
+        if (!(dj > T(0))) {
+          if (bad == 0) bad = k * TS + j0 + j + 1;
+          dj = T(1);
+        }
+        const T rs = T(1) / P::sqrt_(dj);
+        rinv[j] = rs;
+        const T l = (l15 == j) ? dj * rs : a[j] * rs;
+        a[j] = l;
+#pragma unroll
+        for (int c = j + 1; c < DB; ++c) a[c] -= l * rdlane(l, c);
       }
-      const T dj = P::sqrt_(ajj);
-      const T dinv = T(1) / dj;
-      __syncthreads();
-      if (tid < TS) {
-        if (tid > j) A[tid * LDA_P + j] *= dinv;
-        else if (tid == j) A[j * LDA_P + j] = dj;
+      if (bad != 0 && lane == 0 && *flag == 0) *flag = bad;
+      if (lane < DB) {
+#pragma unroll
+        for (int c = 0; c < DB; ++c)
+          if (l15 >= c) At[(j0 + c) * LDP + j0 + l15] = a[c];
       }
-      __syncthreads();
-      const int r = tid & 127, half = tid >> 7;
-      if (r > j) {
-        const T lrj = A[r * LDA_P + j];
-        for (int c = j + 1 + half; c < j0 + DB; c += 2)
-          if (r >= c) A[r * LDA_P + c] -= lrj * A[c * LDA_P + j];
-      }
-    }
-    __syncthreads();
-    // trailing update of everything right of the 16-wide panel (lower triangle only)
-    const int t0 = j0 + DB, nrem = TS - t0;
-    for (int idx = tid; idx < nrem * nrem; idx += 256) {
-      const int rr = idx % nrem, cc = idx / nrem;
-      if (rr >= cc) {
-        const T *ar = A + (t0 + rr) * LDA_P + j0, *ac = A + (t0 + cc) * LDA_P + j0;
+      // inverse of the block: lane x computes column x of Dinv by forward substitution
+      T w[DB];
+#pragma unroll
+      for (int i = 0; i < DB; ++i) {
         T s = 0;
 #pragma unroll
-        for (int q = 0; q < DB; ++q) s += ar[q] * ac[q];
-        A[(t0 + rr) * LDA_P + t0 + cc] -= s;
+        for (int q = 0; q < DB; ++q)
+          if (q < i) s += rdlane(a[q], i) * w[q];
+        w[i] = (i < l15) ? T(0) : ((i == l15) ? rinv[i] : -s * rinv[i]);
+      }
+      if (lane < DB) {
+#pragma unroll
+        for (int i = 0; i < DB; ++i) Dv[jb * DB * DB + l15 * DB + i] = w[i];
       }
     }
-  }
-  __syncthreads();
-  if (tid == 0 && bad != 0 && p.info[b] == 0) p.info[b] = bad;
-  // inverses of the eight 16x16 diagonal blocks: thread -> (block, column), forward substitution
-  if (tid < TS) {
-    const int blk = tid >> 4, col = tid & 15, base = blk * DB;
-    T w[DB];
+    __syncthreads();
+    // (b) panel: rows of block bi below the diagonal block, P[r][c] = sum_q A[r][q] Dinv[c][q]
+    for (int bi = jb + 1 + wave; bi < TS / DB; bi += 4) {
+      acc_t acc = acc_t{0, 0, 0, 0};
+      T fa[4], fb[4];
 #pragma unroll
-    for (int i = 0; i < DB; ++i) {
-      const T *ai = A + (base + i) * LDA_P + base;
-      T s = 0;
+      for (int ks = 0; ks < 4; ++ks) {
+        fa[ks] = Dv[jb * DB * DB + (ks * 4 + lq) * DB + l15];
+        fb[ks] = At[(j0 + ks * 4 + lq) * LDP + bi * DB + l15];
+      }
 #pragma unroll
-      for (int q = 0; q < DB; ++q)
-        if (q < i) s += (q >= col ? ai[q] * w[q] : T(0));
-      const T dinv = T(1) / ai[i];
-      w[i] = (i < col) ? T(0) : ((i == col) ? dinv : -s * dinv);
+      for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) At[(j0 + P::drow(lane, r)) * LDP + bi * DB + l15] = acc[r];
     }
-    T *Di = reinterpret_cast<T *>(p.Dinv) + (size_t)b * p.dinv_stride + ((size_t)k * 8 + blk) * (DB * DB);
+    __syncthreads();
+    // (c) trailing update of the lower block pairs (bi >= bj > jb)
+    const int nb = TS / DB - jb - 1;
+    for (int idx = wave; idx < nb * (nb + 1) / 2; idx += 4) {
+      int bj = 0, rem = idx;
+      while (rem >= nb - bj) {
+        rem -= nb - bj;
+        ++bj;
+      }
+      const int bi = bj + rem + jb + 1;
+      bj += jb + 1;
+      acc_t acc;
 #pragma unroll
-    for (int i = 0; i < DB; ++i) Di[i * DB + col] = w[i];
+      for (int r = 0; r < 4; ++r) acc[r] = At[(bj * DB + P::drow(lane, r)) * LDP + bi * DB + l15];
+      T fa[4], fb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        fa[ks] = -At[(j0 + ks * 4 + lq) * LDP + bj * DB + l15];
+        fb[ks] = At[(j0 + ks * 4 + lq) * LDP + bi * DB + l15];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) At[(bj * DB + P::drow(lane, r)) * LDP + bi * DB + l15] = acc[r];
+    }
+    __syncthreads();
   }
-  for (int idx = tid; idx < TS * TS; idx += 256) {
-    const int c = idx >> 7, r = idx & 127;
-    tile[(size_t)c * ld + r] = (r >= c) ? A[r * LDA_P + c] : T(0);
-  }
-}
 
-// --------------------------------------------------------------------------------------------------
-// k_trsm: L(rt, k) = S(rt, k) L(k,k)^-T by block forward substitution over the eight 16-column
-// blocks (a3 "trsm_panel" and, for the extra tiles, a8 "trsm_var").  grid (row tiles below k, batch)
-// --------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_trsm(FitArgs p, int k) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T *Xs = reinterpret_cast<T *>(smem_raw);  // Xs[r * LDA_P + c]
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const int rt = row_tile_of(blockIdx.x, k + 1, p.NT, p.rows_from_extra);
-  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
-  const int ld = p.ld;
-  T *tile = Lw + (size_t)(k * TS) * ld + (size_t)rt * TS;
-  const T *Lkk = Lw + (size_t)(k * TS) * ld + (size_t)k * TS;  // L(k,k)[c][q] at Lkk[q*ld + c]
-  const T *Di = reinterpret_cast<const T *>(p.Dinv) + (size_t)b * p.dinv_stride + (size_t)k * 8 * (DB * DB);
+  // (d) W = L^-1: block (i, j), i > j:  W_ij = -Dinv_i * sum_{kk=j}^{i-1} L_{i,kk} W_{kk,j}.
+  // Blocks with the same i - j are independent (one level per barrier).  W_ij is stored transposed
+  // at the upper-triangle position, i.e. W_ij[r][c] at At[(16 i + r) * LDP + 16 j + c].
+  T *tsw = Ts + wave * DB * DB;
+  for (int lev = 1; lev < TS / DB; ++lev) {
+    for (int j = wave; j + lev < TS / DB; j += 4) {
+      const int i = j + lev;
+      acc_t acc = acc_t{0, 0, 0, 0};
+      for (int kk = j; kk < i; ++kk) {
+        T fa[4], fb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          fa[ks] = At[(kk * DB + ks * 4 + lq) * LDP + i * DB + l15];  // L_{i,kk}[r = l15][q]
+          fb[ks] = (kk == j) ? Dv[j * DB * DB + l15 * DB + ks * 4 + lq]  // Dinv_j[q][c = l15]
+                             : At[(kk * DB + ks * 4 + lq) * LDP + j * DB + l15];  // W_{kk,j}[q][c]
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tsw[P::drow(lane, r) * DB + l15] = acc[r];  // T[r][c]
+      acc_t acc2 = acc_t{0, 0, 0, 0};
+      T ga[4], gb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        ga[ks] = -Dv[i * DB * DB + (ks * 4 + lq) * DB + l15];  // -Dinv_i[r = l15][q]
+        gb[ks] = tsw[(ks * 4 + lq) * DB + l15];                // T[q][c = l15]
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc2 = P::mfma(ga[ks], gb[ks], acc2);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) At[(i * DB + P::drow(lane, r)) * LDP + j * DB + l15] = acc2[r];
+    }
+    __syncthreads();
+  }
+
+  // (e) write L (upper triangle zeroed) and W (column-major 128 x 128, lower triangular)
+  if (tid == 0 && *flag != 0 && p.info[b] == 0) p.info[b] = *flag;
+  T *Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * TS * TS;
   for (int idx = tid; idx < TS * TS; idx += 256) {
     const int c = idx >> 7, r = idx & 127;
-    Xs[r * LDA_P + c] = tile[(size_t)c * ld + r];
-  }
-  __syncthreads();
-  const int r = tid & 127;
-  const int h = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform half: columns h*8 .. h*8+7
-  T *row = Xs + r * LDA_P;
-  for (int cb = 0; cb < TS / DB; ++cb) {
-    const int c0 = cb * DB + h * 8;
-    T t[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = row[c0 + u];
-    for (int q = 0; q < cb * DB; ++q) {
-      const T xq = row[q];
-      const T *lq = Lkk + (size_t)q * ld + c0;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] -= xq * lq[u];
+    tile[(size_t)c * ld + r] = (r >= c) ? At[c * LDP + r] : T(0);
+    T w = T(0);
+    if (r >= c) {
+      if ((r >> 4) == (c >> 4)) w = Dv[(r >> 4) * DB * DB + (c & 15) * DB + (r & 15)];
+      else w = At[r * LDP + c];
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) row[c0 + u] = t[u];
-    __syncthreads();
-    T tt[DB];
-#pragma unroll
-    for (int q = 0; q < DB; ++q) tt[q] = row[cb * DB + q];
-    T x[8];
-    const T *dcb = Di + cb * (DB * DB);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int c = h * 8 + u;
-      T s = 0;
-#pragma unroll
-      for (int q = 0; q < DB; ++q)
-        if (q <= c) s += tt[q] * dcb[c * DB + q];
-      x[u] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 8; ++u) row[c0 + u] = x[u];
-    __syncthreads();
-  }
-  for (int idx = tid; idx < TS * TS; idx += 256) {
-    const int c = idx >> 7, rr = idx & 127;
-    tile[(size_t)c * ld + rr] = Xs[rr * LDA_P + c];
+    Wk[(size_t)c * TS + r] = w;
   }
 }
 

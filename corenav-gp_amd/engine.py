@@ -13,7 +13,7 @@ F64, F32 = 0, 1
 MAX_D = 8
 MAX_THETA = MAX_D + 2
 PROF_KERNELS = 5
-PROF_NAMES = ("update", "potf2", "trsm", "finalize", "alpha")
+PROF_NAMES = ("update", "potf2", "trmm", "finalize", "alpha")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcorenav_gp.so")
@@ -39,6 +39,7 @@ _SIGS = {
                                                                           ctypes.c_int, _dp, _dp, _dp, _ip]),
     "cgp_fit_predict_batch_device": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5 + [_vp, _vp, _vp, _vp, _vp,
                                                                                  ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "cgp_set_streams": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cgp_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cgp_profile_read": (ctypes.c_int, [_vp, _dp, _dp, ctypes.POINTER(ctypes.c_longlong)]),
     "cgp_llh_to_enu": (ctypes.c_int, [ctypes.c_double] * 3 + [_dp, _dp, _dp]),
@@ -166,6 +167,9 @@ class Context:
         return self._chk(self.lib.cgp_fit_predict_batch_device(self.h, B, N, d, M, kernel_id, dX, dy, dXs, dtheta,
                                                                djitter or None, int(include_noise), dmean, dvar,
                                                                dlogml, dinfo, stream or None))
+
+    def set_streams(self, n):
+        self._chk(self.lib.cgp_set_streams(self.h, int(n)))
 
     def profile_enable(self, on=True):
         self._chk(self.lib.cgp_profile_enable(self.h, int(on)))

@@ -100,9 +100,15 @@ int cgp_fit_predict_batch_device(cgp_ctx *ctx, int batch, int N, int d, int M, i
                                  const double *djitter, int include_noise, void *dmean, void *dvar,
                                  double *dlogml, int *dinfo, void *hip_stream);
 
+/* Number of worker streams a batch is spread over (1..8, default 4): the batch is cut into that
+ * many groups whose launch schedules run concurrently (HIP streams + events, forked from and
+ * joined to the caller's stream), so latency-bound launches of one group overlap MFMA-bound
+ * launches of another. */
+int cgp_set_streams(cgp_ctx *ctx, int n);
+
 /* ---- per-kernel timing for the roofline line (bench.py) --------------------------------------
  * When enabled, every launch is bracketed by hipEvents on its stream; cgp_profile_read drains them.
- * kernel index: 0 update(syrk/gemm+gram) 1 potf2 2 trsm 3 finalize(mean/var/logml) 4 alpha.
+ * kernel index: 0 update(syrk/gemm+gram) 1 potf2(+inverse) 2 trmm 3 finalize(mean/var/logml) 4 alpha.
  * flops = algorithmic flops issued by those launches (DESIGN.md section "Kernels"). */
 #define CGP_PROF_KERNELS 5
 int cgp_profile_enable(cgp_ctx *ctx, int on);
