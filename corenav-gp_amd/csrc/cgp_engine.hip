@@ -244,6 +244,7 @@ FitArgs base_args(cgp_ctx *c, int N, int d, int M, int kid, int include_noise) {
   a.ET = cdiv(M + 1, TS);
   a.kernel_id = kid;
   a.include_noise = include_noise;
+  if (const char *e = getenv("CGP_DBG")) a.dbg = atoi(e);  // timing ablations only
   return a;
 }
 

@@ -53,6 +53,7 @@ struct FitArgs {
   size_t alpha_stride;
   int N, d, M, NT, ET, kernel_id, include_noise;
   int rows_from_extra;   // 1: only the extra (test/y) row tiles are processed (predict after fit)
+  int dbg;               // timing ablations only (env CGP_DBG, results are WRONG when non-zero)
 };
 
 template <typename T> struct Prec;
@@ -87,6 +88,22 @@ __device__ __forceinline__ int row_tile_of(int t, int first_in, int NT, int rows
   return (t < nin) ? first_in + t : NT + (t - nin);
 }
 
+// XCD-aware block -> (tile slot t, fit b) map.  The dispatcher is observed to place consecutive
+// workgroups on consecutive XCDs (8 private L2s); all tiles of one fit share the tile-k column
+// panel, so a fit's tiles are steered to one XCD to make those re-reads L2 hits.  Speed only: any
+// placement is correct.  Needs gridDim.y % 8 == 0, otherwise the identity map is used.
+__device__ __forceinline__ void tile_fit_of_block(int &t, int &b) {
+  const int T = gridDim.x, B = gridDim.y;
+  t = blockIdx.x;
+  b = blockIdx.y;
+  if ((B & 7) == 0) {
+    const int lin = blockIdx.y * T + blockIdx.x;
+    const int xcd = lin & 7, slot = lin >> 3;
+    t = slot % T;
+    b = (slot / T) * 8 + xcd;
+  }
+}
+
 // readlane for scalars of either precision (lane index must be wave-uniform)
 __device__ __forceinline__ float rdlane(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
@@ -95,33 +112,6 @@ __device__ __forceinline__ double rdlane(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
-}
-
-// --------------------------------------------------------------------------------------------------
-// Covariance entry on zero-padded MAXD-vectors.  SE kernels get inputs pre-divided by the
-// length-scales; RBF x Brownian follows GPy's r^2 = x^2 + x'^2 - 2xx' clipped at 0 (auto-covariance
-// diagonal forced to 0) on the raw tick value.
-// --------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T cov_entry(int kid, const T *xr, const T *xc, T amp, T inv_ell, T amp_b, bool same) {
-  if (kid != K_RBF_BROWNIAN) {
-    T d2 = 0;
-#pragma unroll
-    for (int q = 0; q < MAXD; ++q) {
-      const T df = xr[q] - xc[q];
-      d2 += df * df;
-    }
-    return amp * Prec<T>::exp_(T(-0.5) * d2);
-  }
-  const T x = xr[0], xp = xc[0];
-  T r2 = same ? T(0) : (T(-2) * x * xp + (x * x + xp * xp));
-  r2 = r2 < T(0) ? T(0) : r2;
-  const T r = Prec<T>::sqrt_(r2) * inv_ell;
-  const T krbf = amp * Prec<T>::exp_(T(-0.5) * r * r);
-  const int sx = (x > T(0)) - (x < T(0)), sp = (xp > T(0)) - (xp < T(0));
-  const T ax = x < T(0) ? -x : x, ap = xp < T(0) ? -xp : xp;
-  const T kb = (sx == sp) ? amp_b * (ax < ap ? ax : ap) : T(0);
-  return krbf * kb;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -139,7 +129,7 @@ __device__ __forceinline__ T cov_entry(int kid, const T *xr, const T *xc, T amp,
 // --------------------------------------------------------------------------------------------------
 template <typename T, bool TRI>
 __device__ __forceinline__ void mfma_panel_loop(typename Prec<T>::acc_t (&acc)[4][4], const T *gR, size_t ldR,
-                                                const T *gC, size_t ldC, int nchunk, T *smem, int tid) {
+                                                const T *gC, size_t ldC, int nchunk, T *smem, int tid, int dbg = 0) {
   using P = Prec<T>;
   using vec8 = T __attribute__((ext_vector_type(8)));
   constexpr int CH = KT * LDST;
@@ -147,23 +137,8 @@ __device__ __forceinline__ void mfma_panel_loop(typename Prec<T>::acc_t (&acc)[4
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int l15 = lane & 15, lq = lane >> 4;
-  const int sc = tid >> 4, sr = (tid & 15) * 8;  // staging: column sc of the chunk, rows sr..sr+7
-  gR += sr;
-  gC += sr;
-  vec8 pr, pc;
-  if (nchunk > 0) {
-    pr = *reinterpret_cast<const vec8 *>(gR + (size_t)sc * ldR);
-    pc = *reinterpret_cast<const vec8 *>(gC + (size_t)sc * ldC);
-    *reinterpret_cast<vec8 *>(smem + sc * LDST + sr) = pr;
-    *reinterpret_cast<vec8 *>(smem + CH + sc * LDST + sr) = pc;
-  }
-  __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    const T *cur = smem + (c & 1) * 2 * CH;
-    if (c + 1 < nchunk) {
-      pr = *reinterpret_cast<const vec8 *>(gR + (size_t)((c + 1) * KT + sc) * ldR);
-      pc = *reinterpret_cast<const vec8 *>(gC + (size_t)((c + 1) * KT + sc) * ldC);
-    }
+
+  auto compute = [&](const T *cur, int c) {
 #pragma unroll
     for (int ks = 0; ks < KT / 4; ++ks) {
       T fa[4], fb[4];
@@ -182,55 +157,105 @@ __device__ __forceinline__ void mfma_panel_loop(typename Prec<T>::acc_t (&acc)[4
         for (int j = 0; j < 4; ++j) acc[i][j] = P::mfma(fa[i], fb[j], acc[i][j]);
       }
     }
-    if (c + 1 < nchunk) {
-      T *nxt = smem + ((c + 1) & 1) * 2 * CH;
-      *reinterpret_cast<vec8 *>(nxt + sc * LDST + sr) = pr;
-      *reinterpret_cast<vec8 *>(nxt + CH + sc * LDST + sr) = pc;
+  };
+
+  if constexpr (sizeof(T) == 8) {
+    // fp64: global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write).  One
+    // wave-instruction moves one 1 KiB column (128 rows): lane -> rows 2*lane, 2*lane+1; the LDS
+    // destination is wave-uniform base + lane*16 B, which the column-padded image satisfies.
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    auto stage = [&](T *buf, int chunk) {
+#pragma unroll
+      for (int i = 0; i < KT / 4; ++i) {
+        const int col = wave * (KT / 4) + i;
+        __builtin_amdgcn_global_load_lds((gbl_void *)(gR + (size_t)(chunk * KT + col) * ldR + lane * 2),
+                                         (lds_void *)(buf + col * LDST), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void *)(gC + (size_t)(chunk * KT + col) * ldC + lane * 2),
+                                         (lds_void *)(buf + CH + col * LDST), 16, 0, 0);
+      }
+    };
+    if (nchunk > 0) stage(smem, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+      if (c + 1 < nchunk && !(dbg & 1)) stage(smem + ((c + 1) & 1) * 2 * CH, c + 1);
+      compute(smem + (c & 1) * 2 * CH, c);
+      if (!(dbg & 4)) __syncthreads();
+    }
+  } else {
+    // fp32: register-staged (a 512-byte column does not fill a 1 KiB LDS-DMA wave-instruction)
+    const int sc = tid >> 4, sr = (tid & 15) * 8;  // staging: column sc of the chunk, rows sr..sr+7
+    gR += sr;
+    gC += sr;
+    vec8 pr, pc;
+    if (nchunk > 0) {
+      pr = *reinterpret_cast<const vec8 *>(gR + (size_t)sc * ldR);
+      pc = *reinterpret_cast<const vec8 *>(gC + (size_t)sc * ldC);
+      *reinterpret_cast<vec8 *>(smem + sc * LDST + sr) = pr;
+      *reinterpret_cast<vec8 *>(smem + CH + sc * LDST + sr) = pc;
     }
     __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+      if (c + 1 < nchunk) {
+        pr = *reinterpret_cast<const vec8 *>(gR + (size_t)((c + 1) * KT + sc) * ldR);
+        pc = *reinterpret_cast<const vec8 *>(gC + (size_t)((c + 1) * KT + sc) * ldC);
+      }
+      compute(smem + (c & 1) * 2 * CH, c);
+      if (c + 1 < nchunk) {
+        T *nxt = smem + ((c + 1) & 1) * 2 * CH;
+        *reinterpret_cast<vec8 *>(nxt + sc * LDST + sr) = pr;
+        *reinterpret_cast<vec8 *>(nxt + CH + sc * LDST + sr) = pc;
+      }
+      __syncthreads();
+    }
   }
 }
 
-// --------------------------------------------------------------------------------------------------
-// k_update: S(rt, k) = Gram(rt, k) - sum_{j < k} L(rt, j) L(k, j)^T   (a2 gram + a3 syrk/gemm + a8)
-// grid (row tiles, batch).  The Gram tile is evaluated from the inputs in the epilogue, so Ky and
-// K* never exist in HBM.
-// --------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_update(FitArgs p, int k) {
+// exp(x) for x <= 0 (every covariance exponent is -0.5 r^2): n = rint(x log2 e), r = x - n ln2 in
+// two pieces, degree-13 Horner polynomial on |r| <= ln2/2, v_ldexp for 2^n (denormal-exact), 0 below
+// the underflow threshold.  No overflow / NaN special cases are needed on this domain.
+__device__ __forceinline__ double exp_nonpos(double x) {
+  const double n = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double q = 1.6059043836821613e-10;  // 1/13!
+  q = __builtin_fma(q, r, 2.08767569878681e-09);
+  q = __builtin_fma(q, r, 2.505210838544172e-08);
+  q = __builtin_fma(q, r, 2.755731922398589e-07);
+  q = __builtin_fma(q, r, 2.7557319223985893e-06);
+  q = __builtin_fma(q, r, 2.48015873015873e-05);
+  q = __builtin_fma(q, r, 1.984126984126984e-04);
+  q = __builtin_fma(q, r, 1.3888888888888889e-03);
+  q = __builtin_fma(q, r, 8.333333333333333e-03);
+  q = __builtin_fma(q, r, 4.1666666666666664e-02);
+  q = __builtin_fma(q, r, 1.6666666666666666e-01);
+  q = __builtin_fma(q, r, 0.5);
+  q = __builtin_fma(q, r, 1.0);
+  q = __builtin_fma(q, r, 1.0);
+  const double v = __builtin_amdgcn_ldexp(q, (int)n);
+  return x < -745.0 ? 0.0 : v;
+}
+__device__ __forceinline__ float exp_nonpos(float x) { return __expf(x) * (x < -104.f ? 0.f : 1.f); }
+
+// Gram tile G(rt, k) evaluated from the inputs, then S = G - acc, stored to the factor panel.
+// Column points (16 per lane) are the outer static loops, the 4 row points the inner one; all
+// padding / y-row cases are selects, not branches.
+template <typename T, bool BROWN>
+__device__ __forceinline__ void gram_epilogue(const FitArgs &p, typename Prec<T>::acc_t (&acc)[4][4],
+                                              T *__restrict__ Lw, T *__restrict__ smem, int b, int k, int rt, int tid) {
   using P = Prec<T>;
-  using acc_t = typename P::acc_t;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T *smem = reinterpret_cast<T *>(smem_raw);
-
-  const int b = blockIdx.y;
-  const int rt = row_tile_of(blockIdx.x, k, p.NT, p.rows_from_extra);
-  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
-  const int ld = p.ld;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int l15 = lane & 15;
-
-  acc_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-
-  mfma_panel_loop<T, false>(acc, Lw + (size_t)rt * TS, (size_t)ld, Lw + (size_t)k * TS, (size_t)ld,
-                            (k * TS) / KT, smem, tid);
-
-  // ---- epilogue: Gram tile from the inputs, S = G - acc ----
-  const double *th = p.theta + (size_t)b * MAX_THETA;
-  const int kid = p.kernel_id, d = p.d, N = p.N, M = p.M;
+  const double *__restrict__ th = p.theta + (size_t)b * MAX_THETA;
+  const int kid = p.kernel_id, d = p.d, N = p.N, M = p.M, ld = p.ld;
   const bool extra = rt >= p.NT;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15;
   T *xr = smem;                    // [128][MAXD] rows of this tile (training or test points), zero padded
   T *xc = smem + TS * MAXD;        // [128][MAXD] columns = training points of tile k
   T *yc = smem + 2 * TS * MAXD;    // [128] y of the tile-k columns (only the y row uses it)
-  const T *Xb = reinterpret_cast<const T *>(p.X) + (size_t)b * d * N;
-  const T *Xsb = reinterpret_cast<const T *>(p.Xs) + (size_t)b * d * M;
-  const T *yb = reinterpret_cast<const T *>(p.y) + (size_t)b * N;
+  const T *__restrict__ Xb = reinterpret_cast<const T *>(p.X) + (size_t)b * d * N;
+  const T *__restrict__ Xsb = reinterpret_cast<const T *>(p.Xs) + (size_t)b * d * M;
+  const T *__restrict__ yb = reinterpret_cast<const T *>(p.y) + (size_t)b * N;
   for (int idx = tid; idx < MAXD * TS; idx += 256) {
     const int q = idx >> 7, r = idx & 127;
     T vc = T(0), vr = T(0);
@@ -257,10 +282,12 @@ __global__ __launch_bounds__(256, 2) void k_update(FitArgs p, int k) {
   }
   __syncthreads();
   const T amp = T(th[0]);
-  const T inv_ell = (kid == K_RBF_BROWNIAN) ? T(1.0 / th[1]) : T(1);
-  const T amp_b = (kid == K_RBF_BROWNIAN) ? T(th[2]) : T(0);
+  const T inv_ell = BROWN ? T(1.0 / th[1]) : T(1);
+  const T amp_b = BROWN ? T(th[2]) : T(0);
   const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
   const T diag_add = T(th[nth - 1] + 1e-8 + (p.jitter ? p.jitter[b] : 0.0));
+  const int rowbase = extra ? (rt - p.NT) * TS : rt * TS;  // global row index of local row 0
+  T *__restrict__ out = Lw + (size_t)rt * TS + (size_t)(k * TS) * ld;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -271,29 +298,78 @@ __global__ __launch_bounds__(256, 2) void k_update(FitArgs p, int k) {
 #pragma unroll
       for (int q = 0; q < MAXD; ++q) xcol[q] = xc[cl * MAXD + q];
       const T ycl = yc[cl];
+      const bool colok = gcol < N;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int rl = wr * 64 + j * 16 + l15;  // local result row
-        const int grow = extra ? (rt - p.NT) * TS + rl : rt * TS + rl;
-        T xrow[MAXD];
+        const int grow = rowbase + rl;
+        T g;
+        if (!BROWN) {
+          T d2 = 0;
 #pragma unroll
-        for (int q = 0; q < MAXD; ++q) xrow[q] = xr[rl * MAXD + q];
-        T g = cov_entry<T>(kid, xrow, xcol, amp, inv_ell, amp_b, !extra && grow == gcol);
-        if (!extra) {
-          if (grow < N && gcol < N) {
-            if (grow == gcol) g += diag_add;
-          } else {
-            g = (grow == gcol) ? T(1) : T(0);  // identity padding keeps the factor well defined
+          for (int q = 0; q < MAXD; ++q) {
+            const T df = xr[rl * MAXD + q] - xcol[q];
+            d2 += df * df;
           }
+          g = amp * exp_nonpos(T(-0.5) * d2);
         } else {
-          if (gcol >= N || grow > M) g = T(0);
-          else if (grow == M) g = ycl;
+          const T x = xr[rl * MAXD], xp = xcol[0];
+          const bool same = !extra && grow == gcol;  // GPy forces r^2 = 0 on the auto-covariance diagonal
+          T r2 = same ? T(0) : (T(-2) * x * xp + (x * x + xp * xp));
+          r2 = r2 < T(0) ? T(0) : r2;
+          const T rr = P::sqrt_(r2) * inv_ell;
+          const int sx = (x > T(0)) - (x < T(0)), sp = (xp > T(0)) - (xp < T(0));
+          const T ax = x < T(0) ? -x : x, ap = xp < T(0) ? -xp : xp;
+          const T kb = (sx == sp) ? amp_b * (ax < ap ? ax : ap) : T(0);
+          g = amp * exp_nonpos(T(-0.5) * rr * rr) * kb;
         }
-        Lw[(size_t)gcol * ld + (size_t)rt * TS + rl] = g - acc[i][j][r];
+        if (!extra) {
+          const bool dg = grow == gcol;
+          g = dg ? g + diag_add : g;
+          g = (grow < N && colok) ? g : (dg ? T(1) : T(0));  // identity padding keeps the factor well defined
+        } else {
+          g = (grow == M) ? ycl : g;
+          g = (!colok || grow > M) ? T(0) : g;
+        }
+        out[(size_t)cl * ld + rl] = g - acc[i][j][r];
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the 16 column points from being software-pipelined into spills
     }
   }
+}
+
+// --------------------------------------------------------------------------------------------------
+// k_update: S(rt, k) = Gram(rt, k) - sum_{j < k} L(rt, j) L(k, j)^T   (a2 gram + a3 syrk/gemm + a8)
+// grid (row tiles, batch).  The Gram tile is evaluated from the inputs in the epilogue, so Ky and
+// K* never exist in HBM.
+// --------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_update(FitArgs p, int k) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+
+  int bt, b;
+  tile_fit_of_block(bt, b);
+  const int rt = row_tile_of(bt, k, p.NT, p.rows_from_extra);
+  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const int ld = p.ld;
+  const int tid = threadIdx.x;
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+  mfma_panel_loop<T, false>(acc, Lw + (size_t)rt * TS, (size_t)ld, Lw + (size_t)k * TS, (size_t)ld,
+                            (k * TS) / KT, smem, tid, p.dbg);
+  if (p.dbg & 8) return;
+
+  // ---- epilogue: Gram tile from the inputs, S = G - acc ----
+  if (p.kernel_id == K_RBF_BROWNIAN) gram_epilogue<T, true>(p, acc, Lw, smem, b, k, rt, tid);
+  else gram_epilogue<T, false>(p, acc, Lw, smem, b, k, rt, tid);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -307,8 +383,9 @@ __global__ __launch_bounds__(256, 2) void k_trmm(FitArgs p, int k) {
   using acc_t = typename P::acc_t;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
-  const int b = blockIdx.y;
-  const int rt = row_tile_of(blockIdx.x, k + 1, p.NT, p.rows_from_extra);
+  int bt, b;
+  tile_fit_of_block(bt, b);
+  const int rt = row_tile_of(bt, k + 1, p.NT, p.rows_from_extra);
   T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
   const int ld = p.ld;
   const T *Wk = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * TS * TS;
