@@ -38,18 +38,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="independent fits per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="independent fits per GPU per step")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3])
     ap.add_argument("--n", type=int, default=None, help="override window length N")
     ap.add_argument("--cpu-sample", type=int, default=6, help="fits timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, help="worker streams the batch is spread over")
+    ap.add_argument("--streams", type=int, default=1, help="worker streams the batch is spread over")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import corenav_gp_amd.engine as engine
     import corenav_gp_amd.synth as synth
+    from corenav_gp_amd import sharding
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,11 +118,9 @@ def main():
     assert int(dinfo.abs().sum().item()) == 0, "a fit reported a non-positive pivot"
 
     # per-fit summaries gathered over RCCL (the only collective on the path: SURVEY.md 8e)
-    summ = torch.stack([dlogml, dvar.to(torch.float64).max(1).values], 1)
-    if world > 1:
-        allsum = [torch.empty_like(summ) for _ in range(world)]
-        dist.all_gather(allsum, summ)
-        summ = torch.cat(allsum, 0)
+    summ = torch.stack([dlogml, 2.0 * dvar.to(torch.float64).max(1).values.sqrt(), dinfo.to(torch.float64)], 1)
+    table = sharding.gather_summaries(summ, B * world)
+    ens = sharding.ensemble_stats(table)
 
     # ---- roofline of the dominant kernel (k_update: trailing syrk/gemm + Gram), HIP events per launch
     ctx.profile_enable(True)
@@ -146,7 +145,7 @@ def main():
                                    f"N={N} d={d} M={M_TEST} kernel={'SE-ARD' if kid == 1 else 'SE-iso'} {dts}",
                        "fits_per_gpu_per_step": B, "streams": args.streams, "N": N, "d": d, "M": M_TEST,
                        "fit_tflops": value * f_fit / 1e12, "cholesky_roofline_frac": value * f_chol / 1e12 / world / peak,
-                       "inputs": "resident in HBM"},
+                       "inputs": "resident in HBM", "ensemble": ens},
             "roofline": {"bound": "mfma", "kernel": "k_update (syrk/gemm trailing update + fused Gram)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": None, "avg_launch_ms": upd["ms"] / max(upd["launches"], 1),

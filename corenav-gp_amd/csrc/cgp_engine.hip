@@ -4,7 +4,9 @@
 #include "../../include/corenav_gp.h"
 #include "cgp_kernels.hpp"
 #include "gp_predictor_core.hpp"
+#include "gp_predictor.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -665,6 +667,39 @@ int cgp_predict_stop(const double *mean, const double *sigma, int M, const doubl
   if (stop_cmd) *stop_cmd = r.stop_cmd;
   if (i_out) *i_out = r.i;
   if (xy_err) *xy_err = r.xy_err;
+  return CGP_OK;
+}
+
+int cgp_gppredictor_callback(const double *mean, const double *sigma, int M, const double *P, const double *Q,
+                             const double *STM, const double *Hvec, const double pos_llh[3], double arrival_time,
+                             double now, int h_bug_compatible, int *published, double *stop_cmd) {
+  if (!mean || !sigma || M < 0 || !P || !Q || !STM || !Hvec || !pos_llh) return CGP_EINVAL;
+  corenav::NodeHandle nh;
+  int clock_reads = 0, npub = 0;
+  double last = 0.0;
+  nh.now = [&]() { return clock_reads++ == 0 ? arrival_time : now; };
+  nh.call_set_stopping = [&](core_nav::SetStopping &srv) {
+    std::copy(P, P + 225, srv.response.PvecData.begin());
+    std::copy(Q, Q + 225, srv.response.QvecData.begin());
+    std::copy(STM, STM + 225, srv.response.STMvecData.begin());
+    std::copy(Hvec, Hvec + 60, srv.response.HvecData.begin());
+    srv.response.PosData.x = pos_llh[0];
+    srv.response.PosData.y = pos_llh[1];
+    srv.response.PosData.z = pos_llh[2];
+    return srv.request.stopping;
+  };
+  nh.publish_stop_cmd = [&](const std_msgs::Float64 &m) {
+    ++npub;
+    last = m.data;
+  };
+  GpPredictor node(nh);
+  node.h_bug_compatible = h_bug_compatible != 0;
+  auto msg = std::make_shared<core_nav::GP_Output>();
+  msg->mean.assign(mean, mean + M);
+  msg->sigma.assign(sigma, sigma + M);
+  node.GPCallBack(msg);
+  if (published) *published = npub;
+  if (stop_cmd) *stop_cmd = last;
   return CGP_OK;
 }
 

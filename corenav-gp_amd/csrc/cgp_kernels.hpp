@@ -212,44 +212,116 @@ __device__ __forceinline__ void mfma_panel_loop(typename Prec<T>::acc_t (&acc)[4
 }
 
 // exp(x) for x <= 0 (every covariance exponent is -0.5 r^2): n = rint(x log2 e), r = x - n ln2 in
-// two pieces, degree-13 Horner polynomial on |r| <= ln2/2, v_ldexp for 2^n (denormal-exact), 0 below
-// the underflow threshold.  No overflow / NaN special cases are needed on this domain.
-__device__ __forceinline__ double exp_nonpos(double x) {
-  const double n = __builtin_rint(x * 1.4426950408889634);
-  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
-  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
-  double q = 1.6059043836821613e-10;  // 1/13!
-  q = __builtin_fma(q, r, 2.08767569878681e-09);
-  q = __builtin_fma(q, r, 2.505210838544172e-08);
-  q = __builtin_fma(q, r, 2.755731922398589e-07);
-  q = __builtin_fma(q, r, 2.7557319223985893e-06);
-  q = __builtin_fma(q, r, 2.48015873015873e-05);
-  q = __builtin_fma(q, r, 1.984126984126984e-04);
-  q = __builtin_fma(q, r, 1.3888888888888889e-03);
-  q = __builtin_fma(q, r, 8.333333333333333e-03);
-  q = __builtin_fma(q, r, 4.1666666666666664e-02);
-  q = __builtin_fma(q, r, 1.6666666666666666e-01);
-  q = __builtin_fma(q, r, 0.5);
+// two pieces, degree-13 Horner polynomial on |r| <= ln2/2, v_ldexp for 2^n (denormal-exact).  The
+// argument is clamped at -800 (result 0) instead of being special-cased.  Coefficients live in
+// constant memory so they are fetched once into SGPRs and used as v_fma source operands; as
+// immediates every v_fmac would need two v_mov to materialise its addend.
+__constant__ double kExpC[16] = {1.6059043836821613e-10, 2.08767569878681e-09,  2.505210838544172e-08,
+                                 2.755731922398589e-07,  2.7557319223985893e-06, 2.48015873015873e-05,
+                                 1.984126984126984e-04,  1.3888888888888889e-03, 8.333333333333333e-03,
+                                 4.1666666666666664e-02, 1.6666666666666666e-01, 0.5,
+                                 1.4426950408889634,     -6.93147180369123816490e-01, -1.90821492927058770002e-10,
+                                 -800.0};
+struct ExpC {
+  double c[16];
+  __device__ __forceinline__ void load() {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = kExpC[i];
+  }
+};
+__device__ __forceinline__ double exp_nonpos(double x, const ExpC &e) {
+  x = __builtin_fmax(x, e.c[15]);
+  const double n = __builtin_rint(x * e.c[12]);
+  double r = __builtin_fma(n, e.c[13], x);
+  r = __builtin_fma(n, e.c[14], r);
+  double q = e.c[0];
+#pragma unroll
+  for (int i = 1; i < 12; ++i) q = __builtin_fma(q, r, e.c[i]);
   q = __builtin_fma(q, r, 1.0);
   q = __builtin_fma(q, r, 1.0);
-  const double v = __builtin_amdgcn_ldexp(q, (int)n);
-  return x < -745.0 ? 0.0 : v;
+  return __builtin_amdgcn_ldexp(q, (int)n);
 }
-__device__ __forceinline__ float exp_nonpos(float x) { return __expf(x) * (x < -104.f ? 0.f : 1.f); }
+__device__ __forceinline__ float exp_nonpos(float x, const ExpC &) { return __expf(fmaxf(x, -104.f)); }
 
 // Gram tile G(rt, k) evaluated from the inputs, then S = G - acc, stored to the factor panel.
-// Column points (16 per lane) are the outer static loops, the 4 row points the inner one; all
-// padding / y-row cases are selects, not branches.
+// Column points (16 per lane) are the outer static loops, the 4 row points the inner one.
+// FAST: interior tile -- every row and column is a real point and no diagonal / y-row entry is in
+// it, so the padding and noise selects vanish; the other tiles take the general path.
+template <typename T, bool BROWN, bool FAST>
+__device__ __forceinline__ void gram_tile(const FitArgs &p, typename Prec<T>::acc_t (&acc)[4][4], T *__restrict__ out,
+                                          const T *__restrict__ xr, const T *__restrict__ xc, const T *__restrict__ yc,
+                                          bool extra, int rowbase, int colbase, T amp, T inv_ell, T amp_b, T diag_add,
+                                          int lane, int wr, int wc) {
+  using P = Prec<T>;
+  const int N = p.N, M = p.M, ld = p.ld, l15 = lane & 15;
+  ExpC ec;
+  ec.load();
+  T xrow[4][MAXD];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < MAXD; ++q) xrow[j][q] = (BROWN && q > 0) ? T(0) : xr[(wr * 64 + j * 16 + l15) * MAXD + q];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cl = wc * 64 + i * 16 + P::drow(lane, r);  // local result column
+      const int gcol = colbase + cl;
+      T xcol[MAXD];
+#pragma unroll
+      for (int q = 0; q < MAXD; ++q) xcol[q] = (BROWN && q > 0) ? T(0) : xc[cl * MAXD + q];
+      const T ycl = FAST ? T(0) : yc[cl];
+      const bool colok = gcol < N;
+      T *__restrict__ ocol = out + (size_t)cl * ld + wr * 64 + l15;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int grow = rowbase + wr * 64 + j * 16 + l15;
+        T g;
+        if (!BROWN) {
+          T d2 = 0;
+#pragma unroll
+          for (int q = 0; q < MAXD; ++q) {
+            const T df = xrow[j][q] - xcol[q];
+            d2 = __builtin_fma(df, df, d2);
+          }
+          g = (p.dbg & 32) ? d2 : amp * exp_nonpos(T(-0.5) * d2, ec);
+        } else {
+          const T x = xrow[j][0], xp = xcol[0];
+          const bool same = !FAST && !extra && grow == gcol;  // GPy forces r^2 = 0 on the auto-covariance diagonal
+          T r2 = same ? T(0) : (T(-2) * x * xp + (x * x + xp * xp));
+          r2 = r2 < T(0) ? T(0) : r2;
+          const T rr = P::sqrt_(r2) * inv_ell;
+          const int sx = (x > T(0)) - (x < T(0)), sp = (xp > T(0)) - (xp < T(0));
+          const T ax = x < T(0) ? -x : x, ap = xp < T(0) ? -xp : xp;
+          const T kb = (sx == sp) ? amp_b * (ax < ap ? ax : ap) : T(0);
+          g = amp * exp_nonpos(T(-0.5) * rr * rr, ec) * kb;
+        }
+        if (!FAST) {
+          if (!extra) {
+            const bool dg = grow == gcol;
+            g = dg ? g + diag_add : g;
+            g = (grow < N && colok) ? g : (dg ? T(1) : T(0));  // identity padding keeps the factor well defined
+          } else {
+            g = (grow == M) ? ycl : g;
+            g = (!colok || grow > M) ? T(0) : g;
+          }
+        }
+        if (!(p.dbg & 16) || g == T(12345)) ocol[j * 16] = g - acc[i][j][r];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the 16 column points from being software-pipelined into spills
+    }
+  }
+}
+
 template <typename T, bool BROWN>
 __device__ __forceinline__ void gram_epilogue(const FitArgs &p, typename Prec<T>::acc_t (&acc)[4][4],
                                               T *__restrict__ Lw, T *__restrict__ smem, int b, int k, int rt, int tid) {
-  using P = Prec<T>;
   const double *__restrict__ th = p.theta + (size_t)b * MAX_THETA;
   const int kid = p.kernel_id, d = p.d, N = p.N, M = p.M, ld = p.ld;
   const bool extra = rt >= p.NT;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15;
+  const int wr = wave >> 1, wc = wave & 1;
   T *xr = smem;                    // [128][MAXD] rows of this tile (training or test points), zero padded
   T *xc = smem + TS * MAXD;        // [128][MAXD] columns = training points of tile k
   T *yc = smem + 2 * TS * MAXD;    // [128] y of the tile-k columns (only the y row uses it)
@@ -287,55 +359,12 @@ __device__ __forceinline__ void gram_epilogue(const FitArgs &p, typename Prec<T>
   const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
   const T diag_add = T(th[nth - 1] + 1e-8 + (p.jitter ? p.jitter[b] : 0.0));
   const int rowbase = extra ? (rt - p.NT) * TS : rt * TS;  // global row index of local row 0
-  T *__restrict__ out = Lw + (size_t)rt * TS + (size_t)(k * TS) * ld;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int cl = wc * 64 + i * 16 + P::drow(lane, r);  // local result column
-      const int gcol = k * TS + cl;
-      T xcol[MAXD];
-#pragma unroll
-      for (int q = 0; q < MAXD; ++q) xcol[q] = xc[cl * MAXD + q];
-      const T ycl = yc[cl];
-      const bool colok = gcol < N;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int rl = wr * 64 + j * 16 + l15;  // local result row
-        const int grow = rowbase + rl;
-        T g;
-        if (!BROWN) {
-          T d2 = 0;
-#pragma unroll
-          for (int q = 0; q < MAXD; ++q) {
-            const T df = xr[rl * MAXD + q] - xcol[q];
-            d2 += df * df;
-          }
-          g = amp * exp_nonpos(T(-0.5) * d2);
-        } else {
-          const T x = xr[rl * MAXD], xp = xcol[0];
-          const bool same = !extra && grow == gcol;  // GPy forces r^2 = 0 on the auto-covariance diagonal
-          T r2 = same ? T(0) : (T(-2) * x * xp + (x * x + xp * xp));
-          r2 = r2 < T(0) ? T(0) : r2;
-          const T rr = P::sqrt_(r2) * inv_ell;
-          const int sx = (x > T(0)) - (x < T(0)), sp = (xp > T(0)) - (xp < T(0));
-          const T ax = x < T(0) ? -x : x, ap = xp < T(0) ? -xp : xp;
-          const T kb = (sx == sp) ? amp_b * (ax < ap ? ax : ap) : T(0);
-          g = amp * exp_nonpos(T(-0.5) * rr * rr) * kb;
-        }
-        if (!extra) {
-          const bool dg = grow == gcol;
-          g = dg ? g + diag_add : g;
-          g = (grow < N && colok) ? g : (dg ? T(1) : T(0));  // identity padding keeps the factor well defined
-        } else {
-          g = (grow == M) ? ycl : g;
-          g = (!colok || grow > M) ? T(0) : g;
-        }
-        out[(size_t)cl * ld + rl] = g - acc[i][j][r];
-      }
-      __builtin_amdgcn_sched_barrier(0);  // keep the 16 column points from being software-pipelined into spills
-    }
-  }
+  const int colbase = k * TS;
+  T *__restrict__ out = Lw + (size_t)rt * TS + (size_t)colbase * ld;
+  const bool cols_full = colbase + TS <= N;
+  const bool fast = cols_full && (extra ? (rowbase + TS <= M) : (rt != k && rowbase + TS <= N));
+  if (fast) gram_tile<T, BROWN, true>(p, acc, out, xr, xc, yc, extra, rowbase, colbase, amp, inv_ell, amp_b, diag_add, lane, wr, wc);
+  else gram_tile<T, BROWN, false>(p, acc, out, xr, xc, yc, extra, rowbase, colbase, amp, inv_ell, amp_b, diag_add, lane, wr, wc);
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -45,6 +45,8 @@ _SIGS = {
     "cgp_llh_to_enu": (ctypes.c_int, [ctypes.c_double] * 3 + [_dp, _dp, _dp]),
     "cgp_predict_stop": (ctypes.c_int, [_dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_double, ctypes.c_int, _dp, _dp, _ip, _dp, _ip, _dp]),
+    "cgp_gppredictor_callback": (ctypes.c_int, [_dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_double,
+                                                ctypes.c_double, ctypes.c_int, _ip, _dp]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -206,3 +208,16 @@ def predict_stop(mean, sigma, PvecData, QvecData, STMvecData, HvecData, pos_llh,
     if rc:
         raise CgpError(rc)
     return bool(fired.value), cmd.value, i.value, xy.value
+
+
+def gppredictor_callback(mean, sigma, PvecData, QvecData, STMvecData, HvecData, pos_llh, arrival_time, now,
+                         h_bug_compatible=True):
+    """One GpPredictor::GPCallBack through the C++ class; returns (n_published, stop_cmd)."""
+    mean, sigma = _d(mean), _d(sigma)
+    npub, cmd = ctypes.c_int(0), ctypes.c_double(0.0)
+    rc = load().cgp_gppredictor_callback(_p(mean), _p(sigma), len(mean), _p(_d(PvecData)), _p(_d(QvecData)),
+                                         _p(_d(STMvecData)), _p(_d(HvecData)), _p(_d(pos_llh)), arrival_time, now,
+                                         int(h_bug_compatible), ctypes.byref(npub), ctypes.byref(cmd))
+    if rc:
+        raise CgpError(rc)
+    return npub.value, cmd.value

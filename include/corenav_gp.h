@@ -130,6 +130,15 @@ int cgp_predict_stop(const double *mean, const double *sigma, int M, const doubl
                      int h_bug_compatible, const double init_llh[3], const double init_ecef[3],
                      int *fired, double *stop_cmd, int *i_out, double *xy_err);
 
+/* One GpPredictor::GPCallBack (gp_predictor.cpp:17-132) through the C++ class in
+ * csrc/gp_predictor.h with an in-process NodeHandle: the SetStopping service answers with the given
+ * arrays, the clock returns `arrival_time` on the first read (:22) and `now` afterwards (:107), and
+ * whatever the node publishes on stop_cmd is returned.  Used by the replay harness and the tests. */
+int cgp_gppredictor_callback(const double *mean, const double *sigma, int M, const double *PvecData,
+                             const double *QvecData, const double *STMvecData, const double *HvecData,
+                             const double pos_llh[3], double arrival_time, double now,
+                             int h_bug_compatible, int *published, double *stop_cmd);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,3 +93,15 @@ def test_synth_generator_is_deterministic():
     assert k1[1].shape == (2, 256, 6) and k1[3].shape == (2, 599, 6)
     t, s = synth.reference_window()
     assert len(t) == 149 and np.all(np.diff(t) == 1) and np.all(np.abs(s) < 1)
+
+
+def test_gppredictor_class_callback():
+    """The GpPredictor C++ class (reference API names) end to end on an in-process NodeHandle."""
+    g = load_golden("lookahead_restated")
+    npub, cmd = engine.gppredictor_callback(g["mean"], g["sigma"], g["PvecData"], g["QvecData"], g["STMvecData"],
+                                            g["HvecData"], g["PosData"], float(g["arrival_time"]), float(g["now"]))
+    assert npub == 1 and cmd == pytest.approx(float(g["stop_cmd"]), rel=1e-12)
+    # nothing is published when the threshold is never crossed (empty horizon)
+    npub, cmd = engine.gppredictor_callback(np.zeros(0), np.zeros(0), g["PvecData"], g["QvecData"], g["STMvecData"],
+                                            g["HvecData"], g["PosData"], 0.0, 0.0)
+    assert npub == 0
