@@ -148,7 +148,7 @@ def main():
                        "inputs": "resident in HBM", "ensemble": ens},
             "roofline": {"bound": "mfma", "kernel": "k_update (syrk/gemm trailing update + fused Gram)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "avg_launch_ms": upd["ms"] / max(upd["launches"], 1),
+                         "traffic": pmc_traffic(B, N, dts), "avg_launch_ms": upd["ms"] / max(upd["launches"], 1),
                          "launches": upd["launches"]},
             "kernel_ms_per_step": {k: v["ms"] / 2 for k, v in prof.items()},
         }
@@ -158,6 +158,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(B, N, dts):
+    """HBM bytes per k_update launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json:
+    FETCH_SIZE and WRITE_SIZE in separate --pmc runs, FETCH doubled for the gfx950 half-count).  Only valid
+    for the configuration the profile was taken on (default workload); otherwise null."""
+    import glob
+    if (B, N, dts) != (256, 2048, "f64"):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["k_update"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(kid, X, y, Xs, th, nsample, dmean, dvar, dlogml, f_fit):

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output (gpurun_out/<tag>_stats, <tag>_pmc1..4) into profiles/<round>_*.
+PMC passes are separate runs (one counter group each), as the MI355X guide prescribes; FETCH_SIZE is
+doubled for the gfx950 half-count of wide coalesced reads (MI355X_MICROARCH.md, HBM section); units KB."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag, rnd = sys.argv[1], sys.argv[2]          # e.g. r1 r01
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, f"{tag}_stats", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{rnd}_kernel_stats.csv"))
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+dur = collections.defaultdict(float)
+for i in range(1, 5):
+    f = os.path.join(src, f"{tag}_pmc{i}", "p_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    for r in csv.DictReader(open(f)):
+        if "cgp::" not in r["Kernel_Name"]:
+            continue
+        k = r["Kernel_Name"].split("cgp::")[1].split("<")[0]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k][r["Counter_Name"]] += 1
+        if r["Counter_Name"] in ("FETCH_SIZE",):
+            dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+out = {}
+for k, v in agg.items():
+    n = max(cnt[k].values())
+    e = {"dispatches": n}
+    for c, val in v.items():
+        e[c + "_per_launch"] = val / cnt[k][c]
+    if "FETCH_SIZE" in v:
+        fetch = 2.0 * v["FETCH_SIZE"] * 1024 / cnt[k]["FETCH_SIZE"]
+        write = v.get("WRITE_SIZE", 0.0) * 1024 / max(cnt[k].get("WRITE_SIZE", 1), 1)
+        e["hbm_bytes_per_launch"] = fetch + write
+        e["hbm_read_bytes_per_launch_x2_corrected"] = fetch
+        e["hbm_write_bytes_per_launch"] = write
+        e["hbm_GBps_in_pmc_run"] = (fetch + write) * cnt[k]["FETCH_SIZE"] / dur[k] / 1e9 if dur[k] else None
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+        e["MfmaUtil"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)   # 8 XCDs, 1024 SIMDs
+    if "TCC_HIT_sum" in v:
+        e["L2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+    out[k] = e
+json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_summary.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
