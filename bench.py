@@ -115,7 +115,8 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    assert int(dinfo.abs().sum().item()) == 0, "a fit reported a non-positive pivot"
+    if not os.environ.get("CGP_DBG"):   # timing ablations produce wrong factors on purpose
+        assert int(dinfo.abs().sum().item()) == 0, "a fit reported a non-positive pivot"
 
     # per-fit summaries gathered over RCCL (the only collective on the path: SURVEY.md 8e)
     summ = torch.stack([dlogml, 2.0 * dvar.to(torch.float64).max(1).values.sqrt(), dinfo.to(torch.float64)], 1)

@@ -3,6 +3,7 @@
 // There is no CPU fallback anywhere in this file: without a usable device cgp_create returns NULL.
 #include "../../include/corenav_gp.h"
 #include "cgp_kernels.hpp"
+#include "cgp_kernels_fused.hpp"
 #include "gp_predictor_core.hpp"
 #include "gp_predictor.h"
 
@@ -117,6 +118,8 @@ template <typename T> int set_lds_attrs() {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trmm<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
   done = true;
   return 0;
 }
@@ -133,6 +136,19 @@ double trsm_flops(int N, int M, int k, bool in_rows, int batch) {
   const double w = std::min(TS, N - k * TS);
   const double rows = (in_rows ? std::max(0, N - (k + 1) * TS) : 0) + (M + 1);
   return batch * rows * w * w;  // w^2/2 multiply-adds per row
+}
+
+// Fused schedule: k_panel = off-diagonal + extra rows of block column k (update + Gram + in-register
+// trmm); k_diag = the diagonal tile (update + Gram + potf2 + inverse).
+double panel_flops(int N, int M, int d, int k, bool in_rows, int batch) {
+  const double w = std::min(TS, N - k * TS);
+  const double rows = (in_rows ? std::max(0, N - (k + 1) * TS) : 0) + (M + 1);
+  return batch * (rows * w * 2.0 * (double)(k * TS) + rows * w * w + (3.0 * d + 2.0) * (rows - 1) * w);
+}
+double diag_flops(int N, int d, int k, int batch) {
+  const double w = std::min(TS, N - k * TS);
+  const double tri = w * (w + 1) / 2.0;
+  return batch * (tri * 2.0 * (double)(k * TS) + (3.0 * d + 2.0) * tri + w * w * w / 3.0 + w * w * w / 3.0);
 }
 
 // Offsets every per-fit pointer of `a` by g0 fits (group view of a batch).
@@ -188,21 +204,33 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   for (int g = 0; g < G; ++g) L.push_back(Launcher{c, gs[g]});
   if (in_rows)
     for (int g = 0; g < G; ++g) HIP_TRY(c, hipMemsetAsync(ga[g].info, 0, sizeof(int) * gb[g], gs[g]));
+  static const bool classic = [] { const char *e = getenv("CGP_SCHED"); return e && std::string(e) == "classic"; }();
   for (int k = 0; k < a.NT; ++k) {
     const int gx_u = (in_rows ? a.NT - k : 0) + a.ET;
     const int gx_t = (in_rows ? a.NT - k - 1 : 0) + a.ET;
     for (int g = 0; g < G; ++g) {
-      L[g].begin(0, update_flops(a.N, a.M, a.d, k, in_rows, gb[g]));
-      hipLaunchKernelGGL(k_update<T>, dim3(gx_u, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
-      L[g].end();
-      if (in_rows) {
-        L[g].begin(1, gb[g] * (double)TS * TS * TS / 3.0);
-        hipLaunchKernelGGL(k_potf2<T>, dim3(gb[g]), dim3(256), tile_lds, gs[g], ga[g], k);
+      if (classic) {  // three launches per step, S tile through HBM (kept for A/B measurements)
+        L[g].begin(0, update_flops(a.N, a.M, a.d, k, in_rows, gb[g]));
+        hipLaunchKernelGGL(k_update<T>, dim3(gx_u, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
+        L[g].end();
+        if (in_rows) {
+          L[g].begin(1, gb[g] * (double)TS * TS * TS / 3.0);
+          hipLaunchKernelGGL(k_potf2<T>, dim3(gb[g]), dim3(256), tile_lds, gs[g], ga[g], k);
+          L[g].end();
+        }
+        L[g].begin(2, trsm_flops(a.N, a.M, k, in_rows, gb[g]));
+        hipLaunchKernelGGL(k_trmm<T>, dim3(gx_t, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
+        L[g].end();
+      } else {
+        if (in_rows) {
+          L[g].begin(1, diag_flops(a.N, a.d, k, gb[g]));
+          hipLaunchKernelGGL(k_diag<T>, dim3(gb[g]), dim3(256), tile_lds, gs[g], ga[g], k);
+          L[g].end();
+        }
+        L[g].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, gb[g]));
+        hipLaunchKernelGGL(k_panel<T>, dim3(gx_t, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
         L[g].end();
       }
-      L[g].begin(2, trsm_flops(a.N, a.M, k, in_rows, gb[g]));
-      hipLaunchKernelGGL(k_trmm<T>, dim3(gx_t, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
-      L[g].end();
     }
   }
   for (int g = 0; g < G; ++g) {

@@ -452,28 +452,15 @@ __global__ __launch_bounds__(256, 2) void k_trmm(FitArgs p, int k) {
 //   then (d) W = L^-1 by block levels (MFMA), kept transposed in the unused upper triangle.
 // LDS tile is column-major with leading dimension LDP.  info = first non-positive pivot (1-based).
 // --------------------------------------------------------------------------------------------------
+// Phases (a)-(d) on an LDS-resident tile: factor it in place (lower triangle), leave W = L^-1
+// transposed in the strict upper triangle and the inverted 16x16 diagonal blocks in Dv.
 template <typename T>
-__global__ __launch_bounds__(256) void k_potf2(FitArgs p, int k) {
+__device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, int k, int tid) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T *At = reinterpret_cast<T *>(smem_raw);  // element (r, c) at At[c * LDP + r]
-  T *Dv = At + TS * LDP;                     // Dv[jb][q][x] = Dinv_jb[x][q]
-  T *Ts = Dv + 8 * DB * DB;                  // per-wave 16x16 scratch
-  int *flag = reinterpret_cast<int *>(Ts + 4 * DB * DB);
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
-  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
-  const int ld = p.ld;
-  T *tile = Lw + (size_t)(k * TS) * ld + (size_t)k * TS;
-  for (int idx = tid; idx < TS * TS; idx += 256) {
-    const int c = idx >> 7, r = idx & 127;
-    At[c * LDP + r] = tile[(size_t)c * ld + r];
-  }
-  if (tid == 0) *flag = 0;
-  __syncthreads();
-
   for (int jb = 0; jb < TS / DB; ++jb) {
     const int j0 = jb * DB;
     if (wave == 0) {
@@ -596,7 +583,12 @@ __global__ __launch_bounds__(256) void k_potf2(FitArgs p, int k) {
     __syncthreads();
   }
 
-  // (e) write L (upper triangle zeroed) and W (column-major 128 x 128, lower triangular)
+}
+
+// Phase (e): write L (upper triangle zeroed) to the factor panel and W_k (column-major 128 x 128).
+template <typename T>
+__device__ __forceinline__ void potf2_store(const FitArgs &p, const T *At, const T *Dv, const int *flag, T *tile,
+                                            int ld, int b, int k, int tid) {
   if (tid == 0 && *flag != 0 && p.info[b] == 0) p.info[b] = *flag;
   T *Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * TS * TS;
   for (int idx = tid; idx < TS * TS; idx += 256) {
@@ -609,6 +601,27 @@ __global__ __launch_bounds__(256) void k_potf2(FitArgs p, int k) {
     }
     Wk[(size_t)c * TS + r] = w;
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_potf2(FitArgs p, int k) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *At = reinterpret_cast<T *>(smem_raw);  // element (r, c) at At[c * LDP + r]
+  T *Dv = At + TS * LDP;                     // Dv[jb][q][x] = Dinv_jb[x][q]
+  T *Ts = Dv + 8 * DB * DB;                  // per-wave 16x16 scratch
+  int *flag = reinterpret_cast<int *>(Ts + 4 * DB * DB);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const int ld = p.ld;
+  T *tile = Lw + (size_t)(k * TS) * ld + (size_t)k * TS;
+  for (int idx = tid; idx < TS * TS; idx += 256) {
+    const int c = idx >> 7, r = idx & 127;
+    At[c * LDP + r] = tile[(size_t)c * ld + r];
+  }
+  if (tid == 0) *flag = 0;
+  __syncthreads();
+  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid);
+  potf2_store<T>(p, At, Dv, flag, tile, ld, b, k, tid);
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -1,0 +1,369 @@
+// cgp_kernels_fused.hpp -- the two-launch-per-step schedule:
+//   k_diag(k)  : one workgroup per fit.  S(k,k) = G(k,k) - sum_j L(k,j) L(k,j)^T on the MFMA loop,
+//                then potf2 + inverse of that tile without leaving the CU (L(k,k), W_k written).
+//   k_panel(k) : every row tile below k and every extra tile.  S(i,k) as above, kept in the MFMA
+//                accumulators, multiplied by W_k^T IN REGISTERS and stored once as L(i,k): the S
+//                tile never goes to HBM and there is no separate trsm/trmm launch.
+// The in-register product works because the C/D layout of v_mfma_*_16x16x4 is also a valid B-operand
+// layout: accumulator register r of lane (n = lane&15, kq = lane>>4) holds S[row n][col drow(lane,r)],
+// which is B[k = kq][n] of an MFMA whose four k-values are the columns {drow(lane', r)}; the A operand
+// supplies W[c][same columns].  Waves are laid out 4 x 1 (32 rows x 128 columns each) so every
+// column block a wave needs for the triangular product is in its own registers.
+#pragma once
+#include "cgp_kernels.hpp"
+
+namespace cgp {
+
+constexpr int NCB = TS / DB;  // 8 column blocks of 16
+
+// acc[cb][j][reg] = C[row = wave*32 + 2*(lane&15) + j][col = cb*16 + drow(lane, reg)].
+// Rows are interleaved (2*l15 + j) so one lane owns two adjacent rows: 16-byte stores, and the two
+// row fragments of a k-step come out of one 16-byte LDS read.
+template <typename T>
+__device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc)[NCB][2], const T *gR, size_t ldR,
+                                                   const T *gC, size_t ldC, int nchunk, T *smem, int tid) {
+  using P = Prec<T>;
+  using vec8 = T __attribute__((ext_vector_type(8)));
+  using vec2 = T __attribute__((ext_vector_type(2)));
+  constexpr int CH = KT * LDST;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  auto compute = [&](const T *cur) {
+#pragma unroll
+    for (int ks = 0; ks < KT / 4; ++ks) {
+      T fa[NCB];
+      const T *ra = cur + CH + (ks * 4 + lq) * LDST + l15;  // column panel -> result columns
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) fa[cb] = ra[cb * DB];
+      const vec2 fb = *reinterpret_cast<const vec2 *>(cur + (ks * 4 + lq) * LDST + wave * 32 + 2 * l15);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        acc[cb][0] = P::mfma(fa[cb], fb[0], acc[cb][0]);
+        acc[cb][1] = P::mfma(fa[cb], fb[1], acc[cb][1]);
+      }
+    }
+  };
+
+  if constexpr (sizeof(T) == 8) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    auto stage = [&](T *buf, int chunk) {
+#pragma unroll
+      for (int i = 0; i < KT / 4; ++i) {
+        const int col = wave * (KT / 4) + i;
+        __builtin_amdgcn_global_load_lds((gbl_void *)(gR + (size_t)(chunk * KT + col) * ldR + lane * 2),
+                                         (lds_void *)(buf + col * LDST), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void *)(gC + (size_t)(chunk * KT + col) * ldC + lane * 2),
+                                         (lds_void *)(buf + CH + col * LDST), 16, 0, 0);
+      }
+    };
+    if (nchunk > 0) stage(smem, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+      if (c + 1 < nchunk) stage(smem + ((c + 1) & 1) * 2 * CH, c + 1);
+      compute(smem + (c & 1) * 2 * CH);
+      __syncthreads();
+    }
+  } else {
+    const int sc = tid >> 4, sr = (tid & 15) * 8;
+    gR += sr;
+    gC += sr;
+    vec8 pr, pc;
+    if (nchunk > 0) {
+      pr = *reinterpret_cast<const vec8 *>(gR + (size_t)sc * ldR);
+      pc = *reinterpret_cast<const vec8 *>(gC + (size_t)sc * ldC);
+      *reinterpret_cast<vec8 *>(smem + sc * LDST + sr) = pr;
+      *reinterpret_cast<vec8 *>(smem + CH + sc * LDST + sr) = pc;
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+      if (c + 1 < nchunk) {
+        pr = *reinterpret_cast<const vec8 *>(gR + (size_t)((c + 1) * KT + sc) * ldR);
+        pc = *reinterpret_cast<const vec8 *>(gC + (size_t)((c + 1) * KT + sc) * ldC);
+      }
+      compute(smem + (c & 1) * 2 * CH);
+      if (c + 1 < nchunk) {
+        T *nxt = smem + ((c + 1) & 1) * 2 * CH;
+        *reinterpret_cast<vec8 *>(nxt + sc * LDST + sr) = pr;
+        *reinterpret_cast<vec8 *>(nxt + CH + sc * LDST + sr) = pc;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// General exp (|x| small enough not to overflow): the covariance exponent with log(amplitude)
+// folded in can be slightly positive.  Same reduction / polynomial as exp_nonpos.
+__device__ __forceinline__ double exp_gen(double x, const ExpC &e) { return exp_nonpos(x, e); }
+__device__ __forceinline__ float exp_gen(float x, const ExpC &) { return __expf(fmaxf(x, -104.f)); }
+
+constexpr int GK = 12;  // augmented point length: MAXD coordinates, 2 norm slots, padded to a multiple of 4
+
+// acc <- G - acc, in registers.  The covariance exponent e_ij = -0.5 |a_i - b_j|^2 (+ log amplitude)
+// is itself an inner product of augmented points
+//     a' = (a, -0.5|a|^2 + log amp, 1)        b' = (b, 1, -0.5|b|^2)
+// so it is produced by three MFMA 16x16x4 per 16x16 block straight into the accumulator layout; the
+// VALU then only evaluates exp.  (This is the x^2 + x'^2 - 2xx' expansion GPy itself uses for r^2;
+// its rounding error is ~1e-16 |x|^2 absolute in the exponent.)  FAST = interior tile: no selects.
+template <typename T, bool BROWN, bool FAST>
+__device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2],
+                                                const T *__restrict__ xrT, const T *__restrict__ xcT,
+                                                const T *__restrict__ xraw, const T *__restrict__ craw,
+                                                const T *__restrict__ yc, bool extra, int rowbase, int colbase, T amp,
+                                                T amp_b, T diag_add, int lane, int wave) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
+  const int N = p.N, M = p.M, l15 = lane & 15, lq = lane >> 4;
+  ExpC ec;
+  ec.load();
+  T fb[2][GK / 4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int s = 0; s < GK / 4; ++s) fb[j][s] = xrT[(4 * s + lq) * TS + wave * 32 + 2 * l15 + j];
+  T xrw[2] = {T(0), T(0)};
+  if (BROWN) {
+    xrw[0] = xraw[wave * 32 + 2 * l15];
+    xrw[1] = xraw[wave * 32 + 2 * l15 + 1];
+  }
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    T fa[GK / 4];
+#pragma unroll
+    for (int s = 0; s < GK / 4; ++s) fa[s] = xcT[(4 * s + lq) * TS + cb * DB + l15];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc_t e = acc_t{0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < GK / 4; ++s) e = P::mfma(fa[s], fb[j][s], e);
+      const int grow = rowbase + wave * 32 + 2 * l15 + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cl = cb * DB + P::drow(lane, r);
+        const int gcol = colbase + cl;
+        T g;
+        if (!BROWN) {
+          g = (p.dbg & 128) ? e[r] : exp_gen(e[r], ec);
+        } else {
+          const T x = xrw[j], xp = craw[cl];
+          const bool same = !FAST && !extra && grow == gcol;  // GPy forces r^2 = 0 on the auto-covariance diagonal
+          T ee = e[r] > T(0) ? T(0) : e[r];                   // r^2 clipped at 0
+          ee = same ? T(0) : ee;
+          const int sx = (x > T(0)) - (x < T(0)), sp = (xp > T(0)) - (xp < T(0));
+          const T ax = x < T(0) ? -x : x, ap = xp < T(0) ? -xp : xp;
+          const T kb = (sx == sp) ? amp_b * (ax < ap ? ax : ap) : T(0);
+          g = amp * exp_gen(ee, ec) * kb;
+        }
+        if (!FAST) {
+          const bool colok = gcol < N;
+          if (!extra) {
+            const bool dg = grow == gcol;
+            g = dg ? g + diag_add : g;
+            g = (grow < N && colok) ? g : (dg ? T(1) : T(0));  // identity padding keeps the factor well defined
+          } else {
+            g = (grow == M) ? yc[cl] : g;
+            g = (!colok || grow > M) ? T(0) : g;
+          }
+        }
+        acc[cb][j][r] = g - acc[cb][j][r];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one 16x16 block (4 independent exp chains) at a time
+    }
+  }
+}
+
+// Stages the augmented points of tile (rt, k) in LDS ([GK][128], component-major) and applies
+// acc <- G - acc.  Thread t < 128 prepares row point t, thread t >= 128 column point t - 128.
+template <typename T>
+__device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
+                                           int b, int k, int rt, int tid) {
+  const double *__restrict__ th = p.theta + (size_t)b * MAX_THETA;
+  const int kid = p.kernel_id, d = p.d, N = p.N, M = p.M;
+  const bool extra = rt >= p.NT;
+  const bool brown = kid == K_RBF_BROWNIAN;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  T *xrT = smem;                 // [GK][128] augmented row points
+  T *xcT = smem + GK * TS;       // [GK][128] augmented column points
+  T *xraw = smem + 2 * GK * TS;  // [128] raw first coordinate of the row points (Brownian factor)
+  T *craw = xraw + TS;           // [128] raw first coordinate of the column points
+  T *yc = craw + TS;             // [128] y of the tile-k columns (only the y row uses it)
+  const T *__restrict__ Xb = reinterpret_cast<const T *>(p.X) + (size_t)b * d * N;
+  const T *__restrict__ Xsb = reinterpret_cast<const T *>(p.Xs) + (size_t)b * d * M;
+  const T *__restrict__ yb = reinterpret_cast<const T *>(p.y) + (size_t)b * N;
+  const T amp = T(th[0]);
+  const T lamp = brown ? T(0) : T(log(th[0]));  // SE: log amplitude folded into the exponent
+  {
+    const bool isrow = tid < TS;
+    const int r = tid & 127;
+    const T *src = nullptr;
+    int idx = 0, len = 0;
+    if (isrow) {
+      if (!extra) { src = Xb; idx = rt * TS + r; len = N; }
+      else { src = Xsb; idx = (rt - p.NT) * TS + r; len = M; }
+    } else { src = Xb; idx = k * TS + r; len = N; }
+    const bool ok = idx < len;
+    T nrm = 0, x0 = 0;
+    T *dst = isrow ? xrT : xcT;
+#pragma unroll
+    for (int q = 0; q < MAXD; ++q) {
+      T v = T(0);
+      if (q < d && ok) {
+        T sc_q;
+        if (kid == K_SE_ISO) sc_q = T(1.0 / th[1]);
+        else if (kid == K_SE_ARD) sc_q = T(1.0 / th[1 + q]);
+        else sc_q = T(1.0 / th[1]);
+        const T raw = src[(size_t)q * len + idx];
+        if (q == 0) x0 = raw;
+        v = raw * sc_q;
+      }
+      nrm = __builtin_fma(v, v, nrm);
+      dst[q * TS + r] = v;
+    }
+    dst[MAXD * TS + r] = isrow ? (T(-0.5) * nrm + lamp) : T(1);
+    dst[(MAXD + 1) * TS + r] = isrow ? T(1) : T(-0.5) * nrm;
+    dst[(MAXD + 2) * TS + r] = T(0);
+    dst[(MAXD + 3) * TS + r] = T(0);
+    if (isrow) xraw[r] = x0;
+    else {
+      craw[r] = x0;
+      yc[r] = ok ? yb[idx] : T(0);
+    }
+  }
+  __syncthreads();
+  const T amp_b = brown ? T(th[2]) : T(0);
+  const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
+  const T diag_add = T(th[nth - 1] + 1e-8 + (p.jitter ? p.jitter[b] : 0.0));
+  const int rowbase = extra ? (rt - p.NT) * TS : rt * TS;
+  const int colbase = k * TS;
+  const bool fast = (colbase + TS <= N) && (extra ? (rowbase + TS <= M) : (rt != k && rowbase + TS <= N));
+  if (brown) {
+    if (fast) gram_apply_tile<T, true, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
+    else gram_apply_tile<T, true, false>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
+  } else {
+    if (fast) gram_apply_tile<T, false, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
+    else gram_apply_tile<T, false, false>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// k_panel: L(rt, k) = (G(rt,k) - sum_{j<k} L(rt,j) L(k,j)^T) W_k^T   (a2 + a3 syrk/gemm + trsm + a8)
+// --------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
+  using vec2 = T __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  int bt, b;
+  tile_fit_of_block(bt, b);
+  const int rt = row_tile_of(bt, k + 1, p.NT, p.rows_from_extra);
+  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const int ld = p.ld;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15;
+
+  acc_t acc[NCB][2];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = acc_t{0, 0, 0, 0};
+  mfma_rowpanel_loop<T>(acc, Lw + (size_t)rt * TS, (size_t)ld, Lw + (size_t)k * TS, (size_t)ld, (k * TS) / KT, smem, tid);
+  if (!(p.dbg & 8)) gram_apply<T>(p, acc, smem, b, k, rt, tid);
+  __syncthreads();  // every wave is done with the staged inputs before W_k overwrites them
+  if (!(p.dbg & 64)) {
+
+  // W_k (lower triangular) -> LDS as 36 blocks of 16x16: Wl[blk(cb,qb)][q][c] = W[cb*16 + c][qb*16 + q]
+  const T *__restrict__ Wk = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * TS * TS;
+  {
+    const int q = tid >> 4, c = tid & 15;
+    int cb = 0, qb = 0;
+#pragma unroll 6
+    for (int blk = 0; blk < NCB * (NCB + 1) / 2; ++blk) {
+      smem[blk * DB * DB + tid] = Wk[(size_t)(qb * DB + q) * TS + cb * DB + c];
+      if (++qb > cb) {
+        ++cb;
+        qb = 0;
+      }
+    }
+  }
+  __syncthreads();
+
+  // in-register triangular product, descending column blocks so L(:, cb) may overwrite S(:, cb)
+#pragma unroll
+  for (int cb = NCB - 1; cb >= 0; --cb) {
+    acc_t t0 = acc_t{0, 0, 0, 0}, t1 = t0;
+    const T *wrow = smem + (cb * (cb + 1) / 2) * DB * DB + l15;
+#pragma unroll
+    for (int qb = 0; qb <= cb; ++qb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const T a = wrow[qb * DB * DB + P::drow(lane, r) * DB];  // W[cb*16 + l15][qb*16 + drow(lane, r)]
+        t0 = P::mfma(a, acc[qb][0][r], t0);
+        t1 = P::mfma(a, acc[qb][1][r], t1);
+      }
+    }
+    acc[cb][0] = t0;
+    acc[cb][1] = t1;
+    __builtin_amdgcn_sched_barrier(0);  // one column block at a time: bounds the live W fragments
+  }
+  }
+
+  T *__restrict__ out = Lw + (size_t)(k * TS) * ld + (size_t)rt * TS + wave * 32 + 2 * l15;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vec2 v;
+      v[0] = acc[cb][0][r];
+      v[1] = acc[cb][1][r];
+      *reinterpret_cast<vec2 *>(out + (size_t)(cb * DB + P::drow(lane, r)) * ld) = v;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// k_diag: the diagonal tile of block step k, updated, factored and inverted by one workgroup.
+// --------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
+  using vec2 = T __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  const int b = blockIdx.x;
+  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const int ld = p.ld;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15;
+
+  acc_t acc[NCB][2];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = acc_t{0, 0, 0, 0};
+  mfma_rowpanel_loop<T>(acc, Lw + (size_t)k * TS, (size_t)ld, Lw + (size_t)k * TS, (size_t)ld, (k * TS) / KT, smem, tid);
+  gram_apply<T>(p, acc, smem, b, k, k, tid);
+  __syncthreads();
+
+  T *At = smem;                // element (r, c) at At[c * LDP + r]
+  T *Dv = At + TS * LDP;
+  T *Ts = Dv + 8 * DB * DB;
+  int *flag = reinterpret_cast<int *>(Ts + 4 * DB * DB);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vec2 v;
+      v[0] = acc[cb][0][r];
+      v[1] = acc[cb][1][r];
+      *reinterpret_cast<vec2 *>(At + (cb * DB + P::drow(lane, r)) * LDP + wave * 32 + 2 * l15) = v;
+    }
+  if (tid == 0) *flag = 0;
+  __syncthreads();
+  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid);
+  potf2_store<T>(p, At, Dv, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
+}
+
+}  // namespace cgp
