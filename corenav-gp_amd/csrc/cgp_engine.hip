@@ -45,7 +45,7 @@ struct cgp_ctx {
   // device buffers
   void *Lw = nullptr, *Winv = nullptr, *dX = nullptr, *dXs = nullptr, *dy = nullptr;
   void *dmean = nullptr, *dvar = nullptr, *dalpha = nullptr;
-  double *dtheta = nullptr, *djitter = nullptr, *dlogml = nullptr;
+  double *dtheta = nullptr, *djitter = nullptr, *dlogml = nullptr, *dprep = nullptr;
   int *dinfo = nullptr;
   size_t lw_stride = 0, winv_stride = 0, alpha_stride = 0;
   // state of the last single fit (cgp_fit -> cgp_predict)
@@ -167,6 +167,7 @@ template <typename T> FitArgs group_view(const FitArgs &a, int g0) {
   v.alpha = const_cast<void *>(adv(a.alpha, (size_t)g0 * a.alpha_stride));
   v.theta = a.theta + (size_t)g0 * MAX_THETA;
   v.jitter = a.jitter ? a.jitter + g0 : nullptr;
+  v.prep = a.prep ? a.prep + (size_t)g0 * PREP_N : nullptr;
   v.logml = a.logml ? a.logml + g0 : nullptr;
   v.info = a.info ? a.info + g0 : nullptr;
   return v;
@@ -196,6 +197,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     gs[g] = (G == 1) ? s : c->wstream[g];
     g0 += gb[g];
   }
+  hipLaunchKernelGGL(k_prep, dim3(cdiv(batch, 64)), dim3(64), 0, s, a, batch, c->dprep);
   if (G > 1) {
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
     for (int g = 0; g < G; ++g) HIP_TRY(c, hipStreamWaitEvent(gs[g], c->ev_fork, 0));
@@ -267,6 +269,7 @@ FitArgs base_args(cgp_ctx *c, int N, int d, int M, int kid, int include_noise) {
   a.winv_stride = c->winv_stride;
   a.alpha = c->dalpha;
   a.alpha_stride = c->alpha_stride;
+  a.prep = c->dprep;
   a.N = N;
   a.d = d;
   a.M = M;
@@ -391,6 +394,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc(&c->dalpha, B * c->alpha_stride * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dtheta, B * CGP_MAX_THETA * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->djitter, B * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->dprep, B * PREP_N * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dlogml, B * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dinfo, B * sizeof(int)) == hipSuccess;
   if (!ok) {
@@ -409,7 +413,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {

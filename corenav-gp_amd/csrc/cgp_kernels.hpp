@@ -31,6 +31,7 @@ constexpr int LDST = 144;  // LDS row stride of a staged chunk (elements): (144*
 constexpr int DB = 16;     // diagonal sub-block of potf2 / trsm
 constexpr int MAXD = 8;
 constexpr int MAX_THETA = MAXD + 2;
+constexpr int PREP_N = 16;  // prep[0..7] 1/ell_q, [8] log amp (SE) or 0, [9] amp, [10] amp_b, [11] diag add
 constexpr int LDP = TS + 2;   // LDS leading dimension of the potf2 tile (2-way conflicts at most)
 
 enum { K_SE_ISO = 0, K_SE_ARD = 1, K_RBF_BROWNIAN = 2 };
@@ -44,6 +45,7 @@ struct FitArgs {
   const void *y;         // [batch][N]
   const double *theta;   // [batch][MAX_THETA]
   const double *jitter;  // [batch] or nullptr
+  const double *prep;    // [batch][PREP_N] per-fit derived constants written by k_prep
   void *Winv;            // [batch][NTmax][128*128]  W_k = L(k,k)^-1, column-major, lower triangular
   size_t winv_stride;    // elements per fit
   int *info;             // [batch]

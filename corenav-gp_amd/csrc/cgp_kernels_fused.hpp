@@ -19,7 +19,30 @@ constexpr int NCB = TS / DB;  // 8 column blocks of 16
 // acc[cb][j][reg] = C[row = wave*32 + 2*(lane&15) + j][col = cb*16 + drow(lane, reg)].
 // Rows are interleaved (2*l15 + j) so one lane owns two adjacent rows: 16-byte stores, and the two
 // row fragments of a k-step come out of one 16-byte LDS read.
+// Chunk 0 of both panels into LDS buffer 0 (issued before the Gram phase so it lands under it).
 template <typename T>
+__device__ __forceinline__ void stage_first_chunk(const T *gR, size_t ldR, const T *gC, size_t ldC, T *smem, int tid) {
+  constexpr int CH = KT * LDST;
+  if constexpr (sizeof(T) == 8) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int i = 0; i < KT / 4; ++i) {
+      const int col = wave * (KT / 4) + i;
+      __builtin_amdgcn_global_load_lds((gbl_void *)(gR + (size_t)col * ldR + lane * 2), (lds_void *)(smem + col * LDST), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void *)(gC + (size_t)col * ldC + lane * 2), (lds_void *)(smem + CH + col * LDST), 16, 0, 0);
+    }
+  } else {
+    using vec8 = T __attribute__((ext_vector_type(8)));
+    const int sc = tid >> 4, sr = (tid & 15) * 8;
+    *reinterpret_cast<vec8 *>(smem + sc * LDST + sr) = *reinterpret_cast<const vec8 *>(gR + sr + (size_t)sc * ldR);
+    *reinterpret_cast<vec8 *>(smem + CH + sc * LDST + sr) = *reinterpret_cast<const vec8 *>(gC + sr + (size_t)sc * ldC);
+  }
+}
+
+template <typename T, bool PRESTAGED = false>
 __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc)[NCB][2], const T *gR, size_t ldR,
                                                    const T *gC, size_t ldC, int nchunk, T *smem, int tid) {
   using P = Prec<T>;
@@ -59,7 +82,7 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
                                          (lds_void *)(buf + CH + col * LDST), 16, 0, 0);
       }
     };
-    if (nchunk > 0) stage(smem, 0);
+    if (nchunk > 0 && !PRESTAGED) stage(smem, 0);
     __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
       if (c + 1 < nchunk) stage(smem + ((c + 1) & 1) * 2 * CH, c + 1);
@@ -71,7 +94,7 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
     gR += sr;
     gC += sr;
     vec8 pr, pc;
-    if (nchunk > 0) {
+    if (nchunk > 0 && !PRESTAGED) {
       pr = *reinterpret_cast<const vec8 *>(gR + (size_t)sc * ldR);
       pc = *reinterpret_cast<const vec8 *>(gC + (size_t)sc * ldC);
       *reinterpret_cast<vec8 *>(smem + sc * LDST + sr) = pr;
@@ -101,7 +124,7 @@ __device__ __forceinline__ float exp_gen(float x, const ExpC &) { return __expf(
 
 constexpr int GK = 12;  // augmented point length: MAXD coordinates, 2 norm slots, padded to a multiple of 4
 
-// acc <- G - acc, in registers.  The covariance exponent e_ij = -0.5 |a_i - b_j|^2 (+ log amplitude)
+// acc <- -G, in registers (the MFMA loop then adds L L^T, so acc ends as -S).  The covariance exponent e_ij = -0.5 |a_i - b_j|^2 (+ log amplitude)
 // is itself an inner product of augmented points
 //     a' = (a, -0.5|a|^2 + log amp, 1)        b' = (b, 1, -0.5|b|^2)
 // so it is produced by three MFMA 16x16x4 per 16x16 block straight into the accumulator layout; the
@@ -167,20 +190,71 @@ __device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<
             g = (!colok || grow > M) ? T(0) : g;
           }
         }
-        acc[cb][j][r] = g - acc[cb][j][r];
+        acc[cb][j][r] = -g;
       }
-      __builtin_amdgcn_sched_barrier(0);  // one 16x16 block (4 independent exp chains) at a time
     }
+    __builtin_amdgcn_sched_barrier(0);  // two 16x16 blocks (8 independent exp chains) at a time
   }
 }
 
+// Per-fit derived constants (inverse length-scales, log amplitude, diagonal addend), computed once
+// per schedule so the tile kernels read them with scalar loads instead of dividing per thread.
+__global__ void k_prep(FitArgs p, int batch, double *prep) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const double *th = p.theta + (size_t)b * MAX_THETA;
+  double *o = prep + (size_t)b * PREP_N;
+  const int kid = p.kernel_id, d = p.d;
+  for (int q = 0; q < MAXD; ++q) {
+    double s = 0.0;
+    if (q < d) s = (kid == K_SE_ARD) ? 1.0 / th[1 + q] : 1.0 / th[1];
+    o[q] = s;
+  }
+  const bool brown = kid == K_RBF_BROWNIAN;
+  o[8] = brown ? 0.0 : log(th[0]);
+  o[9] = th[0];
+  o[10] = brown ? th[2] : 0.0;
+  const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
+  o[11] = th[nth - 1] + 1e-8 + (p.jitter ? p.jitter[b] : 0.0);
+  for (int q = 12; q < PREP_N; ++q) o[q] = 0.0;
+}
+
+// The raw coordinates of the point a thread prepares for the Gram tile (thread t < 128: row point t,
+// t >= 128: column point t - 128), fetched at kernel entry so their HBM latency is hidden behind
+// the MFMA loop.
+template <typename T> struct GramPre {
+  T v[MAXD];
+  T yv;
+};
+
+template <typename T>
+__device__ __forceinline__ void gram_prefetch(const FitArgs &p, int b, int k, int rt, int tid, GramPre<T> &g) {
+  const int d = p.d, N = p.N, M = p.M;
+  const bool extra = rt >= p.NT;
+  const T *__restrict__ Xb = reinterpret_cast<const T *>(p.X) + (size_t)b * d * N;
+  const T *__restrict__ Xsb = reinterpret_cast<const T *>(p.Xs) + (size_t)b * d * M;
+  const T *__restrict__ yb = reinterpret_cast<const T *>(p.y) + (size_t)b * N;
+  const bool isrow = tid < TS;
+  const int r = tid & 127;
+  const T *src = Xb;
+  int idx, len = N;
+  if (isrow) {
+    if (!extra) idx = rt * TS + r;
+    else { src = Xsb; idx = (rt - p.NT) * TS + r; len = M; }
+  } else idx = k * TS + r;
+  const bool ok = idx < len;
+#pragma unroll
+  for (int q = 0; q < MAXD; ++q) g.v[q] = (q < d && ok) ? src[(size_t)q * len + idx] : T(0);
+  g.yv = (!isrow && ok) ? yb[idx] : T(0);
+}
+
 // Stages the augmented points of tile (rt, k) in LDS ([GK][128], component-major) and applies
-// acc <- G - acc.  Thread t < 128 prepares row point t, thread t >= 128 column point t - 128.
+// acc <- G - acc.
 template <typename T>
 __device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
-                                           int b, int k, int rt, int tid) {
-  const double *__restrict__ th = p.theta + (size_t)b * MAX_THETA;
-  const int kid = p.kernel_id, d = p.d, N = p.N, M = p.M;
+                                           int b, int k, int rt, int tid, const GramPre<T> &g) {
+  const double *__restrict__ pr = p.prep + (size_t)b * PREP_N;
+  const int kid = p.kernel_id, N = p.N, M = p.M;
   const bool extra = rt >= p.NT;
   const bool brown = kid == K_RBF_BROWNIAN;
   const int lane = tid & 63;
@@ -190,52 +264,29 @@ __device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::a
   T *xraw = smem + 2 * GK * TS;  // [128] raw first coordinate of the row points (Brownian factor)
   T *craw = xraw + TS;           // [128] raw first coordinate of the column points
   T *yc = craw + TS;             // [128] y of the tile-k columns (only the y row uses it)
-  const T *__restrict__ Xb = reinterpret_cast<const T *>(p.X) + (size_t)b * d * N;
-  const T *__restrict__ Xsb = reinterpret_cast<const T *>(p.Xs) + (size_t)b * d * M;
-  const T *__restrict__ yb = reinterpret_cast<const T *>(p.y) + (size_t)b * N;
-  const T amp = T(th[0]);
-  const T lamp = brown ? T(0) : T(log(th[0]));  // SE: log amplitude folded into the exponent
   {
     const bool isrow = tid < TS;
     const int r = tid & 127;
-    const T *src = nullptr;
-    int idx = 0, len = 0;
-    if (isrow) {
-      if (!extra) { src = Xb; idx = rt * TS + r; len = N; }
-      else { src = Xsb; idx = (rt - p.NT) * TS + r; len = M; }
-    } else { src = Xb; idx = k * TS + r; len = N; }
-    const bool ok = idx < len;
-    T nrm = 0, x0 = 0;
     T *dst = isrow ? xrT : xcT;
+    T nrm = 0;
 #pragma unroll
     for (int q = 0; q < MAXD; ++q) {
-      T v = T(0);
-      if (q < d && ok) {
-        T sc_q;
-        if (kid == K_SE_ISO) sc_q = T(1.0 / th[1]);
-        else if (kid == K_SE_ARD) sc_q = T(1.0 / th[1 + q]);
-        else sc_q = T(1.0 / th[1]);
-        const T raw = src[(size_t)q * len + idx];
-        if (q == 0) x0 = raw;
-        v = raw * sc_q;
-      }
+      const T v = g.v[q] * T(pr[q]);
       nrm = __builtin_fma(v, v, nrm);
       dst[q * TS + r] = v;
     }
-    dst[MAXD * TS + r] = isrow ? (T(-0.5) * nrm + lamp) : T(1);
+    dst[MAXD * TS + r] = isrow ? (T(-0.5) * nrm + T(pr[8])) : T(1);
     dst[(MAXD + 1) * TS + r] = isrow ? T(1) : T(-0.5) * nrm;
     dst[(MAXD + 2) * TS + r] = T(0);
     dst[(MAXD + 3) * TS + r] = T(0);
-    if (isrow) xraw[r] = x0;
+    if (isrow) xraw[r] = g.v[0];
     else {
-      craw[r] = x0;
-      yc[r] = ok ? yb[idx] : T(0);
+      craw[r] = g.v[0];
+      yc[r] = g.yv;
     }
   }
   __syncthreads();
-  const T amp_b = brown ? T(th[2]) : T(0);
-  const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
-  const T diag_add = T(th[nth - 1] + 1e-8 + (p.jitter ? p.jitter[b] : 0.0));
+  const T amp = T(pr[9]), amp_b = T(pr[10]), diag_add = T(pr[11]);
   const int rowbase = extra ? (rt - p.NT) * TS : rt * TS;
   const int colbase = k * TS;
   const bool fast = (colbase + TS <= N) && (extra ? (rowbase + TS <= M) : (rt != k && rowbase + TS <= N));
@@ -267,11 +318,19 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15;
 
+  // Gram first: acc = -G(rt, k) while nothing else is live in the register file, with chunk 0 of the
+  // panels already in flight into LDS buffer 0 (the Gram inputs are staged in buffer 1's space).
+  constexpr int CH2 = 2 * KT * LDST;
   acc_t acc[NCB][2];
-#pragma unroll
-  for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = acc_t{0, 0, 0, 0};
-  mfma_rowpanel_loop<T>(acc, Lw + (size_t)rt * TS, (size_t)ld, Lw + (size_t)k * TS, (size_t)ld, (k * TS) / KT, smem, tid);
-  if (!(p.dbg & 8)) gram_apply<T>(p, acc, smem, b, k, rt, tid);
+  const T *gR = Lw + (size_t)rt * TS, *gC = Lw + (size_t)k * TS;
+  const int nchunk = (k * TS) / KT;
+  {
+    GramPre<T> gp;
+    gram_prefetch<T>(p, b, k, rt, tid, gp);
+    if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
+    gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
+  }
+  mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
   __syncthreads();  // every wave is done with the staged inputs before W_k overwrites them
   if (!(p.dbg & 64)) {
 
@@ -300,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
     for (int qb = 0; qb <= cb; ++qb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const T a = wrow[qb * DB * DB + P::drow(lane, r) * DB];  // W[cb*16 + l15][qb*16 + drow(lane, r)]
+        const T a = -wrow[qb * DB * DB + P::drow(lane, r) * DB];  // -W[cb*16 + l15][qb*16 + drow(lane, r)] (acc = -S)
         t0 = P::mfma(a, acc[qb][0][r], t0);
         t1 = P::mfma(a, acc[qb][1][r], t1);
       }
@@ -340,11 +399,17 @@ __global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15;
 
+  constexpr int CH2 = 2 * KT * LDST;
   acc_t acc[NCB][2];
-#pragma unroll
-  for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = acc_t{0, 0, 0, 0};
-  mfma_rowpanel_loop<T>(acc, Lw + (size_t)k * TS, (size_t)ld, Lw + (size_t)k * TS, (size_t)ld, (k * TS) / KT, smem, tid);
-  gram_apply<T>(p, acc, smem, b, k, k, tid);
+  const T *gR = Lw + (size_t)k * TS;
+  const int nchunk = (k * TS) / KT;
+  {
+    GramPre<T> gp;
+    gram_prefetch<T>(p, b, k, k, tid, gp);
+    if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gR, (size_t)ld, smem, tid);
+    gram_apply<T>(p, acc, smem + CH2, b, k, k, tid, gp);
+  }
+  mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gR, (size_t)ld, nchunk, smem, tid);
   __syncthreads();
 
   T *At = smem;                // element (r, c) at At[c * LDP + r]
@@ -356,8 +421,8 @@ __global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       vec2 v;
-      v[0] = acc[cb][0][r];
-      v[1] = acc[cb][1][r];
+      v[0] = -acc[cb][0][r];
+      v[1] = -acc[cb][1][r];
       *reinterpret_cast<vec2 *>(At + (cb * DB + P::drow(lane, r)) * LDP + wave * 32 + 2 * l15) = v;
     }
   if (tid == 0) *flag = 0;
