@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--n", type=int, default=None, help="override window length N")
     ap.add_argument("--cpu-sample", type=int, default=6, help="fits timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="worker streams the batch is spread over")
+    ap.add_argument("--streams", type=int, default=2, help="worker streams the batch is spread over")
     args = ap.parse_args()
 
     import torch
@@ -123,7 +123,7 @@ def main():
     table = sharding.gather_summaries(summ, B * world)
     ens = sharding.ensemble_stats(table)
 
-    # ---- roofline of the dominant kernel (k_update: trailing syrk/gemm + Gram), HIP events per launch
+    # ---- roofline of the dominant kernel (k_panel: trailing syrk/gemm + Gram + trmm), HIP events per launch
     ctx.profile_enable(True)
     for _ in range(2):
         step()
@@ -147,7 +147,7 @@ def main():
                        "fits_per_gpu_per_step": B, "streams": args.streams, "N": N, "d": d, "M": M_TEST,
                        "fit_tflops": value * f_fit / 1e12, "cholesky_roofline_frac": value * f_chol / 1e12 / world / peak,
                        "inputs": "resident in HBM", "ensemble": ens},
-            "roofline": {"bound": "mfma", "kernel": "k_update (syrk/gemm trailing update + fused Gram)",
+            "roofline": {"bound": "mfma", "kernel": "k_panel (syrk/gemm trailing update + fused Gram + in-register trmm)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(B, N, dts), "avg_launch_ms": upd["ms"] / max(upd["launches"], 1),
                          "launches": upd["launches"]},
@@ -172,7 +172,8 @@ def pmc_traffic(B, N, dts):
     if not files:
         return None
     try:
-        return json.load(open(files[-1]))["k_update"]["hbm_bytes_per_launch"]
+        d = json.load(open(files[-1]))
+        return d.get("k_panel", d.get("k_update"))["hbm_bytes_per_launch"]
     except Exception:
         return None
 

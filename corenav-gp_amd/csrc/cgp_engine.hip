@@ -46,6 +46,7 @@ struct cgp_ctx {
   void *Lw = nullptr, *Winv = nullptr, *dX = nullptr, *dXs = nullptr, *dy = nullptr;
   void *dmean = nullptr, *dvar = nullptr, *dalpha = nullptr;
   double *dtheta = nullptr, *djitter = nullptr, *dlogml = nullptr, *dprep = nullptr;
+  long long *ddbg = nullptr;
   int *dinfo = nullptr;
   size_t lw_stride = 0, winv_stride = 0, alpha_stride = 0;
   // state of the last single fit (cgp_fit -> cgp_predict)
@@ -270,6 +271,7 @@ FitArgs base_args(cgp_ctx *c, int N, int d, int M, int kid, int include_noise) {
   a.alpha = c->dalpha;
   a.alpha_stride = c->alpha_stride;
   a.prep = c->dprep;
+  a.dbgbuf = c->ddbg;
   a.N = N;
   a.d = d;
   a.M = M;
@@ -394,6 +396,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc(&c->dalpha, B * c->alpha_stride * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dtheta, B * CGP_MAX_THETA * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->djitter, B * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->ddbg, 64 * sizeof(long long)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dprep, B * PREP_N * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dlogml, B * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dinfo, B * sizeof(int)) == hipSuccess;
@@ -413,7 +416,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {
@@ -426,6 +429,14 @@ void cgp_destroy(cgp_ctx *c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+int cgp_debug_read(cgp_ctx *c, long long out[64]) {
+  if (!c || !out) return CGP_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());
+  HIP_TRY(c, hipMemcpy(out, c->ddbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  return CGP_OK;
 }
 
 int cgp_set_streams(cgp_ctx *c, int n) {

@@ -55,6 +55,7 @@ struct FitArgs {
   size_t alpha_stride;
   int N, d, M, NT, ET, kernel_id, include_noise;
   int rows_from_extra;   // 1: only the extra (test/y) row tiles are processed (predict after fit)
+  long long *dbgbuf;     // 64 slots of s_memtime stamps (block 0, CGP_DBG & 512)
   int dbg;               // timing ablations only (env CGP_DBG, results are WRONG when non-zero)
 };
 
@@ -69,6 +70,15 @@ template <> struct Prec<double> {
   static __device__ __forceinline__ double exp_(double x) { return exp(x); }
   static __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
   static __device__ __forceinline__ double log_(double x) { return log(x); }
+  // 1/sqrt(x), x > 0 and normal: hardware seed + two Newton steps (shorter dependent chain than
+  // sqrt followed by a division; this sits on the serial critical path of the diagonal blocks)
+  static __device__ __forceinline__ double rsqrt_(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    r = __builtin_fma(r, __builtin_fma(-h * r, r, 0.5), r);
+    r = __builtin_fma(r, __builtin_fma(-h * r, r, 0.5), r);
+    return r;
+  }
 };
 template <> struct Prec<float> {
   using acc_t = float __attribute__((ext_vector_type(4)));
@@ -80,6 +90,10 @@ template <> struct Prec<float> {
   static __device__ __forceinline__ float exp_(float x) { return expf(x); }
   static __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
   static __device__ __forceinline__ float log_(float x) { return logf(x); }
+  static __device__ __forceinline__ float rsqrt_(float x) {
+    float r = __builtin_amdgcn_rsqf(x);
+    return __builtin_fmaf(r, __builtin_fmaf(-0.5f * x * r, r, 0.5f), r);
+  }
 };
 
 // Row-tile index (in units of 128 rows of Lw) handled by block t of a step-k launch.
@@ -457,14 +471,16 @@ __global__ __launch_bounds__(256, 2) void k_trmm(FitArgs p, int k) {
 // Phases (a)-(d) on an LDS-resident tile: factor it in place (lower triangle), leave W = L^-1
 // transposed in the strict upper triangle and the inverted 16x16 diagonal blocks in Dv.
 template <typename T>
-__device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, int k, int tid) {
+__device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, int k, int tid, long long *dbgbuf = nullptr) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
+  long long tA = 0, tB = 0, tC = 0, t0 = __builtin_amdgcn_s_memtime();
   for (int jb = 0; jb < TS / DB; ++jb) {
     const int j0 = jb * DB;
+    long long s0 = __builtin_amdgcn_s_memtime();
     if (wave == 0) {
       // (a) lane holds row (lane & 15) of the diagonal block (replicated over the four 16-lane groups)
       T a[DB], rinv[DB];
@@ -478,7 +494,7 @@ __device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, i
           if (bad == 0) bad = k * TS + j0 + j + 1;
           dj = T(1);
         }
-        const T rs = T(1) / P::sqrt_(dj);
+        const T rs = P::rsqrt_(dj);
         rinv[j] = rs;
         const T l = (l15 == j) ? dj * rs : a[j] * rs;
         a[j] = l;
@@ -507,6 +523,8 @@ __device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, i
       }
     }
     __syncthreads();
+    long long s1 = __builtin_amdgcn_s_memtime();
+    tA += s1 - s0;
     // (b) panel: rows of block bi below the diagonal block, P[r][c] = sum_q A[r][q] Dinv[c][q]
     for (int bi = jb + 1 + wave; bi < TS / DB; bi += 4) {
       acc_t acc = acc_t{0, 0, 0, 0};
@@ -522,6 +540,8 @@ __device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, i
       for (int r = 0; r < 4; ++r) At[(j0 + P::drow(lane, r)) * LDP + bi * DB + l15] = acc[r];
     }
     __syncthreads();
+    long long s2 = __builtin_amdgcn_s_memtime();
+    tB += s2 - s1;
     // (c) trailing update of the lower block pairs (bi >= bj > jb)
     const int nb = TS / DB - jb - 1;
     for (int idx = wave; idx < nb * (nb + 1) / 2; idx += 4) {
@@ -547,7 +567,9 @@ __device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, i
       for (int r = 0; r < 4; ++r) At[(bj * DB + P::drow(lane, r)) * LDP + bi * DB + l15] = acc[r];
     }
     __syncthreads();
+    tC += __builtin_amdgcn_s_memtime() - s2;
   }
+  long long t1 = __builtin_amdgcn_s_memtime();
 
   // (d) W = L^-1: block (i, j), i > j:  W_ij = -Dinv_i * sum_{kk=j}^{i-1} L_{i,kk} W_{kk,j}.
   // Blocks with the same i - j are independent (one level per barrier).  W_ij is stored transposed
@@ -584,7 +606,13 @@ __device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, i
     }
     __syncthreads();
   }
-
+  if (dbgbuf && tid == 0 && blockIdx.x == 0) {
+    dbgbuf[0] = tA;
+    dbgbuf[1] = tB;
+    dbgbuf[2] = tC;
+    dbgbuf[3] = t1 - t0;
+    dbgbuf[4] = __builtin_amdgcn_s_memtime() - t1;
+  }
 }
 
 // Phase (e): write L (upper triangle zeroed) to the factor panel and W_k (column-major 128 x 128).

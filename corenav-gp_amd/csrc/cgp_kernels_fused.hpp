@@ -399,6 +399,7 @@ __global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15;
 
+  const long long tstart = __builtin_amdgcn_s_memtime();
   constexpr int CH2 = 2 * KT * LDST;
   acc_t acc[NCB][2];
   const T *gR = Lw + (size_t)k * TS;
@@ -427,8 +428,10 @@ __global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
     }
   if (tid == 0) *flag = 0;
   __syncthreads();
-  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid);
+  const long long tq = __builtin_amdgcn_s_memtime();
+  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, (p.dbg & 512) ? p.dbgbuf : nullptr);
   potf2_store<T>(p, At, Dv, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
+  if ((p.dbg & 512) && tid == 0 && b == 0) { p.dbgbuf[5] = __builtin_amdgcn_s_memtime() - tq; p.dbgbuf[6] = tq - tstart; }
 }
 
 }  // namespace cgp

@@ -40,6 +40,7 @@ _SIGS = {
     "cgp_fit_predict_batch_device": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5 + [_vp, _vp, _vp, _vp, _vp,
                                                                                  ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cgp_set_streams": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "cgp_debug_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong)]),
     "cgp_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cgp_profile_read": (ctypes.c_int, [_vp, _dp, _dp, ctypes.POINTER(ctypes.c_longlong)]),
     "cgp_llh_to_enu": (ctypes.c_int, [ctypes.c_double] * 3 + [_dp, _dp, _dp]),
@@ -169,6 +170,11 @@ class Context:
         return self._chk(self.lib.cgp_fit_predict_batch_device(self.h, B, N, d, M, kernel_id, dX, dy, dXs, dtheta,
                                                                djitter or None, int(include_noise), dmean, dvar,
                                                                dlogml, dinfo, stream or None))
+
+    def debug_read(self):
+        out = np.zeros(64, dtype=np.int64)
+        self._chk(self.lib.cgp_debug_read(self.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
+        return out
 
     def set_streams(self, n):
         self._chk(self.lib.cgp_set_streams(self.h, int(n)))

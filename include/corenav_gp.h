@@ -106,6 +106,9 @@ int cgp_fit_predict_batch_device(cgp_ctx *ctx, int batch, int N, int d, int M, i
  * launches of another. */
 int cgp_set_streams(cgp_ctx *ctx, int n);
 
+/* Development aid: 64 in-kernel s_memtime stamps (100 MHz ticks) written when env CGP_DBG & 512. */
+int cgp_debug_read(cgp_ctx *ctx, long long out[64]);
+
 /* ---- per-kernel timing for the roofline line (bench.py) --------------------------------------
  * When enabled, every launch is bracketed by hipEvents on its stream; cgp_profile_read drains them.
  * kernel index: 0 update(syrk/gemm+gram) 1 potf2(+inverse) 2 trmm 3 finalize(mean/var/logml) 4 alpha.
