@@ -6,6 +6,7 @@
 #include "cgp_kernels_fused.hpp"
 #include "gp_predictor_core.hpp"
 #include "gp_predictor.h"
+#include "lbfgs.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -47,6 +48,7 @@ struct cgp_ctx {
   void *dmean = nullptr, *dvar = nullptr, *dalpha = nullptr;
   double *dtheta = nullptr, *djitter = nullptr, *dlogml = nullptr, *dprep = nullptr;
   long long *ddbg = nullptr;
+  double *dgpart = nullptr;
   int *dinfo = nullptr;
   size_t lw_stride = 0, winv_stride = 0, alpha_stride = 0;
   // state of the last single fit (cgp_fit -> cgp_predict)
@@ -120,6 +122,7 @@ template <typename T> int set_lds_attrs() {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trmm<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
   done = true;
   return 0;
@@ -396,6 +399,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc(&c->dalpha, B * c->alpha_stride * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dtheta, B * CGP_MAX_THETA * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->djitter, B * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->dgpart, (size_t)c->NTmax * (c->NTmax + 1) / 2 * GRAD_N * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->ddbg, 64 * sizeof(long long)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dprep, B * PREP_N * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dlogml, B * sizeof(double)) == hipSuccess;
@@ -416,7 +420,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {
@@ -747,3 +751,139 @@ int cgp_gppredictor_callback(const double *mean, const double *sigma, int M, con
 }
 
 }  // extern "C"
+
+namespace {
+// One gradient-mode evaluation on the device for the window already uploaded to slot 0.
+template <typename T>
+int grad_eval(cgp_ctx *c, int N, int d, int kid, double *logml, double sums[GRAD_N], int *info) {
+  hipStream_t s = c->stream;
+  FitArgs a = base_args(c, N, d, /*M=*/N, kid, 0);
+  a.xid = 1;
+  a.X = c->dX;
+  a.Xs = c->dX;  // unused: the "test rows" are the identity
+  a.y = c->dy;
+  a.theta = c->dtheta;
+  a.jitter = c->djitter;
+  a.mean = c->dmean;
+  a.var = c->dvar;
+  a.logml = c->dlogml;
+  a.info = c->dinfo;
+  a.gpart = c->dgpart;
+  int rc = run(c, a, 1, true, true, s);
+  if (rc != CGP_OK) return rc;
+  const int npairs = a.NT * (a.NT + 1) / 2;
+  hipLaunchKernelGGL(k_grad<T>, dim3(npairs, 1), dim3(256), upd_lds_bytes<T>(), s, a, npairs);
+  HIP_TRY(c, hipGetLastError());
+  std::vector<double> part((size_t)npairs * GRAD_N);
+  HIP_TRY(c, hipMemcpyAsync(part.data(), c->dgpart, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(logml, c->dlogml, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(info, c->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  for (int i = 0; i < GRAD_N; ++i) sums[i] = 0.0;
+  for (int pz = 0; pz < npairs; ++pz)  // fixed order: deterministic
+    for (int i = 0; i < GRAD_N; ++i) sums[i] += part[(size_t)pz * GRAD_N + i];
+  return CGP_OK;
+}
+}  // namespace
+
+extern "C" int cgp_nll_grad(cgp_ctx *c, const double *X, const double *y, int N, int d, int kid, const double *theta,
+                            double *nll, double *grad) {
+  int rc = check_shape(c, 1, N, d, N, kid);
+  if (rc != CGP_OK) return rc;
+  if (!X || !y || !theta || !nll || !grad) return CGP_EINVAL;
+  const int nth = ntheta(kid, d);
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  std::vector<char> hx((size_t)d * N * c->esz), hy((size_t)N * c->esz);
+  pack_soa(X, N, d, c->dtype, hx, 0);
+  pack_vec(y, N, c->dtype, hy, 0);
+  std::vector<double> hth;
+  HIP_TRY(c, hipMemcpyAsync(c->dX, hx.data(), hx.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemcpyAsync(c->dy, hy.data(), hy.size(), hipMemcpyHostToDevice, s));
+  rc = upload_theta(c, theta, nth, nth, 1, s, hth);
+  if (rc != CGP_OK) return rc;
+  double jit = 0.0, logml = 0.0, sums[GRAD_N];
+  int info = 0;
+  for (int attempt = 0; attempt <= 5; ++attempt) {  // GPy jitchol policy
+    HIP_TRY(c, hipMemcpyAsync(c->djitter, &jit, sizeof(double), hipMemcpyHostToDevice, s));
+    rc = c->dtype == CGP_F64 ? grad_eval<double>(c, N, d, kid, &logml, sums, &info)
+                             : grad_eval<float>(c, N, d, kid, &logml, sums, &info);
+    if (rc != CGP_OK) return rc;
+    if (info == 0) break;
+    jit = (attempt == 0) ? mean_diag(kid, theta, d, X, N) * 1e-6 : jit * 10.0;
+  }
+  c->fjitter = (info == 0) ? jit : 0.0;
+  c->have_fit = (info == 0);
+  c->fN = N;
+  c->fd = d;
+  c->fkernel = kid;
+  memcpy(c->ftheta, theta, sizeof(double) * nth);
+  if (info != 0) return info;
+  *nll = -logml;
+  // dlogML/dtheta = 0.5 * sum_ij w_ij dK_ij/dtheta  ->  gradient of the NEGATIVE log likelihood
+  if (kid == CGP_KERNEL_SE_ISO) {
+    double se = 0;
+    for (int q = 0; q < d; ++q) se += sums[1 + q];
+    grad[0] = -0.5 * sums[0] / theta[0];
+    grad[1] = -0.5 * se / theta[1];
+    grad[2] = -0.5 * sums[9];
+  } else if (kid == CGP_KERNEL_SE_ARD) {
+    grad[0] = -0.5 * sums[0] / theta[0];
+    for (int q = 0; q < d; ++q) grad[1 + q] = -0.5 * sums[1 + q] / theta[1 + q];
+    grad[d + 1] = -0.5 * sums[9];
+  } else {
+    grad[0] = -0.5 * sums[0] / theta[0];
+    grad[1] = -0.5 * sums[1] / theta[1];
+    grad[2] = -0.5 * sums[0] / theta[2];
+    grad[3] = -0.5 * sums[9];
+  }
+  return CGP_OK;
+}
+
+extern "C" int cgp_optimize(cgp_ctx *c, const double *X, const double *y, int N, int d, int kid, double *theta,
+                            int max_evals, double *logml, int *n_evals) {
+  int rc = check_shape(c, 1, N, d, N, kid);
+  if (rc != CGP_OK) return rc;
+  if (!X || !y || !theta) return CGP_EINVAL;
+  const int nth = ntheta(kid, d);
+  // Logexp transform (GPy paramz.transformations.Logexp): theta = log(1 + exp(x))
+  auto to_theta = [](double x) { return x > 35.0 ? x : std::log1p(std::exp(x)); };
+  auto to_x = [](double th) { return th > 35.0 ? th : std::log(std::expm1(th)); };
+  std::vector<double> x(nth), th(nth), g(nth);
+  for (int i = 0; i < nth; ++i) {
+    if (!(theta[i] > 0.0)) return CGP_EINVAL;
+    x[i] = to_x(theta[i]);
+  }
+  int hard_error = CGP_OK;
+  auto fg = [&](const std::vector<double> &xx, std::vector<double> &gx) -> double {
+    for (int i = 0; i < nth; ++i) th[i] = std::max(to_theta(xx[i]), 1e-300);
+    double nll = 0.0;
+    const int r = cgp_nll_grad(c, X, y, N, d, kid, th.data(), &nll, g.data());
+    if (r < 0) hard_error = r;
+    if (r != 0) return INFINITY;  // not PD even with jitter: infeasible point
+    for (int i = 0; i < nth; ++i) gx[i] = g[i] * (xx[i] > 35.0 ? 1.0 : -std::expm1(-th[i]));  // dtheta/dx = 1 - exp(-theta)
+    return nll;
+  };
+  corenav::LbfgsResult res = corenav::lbfgs_minimize(fg, x, max_evals > 0 ? max_evals : 1000);
+  if (hard_error != CGP_OK) return hard_error;
+  for (int i = 0; i < nth; ++i) theta[i] = to_theta(x[i]);
+  // leave the context fitted at the optimum
+  double nll = 0.0;
+  rc = cgp_nll_grad(c, X, y, N, d, kid, theta, &nll, g.data());
+  if (rc != CGP_OK) return rc;
+  if (logml) *logml = -nll;
+  if (n_evals) *n_evals = res.evals + 1;
+  return CGP_OK;
+}
+
+extern "C" int cgp_slip_node_callback_opt(cgp_ctx *c, const double *time_array, const double *slip_array, int n,
+                                          int kid, double *theta, int max_evals, double *mean, double *sigma, int cap,
+                                          int *m_out) {
+  if (!c || !time_array || !slip_array || !theta || n < 2) return CGP_EINVAL;
+  if (max_evals > 0) {
+    const int ntr = (int)(0.9 * (double)n);  // gp_slip_node.py:27-29
+    int rc = cgp_optimize(c, time_array, slip_array, ntr, 1, kid, theta, max_evals, nullptr, nullptr);  // :36
+    if (rc != CGP_OK) return rc;
+  }
+  return cgp_slip_node_callback(c, time_array, slip_array, n, kid, theta, mean, sigma, cap, m_out);
+}

@@ -32,6 +32,7 @@ constexpr int DB = 16;     // diagonal sub-block of potf2 / trsm
 constexpr int MAXD = 8;
 constexpr int MAX_THETA = MAXD + 2;
 constexpr int PREP_N = 16;  // prep[0..7] 1/ell_q, [8] log amp (SE) or 0, [9] amp, [10] amp_b, [11] diag add
+constexpr int GRAD_N = 12;  // k_grad sums: [0] amplitude, [1..8] length-scales, [9] noise
 constexpr int LDP = TS + 2;   // LDS leading dimension of the potf2 tile (2-way conflicts at most)
 
 enum { K_SE_ISO = 0, K_SE_ARD = 1, K_RBF_BROWNIAN = 2 };
@@ -55,6 +56,8 @@ struct FitArgs {
   size_t alpha_stride;
   int N, d, M, NT, ET, kernel_id, include_noise;
   int rows_from_extra;   // 1: only the extra (test/y) row tiles are processed (predict after fit)
+  int xid;               // 1: the M (= N) "test rows" are the identity, so the extra block becomes (L^-1)^T (gradient mode)
+  double *gpart;         // [batch][pairs][GRAD_N] per-tile-pair partial sums of k_grad
   long long *dbgbuf;     // 64 slots of s_memtime stamps (block 0, CGP_DBG & 512)
   int dbg;               // timing ablations only (env CGP_DBG, results are WRONG when non-zero)
 };

@@ -186,6 +186,7 @@ __device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<
             g = dg ? g + diag_add : g;
             g = (grow < N && colok) ? g : (dg ? T(1) : T(0));  // identity padding keeps the factor well defined
           } else {
+            if (p.xid) g = (grow == gcol) ? T(1) : T(0);  // gradient mode: "test rows" = identity
             g = (grow == M) ? yc[cl] : g;
             g = (!colok || grow > M) ? T(0) : g;
           }
@@ -289,7 +290,7 @@ __device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::a
   const T amp = T(pr[9]), amp_b = T(pr[10]), diag_add = T(pr[11]);
   const int rowbase = extra ? (rt - p.NT) * TS : rt * TS;
   const int colbase = k * TS;
-  const bool fast = (colbase + TS <= N) && (extra ? (rowbase + TS <= M) : (rt != k && rowbase + TS <= N));
+  const bool fast = (colbase + TS <= N) && (extra ? (rowbase + TS <= M && !p.xid) : (rt != k && rowbase + TS <= N));
   if (brown) {
     if (fast) gram_apply_tile<T, true, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
     else gram_apply_tile<T, true, false>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
@@ -432,6 +433,135 @@ __global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
   potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, (p.dbg & 512) ? p.dbgbuf : nullptr);
   potf2_store<T>(p, At, Dv, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
   if ((p.dbg & 512) && tid == 0 && b == 0) { p.dbgbuf[5] = __builtin_amdgcn_s_memtime() - tq; p.dbgbuf[6] = tq - tstart; }
+}
+
+// --------------------------------------------------------------------------------------------------
+// k_grad (GPy's dL_dK = 0.5 (alpha alpha^T - Ky^-1) contracted with dK/dtheta):
+// after a gradient-mode factorisation (xid = 1, M = N) the extra block of the factor panel holds
+// Wt = (L^-1)^T, so Ky^-1 = Wt Wt^T is a syrk of its row panels -- the same MFMA loop as the
+// update.  Workgroup (pair, fit) forms the 128x128 tile (ti >= tj) of Ky^-1 in registers and reduces
+//     S_amp  = sum w_ij K_ij        S_ell[q] = sum w_ij K_ij d_q^2        S_noise = sum_i w_ii
+// with w = alpha_i alpha_j - Ky^-1_ij, d_q the length-scaled coordinate difference; off-diagonal
+// tiles count twice.  Wt[e][c] = 0 for c < e, so the inner dimension starts at column block ti.
+// --------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_grad(FitArgs p, int npairs) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  const int b = blockIdx.y, pair = blockIdx.x;
+  int ti = 0, rem = pair;
+  while (rem > ti) {
+    rem -= ti + 1;
+    ++ti;
+  }
+  const int tj = rem;  // ti >= tj
+  const T *Lw = reinterpret_cast<const T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const int ld = p.ld, N = p.N, d = p.d, kid = p.kernel_id;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15;
+  const size_t rb = (size_t)p.NT * TS;
+
+  acc_t acc[NCB][2];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = acc_t{0, 0, 0, 0};
+  const T *gR = Lw + rb + (size_t)ti * TS + (size_t)(ti * TS) * ld;
+  const T *gC = Lw + rb + (size_t)tj * TS + (size_t)(ti * TS) * ld;
+  mfma_rowpanel_loop<T, false>(acc, gR, (size_t)ld, gC, (size_t)ld, (p.NT - ti) * (TS / KT), smem, tid);
+
+  // inputs of the tile: scaled coordinates [MAXD][128] of rows and columns, alpha of both
+  const double *__restrict__ pr = p.prep + (size_t)b * PREP_N;
+  T *xr = smem, *xc = smem + MAXD * TS, *ar = smem + 2 * MAXD * TS, *ac = ar + TS;
+  const T *__restrict__ Xb = reinterpret_cast<const T *>(p.X) + (size_t)b * d * N;
+  const T *__restrict__ al = reinterpret_cast<const T *>(p.alpha) + (size_t)b * p.alpha_stride;
+  const bool brown = kid == K_RBF_BROWNIAN;
+  for (int idx = tid; idx < MAXD * TS; idx += 256) {
+    const int q = idx >> 7, r = idx & 127;
+    const T sc = brown ? T(1) : T(pr[q]);  // Brownian keeps the raw tick (GPy's r^2 expansion)
+    const int gi = ti * TS + r, gj = tj * TS + r;
+    xr[idx] = (q < d && gi < N) ? Xb[(size_t)q * N + gi] * sc : T(0);
+    xc[idx] = (q < d && gj < N) ? Xb[(size_t)q * N + gj] * sc : T(0);
+  }
+  if (tid < TS) {
+    const int gi = ti * TS + tid, gj = tj * TS + tid;
+    ar[tid] = gi < N ? al[gi] : T(0);
+    ac[tid] = gj < N ? al[gj] : T(0);
+  }
+  __syncthreads();
+  const T amp = T(pr[9]), amp_b = T(pr[10]);
+  const T inv_ell = T(pr[0]);
+  double s_amp = 0, s_noise = 0, s_ell[MAXD];
+#pragma unroll
+  for (int q = 0; q < MAXD; ++q) s_ell[q] = 0;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cl = cb * DB + P::drow(lane, r);
+      const int gcol = tj * TS + cl;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rl = wave * 32 + 2 * l15 + j;
+        const int grow = ti * TS + rl;
+        const T kinv = acc[cb][j][r];
+        if (grow < N && gcol < N) {
+          const T w = ar[rl] * ac[cl] - kinv;
+          T kv, dq2[MAXD];
+          if (!brown) {
+            T d2 = 0;
+#pragma unroll
+            for (int q = 0; q < MAXD; ++q) {
+              const T df = xr[q * TS + rl] - xc[q * TS + cl];
+              dq2[q] = df * df;
+              d2 += dq2[q];
+            }
+            kv = amp * P::exp_(T(-0.5) * d2);
+          } else {
+            const T x = xr[rl], xp = xc[cl];
+            T r2 = (grow == gcol) ? T(0) : (T(-2) * x * xp + (x * x + xp * xp));
+            r2 = r2 < T(0) ? T(0) : r2;
+            const T rr = P::sqrt_(r2) * inv_ell;
+            const int sx = (x > T(0)) - (x < T(0)), sp = (xp > T(0)) - (xp < T(0));
+            const T ax = x < T(0) ? -x : x, ap = xp < T(0) ? -xp : xp;
+            const T kb = (sx == sp) ? amp_b * (ax < ap ? ax : ap) : T(0);
+            kv = amp * P::exp_(T(-0.5) * rr * rr) * kb;
+#pragma unroll
+            for (int q = 0; q < MAXD; ++q) dq2[q] = T(0);
+            dq2[0] = rr * rr;
+          }
+          const double wk = (double)w * (double)kv;
+          s_amp += wk;
+#pragma unroll
+          for (int q = 0; q < MAXD; ++q) s_ell[q] += wk * (double)dq2[q];
+          if (grow == gcol) s_noise += (double)w;
+        }
+      }
+    }
+  }
+  // workgroup reduction: wave shuffles, then LDS
+  __syncthreads();
+  double *red = reinterpret_cast<double *>(smem_raw);  // [4][GRAD_N]
+  double vals[GRAD_N];
+  vals[0] = s_amp;
+#pragma unroll
+  for (int q = 0; q < MAXD; ++q) vals[1 + q] = s_ell[q];
+  vals[9] = s_noise;
+  vals[10] = vals[11] = 0;
+#pragma unroll
+  for (int i = 0; i < GRAD_N; ++i) {
+    double v = vals[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) red[wave * GRAD_N + i] = v;
+  }
+  __syncthreads();
+  if (tid < GRAD_N) {
+    const double wgt = (ti == tj) ? 1.0 : 2.0;
+    const double v = (red[tid] + red[GRAD_N + tid]) + (red[2 * GRAD_N + tid] + red[3 * GRAD_N + tid]);
+    p.gpart[((size_t)b * npairs + pair) * GRAD_N + tid] = wgt * v;
+  }
 }
 
 }  // namespace cgp

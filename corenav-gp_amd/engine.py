@@ -33,6 +33,10 @@ _SIGS = {
     "cgp_get_alpha": (ctypes.c_int, [_vp, _dp]),
     "cgp_get_factor": (ctypes.c_int, [_vp, _dp]),
     "cgp_last_jitter": (ctypes.c_double, [_vp]),
+    "cgp_nll_grad": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]),
+    "cgp_optimize": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _ip]),
+    "cgp_slip_node_callback_opt": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp,
+                                                  ctypes.c_int, _ip]),
     "cgp_slip_node_callback": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
                                               ctypes.c_int, _ip]),
     "cgp_fit_predict_batch": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5 + [_dp, _dp, _dp, _dp, ctypes.c_int,
@@ -140,6 +144,48 @@ class Context:
 
     def last_jitter(self):
         return self.lib.cgp_last_jitter(self.h)
+
+    def nll_grad(self, X, y, kernel_id, theta):
+        """Negative log marginal likelihood and its gradient wrt the natural parameters."""
+        X = _d(X)
+        if X.ndim == 1:
+            X = X[:, None]
+        y, theta = _d(y).reshape(-1), _d(theta)
+        nll, grad = ctypes.c_double(0.0), np.empty(len(theta))
+        rc = self._chk(self.lib.cgp_nll_grad(self.h, _p(X), _p(y), X.shape[0], X.shape[1], kernel_id, _p(theta),
+                                             ctypes.byref(nll), _p(grad)))
+        if rc > 0:
+            raise CgpError(rc)
+        self._n = X.shape[0]
+        return nll.value, grad
+
+    def optimize(self, X, y, kernel_id, theta0, max_evals=1000):
+        """GPy m.optimize() equivalent; returns (theta_opt, logml, n_evals)."""
+        X = _d(X)
+        if X.ndim == 1:
+            X = X[:, None]
+        y = _d(y).reshape(-1)
+        theta = np.array(theta0, dtype=np.float64)
+        logml, nev = ctypes.c_double(0.0), ctypes.c_int(0)
+        rc = self._chk(self.lib.cgp_optimize(self.h, _p(X), _p(y), X.shape[0], X.shape[1], kernel_id, _p(theta),
+                                             max_evals, ctypes.byref(logml), ctypes.byref(nev)))
+        if rc > 0:
+            raise CgpError(rc)
+        self._n = X.shape[0]
+        return theta, logml.value, nev.value
+
+    def slip_node_callback_opt(self, time_array, slip_array, theta0, kernel_id=KERNEL_RBF_BROWNIAN, max_evals=1000,
+                               cap=4096):
+        t, s = _d(time_array).reshape(-1), _d(slip_array).reshape(-1)
+        theta = np.array(theta0, dtype=np.float64)
+        mean, sigma = np.empty(cap), np.empty(cap)
+        m_out = ctypes.c_int(0)
+        rc = self._chk(self.lib.cgp_slip_node_callback_opt(self.h, _p(t), _p(s), len(t), kernel_id, _p(theta), max_evals,
+                                                           _p(mean), _p(sigma), cap, ctypes.byref(m_out)))
+        if rc > 0:
+            raise CgpError(rc)
+        m = min(m_out.value, cap)
+        return mean[:m].copy(), sigma[:m].copy(), theta
 
     def slip_node_callback(self, time_array, slip_array, theta, kernel_id=KERNEL_RBF_BROWNIAN, cap=4096):
         t, s, theta = _d(time_array).reshape(-1), _d(slip_array).reshape(-1), _d(theta)

@@ -69,11 +69,30 @@ int cgp_get_factor(cgp_ctx *ctx, double *L);
 /* Jitter that was added to the diagonal for the last fit to succeed (0 if none). */
 double cgp_last_jitter(const cgp_ctx *ctx);
 
+/* ---- hyper-parameter optimisation (the reference's `m.optimize()`, gp_slip_node.py:36) ----------
+ * cgp_nll_grad: value and gradient of the NEGATIVE log marginal likelihood at theta (natural
+ * parameters, same layout as cgp_fit).  GPy's ExactGaussianInference: dL/dK = 0.5 (alpha alpha^T -
+ * Ky^-1) contracted with dK/dtheta; Ky^-1 is formed on the device as a syrk of L^-1.  Needs a
+ * context created with max_m >= N.  grad has ntheta entries.  Leaves the context fitted at theta. */
+int cgp_nll_grad(cgp_ctx *ctx, const double *X, const double *y, int N, int d, int kernel_id,
+                 const double *theta, double *nll, double *grad);
+/* cgp_optimize: minimises the negative log marginal likelihood over the Logexp-transformed
+ * parameters theta = log(1 + exp(x)) (GPy's default positivity constraint) with L-BFGS, starting from
+ * theta_inout (GPy starts every parameter at 1.0), at most max_evals objective evaluations (GPy:
+ * 1000).  Writes the optimum to theta_inout, its log marginal likelihood to *logml, the number of
+ * evaluations to *n_evals, and leaves the context fitted at the optimum (cgp_predict may follow). */
+int cgp_optimize(cgp_ctx *ctx, const double *X, const double *y, int N, int d, int kernel_id,
+                 double *theta_inout, int max_evals, double *logml, int *n_evals);
+
 /* ---- the node callback in one call -------------------------------------------------------------
  * Everything gp_slip_node.py:16-63 computes between "GP Input Arrived" and pub.publish(), at fixed
  * theta: first int(0.9 n) samples train (:27-29), grid arange(min, max + 600, 1) (:45), output
  * mean = means[n:], sigma = 2 sqrt(var[n:]) (:59-61).  Writes at most `cap` entries; *m_out gets
- * the number of entries the reference would publish. */
+ * the number of entries the reference would publish.  cgp_slip_node_callback_opt additionally runs
+ * cgp_optimize on the training window first (max_evals <= 0: fixed theta), returning theta. */
+int cgp_slip_node_callback_opt(cgp_ctx *ctx, const double *time_array, const double *slip_array, int n,
+                               int kernel_id, double *theta_inout, int max_evals, double *mean,
+                               double *sigma, int cap, int *m_out);
 int cgp_slip_node_callback(cgp_ctx *ctx, const double *time_array, const double *slip_array, int n,
                            int kernel_id, const double *theta, double *mean, double *sigma, int cap,
                            int *m_out);

@@ -325,3 +325,77 @@ def predict_stop(mean, sigma, P, Q, STM, H, pos_llh, arrival_time=0.0, now=0.0,
 # --------------------------------------------------------------------------------------------------
 def sliding_window_refit(kernel_id, theta, Xwin, ywin):
     return fit(kernel_id, theta, Xwin, ywin)
+
+
+# --------------------------------------------------------------------------------------------------
+# a7 / f2: hyper-parameter optimisation.  gp_slip_node.py:36 `m.optimize()` = paramz 'lbfgsb'
+# (scipy fmin_l_bfgs_b, no bounds, maxfun 1000) on the Logexp-transformed parameters, objective
+# -log p(y|X,theta), gradient from dL/dK = 0.5 (alpha alpha^T - Ky^-1)  (SURVEY.md 3B).
+# --------------------------------------------------------------------------------------------------
+def dK_dtheta(kernel_id, theta, X):
+    """List of dK/dtheta_p (N x N each), natural parameters, noise last."""
+    X = np.asarray(X, dtype=np.float64)
+    theta = np.asarray(theta, dtype=np.float64)
+    N, d = X.shape
+    K = kernel_K(kernel_id, theta, X)
+    out = []
+    if kernel_id in (KERNEL_SE_ISO, KERNEL_SE_ARD):
+        ell = np.full(d, theta[1]) if kernel_id == KERNEL_SE_ISO else theta[1:1 + d]
+        out.append(K / theta[0])
+        dq2 = [((X[:, None, q] - X[None, :, q]) / ell[q]) ** 2 for q in range(d)]
+        if kernel_id == KERNEL_SE_ISO:
+            out.append(K * sum(dq2) / theta[1])
+        else:
+            out.extend(K * dq2[q] / ell[q] for q in range(d))
+    else:
+        Xsq = np.sum(np.square(X), 1)
+        r2 = -2.0 * X @ X.T + (Xsq[:, None] + Xsq[None, :])
+        r2[np.diag_indices_from(r2)] = 0.0
+        r2 = np.clip(r2, 0.0, np.inf) / theta[1] ** 2
+        out.append(K / theta[0])
+        out.append(K * r2 / theta[1])
+        out.append(K / theta[2])
+    out.append(np.eye(N))
+    return out
+
+
+def nll_and_grad(kernel_id, theta, X, y):
+    """Negative log marginal likelihood and its gradient wrt the natural parameters."""
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim == 1:
+        X = X[:, None]
+    f = fit(kernel_id, theta, X, y, want_inverse=True)
+    dL_dK = 0.5 * (np.outer(f.alpha, f.alpha) - f.Kyinv)
+    g = np.array([np.sum(dL_dK * dK) for dK in dK_dtheta(kernel_id, theta, X)])
+    return -f.logml, -g
+
+
+def logexp(x):
+    return np.where(x > 35.0, x, np.log1p(np.exp(np.minimum(x, 35.0))))
+
+
+def logexp_inv(th):
+    return np.where(th > 35.0, th, np.log(np.expm1(np.minimum(th, 35.0))))
+
+
+def optimize(kernel_id, X, y, theta0=None, max_evals=1000):
+    """Returns (theta_opt, logml, n_evals); theta0 defaults to GPy's all-ones start."""
+    import scipy.optimize as so
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim == 1:
+        X = X[:, None]
+    nth = n_theta(kernel_id, X.shape[1])
+    th0 = np.ones(nth) if theta0 is None else np.asarray(theta0, dtype=np.float64)
+    count = [0]
+
+    def fg(x):
+        count[0] += 1
+        th = logexp(x)
+        try:
+            nll, g = nll_and_grad(kernel_id, th, X, y)
+        except np.linalg.LinAlgError:
+            return 1e300, np.zeros_like(x)
+        return nll, g * -np.expm1(-th)        # dtheta/dx = 1 - exp(-theta)
+
+    x, fval, _ = so.fmin_l_bfgs_b(fg, logexp_inv(th0), maxfun=max_evals)
+    return logexp(x), -fval, count[0]

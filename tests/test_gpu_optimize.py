@@ -1,0 +1,85 @@
+"""GPU tests of the hyper-parameter path (the reference's `m.optimize()`,
+gp_slip_node.py:36): the device gradient of the negative log marginal likelihood against the oracle
+(which is itself pinned against finite differences on the CPU), and the optimiser against scipy's
+L-BFGS-B on the oracle objective from the same start."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import gp_oracle as go
+import corenav_gp_amd.synth as synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import corenav_gp_amd.engine as e
+    e.load()
+    return e
+
+
+@pytest.mark.parametrize("kid,N,d", [(2, 134, 1), (2, 15, 1), (0, 200, 3), (1, 256, 6), (1, 300, 2), (1, 640, 6)])
+def test_nll_grad_matches_oracle(engine, kid, N, d):
+    rng = np.random.default_rng(7 * N + d)
+    if kid == 2:
+        X = (11.0 + np.arange(N))[:, None]
+        theta = np.array([0.7, 12.0, 0.03, 0.02])
+    else:
+        X = rng.normal(size=(N, d))
+        theta = np.concatenate([[0.9], rng.uniform(0.6, 1.8, 1 if kid == 0 else d), [0.08]])
+    y = 0.2 * np.sin(np.arange(N) / 5.0) + 0.05 * rng.normal(size=N)
+    ctx = engine.Context(max_n=N, max_m=N, max_d=d)
+    nll, g = ctx.nll_grad(X, y, kid, theta)
+    onll, og = go.nll_and_grad(kid, theta, X, y)
+    assert abs(nll - onll) <= 1e-6 * abs(onll)
+    # 1e-6 relative to the gradient's scale (single components can pass through zero)
+    assert np.max(np.abs(g - og)) <= 1e-6 * np.max(np.abs(og))
+    # the context is left fitted at theta: prediction still works after a gradient evaluation
+    Xs = X[:5] + 0.25
+    mu, var = ctx.predict(Xs)
+    f = go.fit(kid, theta, X, y)
+    omu, ovar = go.predict(f, Xs)
+    assert np.max(np.abs(mu - omu)) <= 1e-6 * np.max(np.abs(omu)) and np.max(np.abs(var - ovar) / ovar) < 1e-6
+
+
+def test_optimize_reference_window(engine):
+    """The reference node's flow: all-ones start (GPy defaults), optimise, predict 599 points."""
+    g = load_golden("slipval_window_rbfbrownian")
+    X, Y, xtr, ytr = go.slip_node_split(g["time_array"], g["slip_array"])
+    ctx = engine.Context(max_n=256, max_m=1024, max_d=1)
+    th, lml, nev = ctx.optimize(xtr, ytr[:, 0], 2, np.ones(4))
+    oth, olml, onev = go.optimize(2, xtr, ytr[:, 0])
+    assert nev <= 1000 and np.all(th > 0)
+    # looser contract for the optimiser: at least as good a likelihood as scipy's optimum
+    assert lml >= olml - 1e-5 * abs(olml)
+    # and the value reported is the true logML at the returned theta
+    assert lml == pytest.approx(-go.nll_and_grad(2, th, xtr, ytr[:, 0])[0], rel=1e-8)
+    mean, sigma, th2 = ctx.slip_node_callback_opt(g["time_array"], g["slip_array"], np.ones(4))
+    em, es = go.slip_node_callback(g["time_array"], g["slip_array"], th2)
+    assert mean.shape == (599,)
+    assert np.max(np.abs(mean - em)) <= 1e-6 * np.max(np.abs(em)) and np.max(np.abs(sigma - es) / es) < 1e-6
+    # predictions at the two optima agree to the looser optimiser tolerance
+    om, osig = go.slip_node_callback(g["time_array"], g["slip_array"], oth)
+    assert np.max(np.abs(mean - om)) <= 2e-2 * np.max(np.abs(om)) + 1e-3
+
+
+def test_optimize_se_ard(engine):
+    X, y, Xs = synth.window(192, 3, 16, seed=4242)
+    ctx = engine.Context(max_n=192, max_m=192, max_d=3)
+    th0 = np.array([1.0, 1.0, 1.0, 1.0, 1.0])
+    th, lml, nev = ctx.optimize(X, y, 1, th0)
+    oth, olml, _ = go.optimize(1, X, y, th0)
+    assert lml >= olml - 1e-5 * abs(olml)
+    assert lml > -go.nll_and_grad(1, th0, X, y)[0]
+
+
+def test_node_mirror_optimises_like_the_reference(engine):
+    """GpSlipNode default = the reference behaviour: GPy start values, optimise, publish 599 points."""
+    from corenav_gp_amd import gp_slip_node as node
+    g = load_golden("synth_window_rbfbrownian")
+    n = node.GpSlipNode()
+    out = n.callback(node.GP_Input(g["time_array"], g["slip_array"]))
+    assert len(out.mean) == 599 and np.all(np.isfinite(out.sigma)) and np.all(out.sigma > 0)
+    X, Y, xtr, ytr = go.slip_node_split(g["time_array"], g["slip_array"])
+    assert -go.nll_and_grad(2, n.last_theta, xtr, ytr[:, 0])[0] > -go.nll_and_grad(2, np.ones(4), xtr, ytr[:, 0])[0]

@@ -154,3 +154,36 @@ def test_llh_to_enu():
     assert np.linalg.norm(e) < 5.0       # the YAML origin LLH and ECEF agree to a few metres
     up = go.llh_to_enu(go.INIT_LLH[0], go.INIT_LLH[1], go.INIT_LLH[2] + 10.0)
     assert abs((up - e)[2] - 10.0) < 1e-6
+
+
+@pytest.mark.parametrize("kid,d", [(0, 2), (1, 3), (2, 1)])
+def test_nll_gradient_vs_finite_differences(kid, d):
+    """Pins the analytic gradient of the restatement (GPy's dL/dK form) against central differences."""
+    rng = np.random.default_rng(11 + kid)
+    N = 40
+    if kid == 2:
+        X = (11.0 + np.arange(N))[:, None]
+        theta = np.array([0.7, 12.0, 0.03, 0.02])
+    else:
+        X = rng.normal(size=(N, d))
+        theta = np.concatenate([[0.9], rng.uniform(0.6, 1.8, 1 if kid == 0 else d), [0.08]])
+    y = 0.2 * np.sin(np.arange(N) / 5.0) + 0.05 * rng.normal(size=N)
+    nll, g = go.nll_and_grad(kid, theta, X, y)
+    for p in range(len(theta)):
+        h = 1e-6 * theta[p]
+        tp, tm = theta.copy(), theta.copy()
+        tp[p] += h
+        tm[p] -= h
+        fd = (go.nll_and_grad(kid, tp, X, y)[0] - go.nll_and_grad(kid, tm, X, y)[0]) / (2 * h)
+        assert g[p] == pytest.approx(fd, rel=2e-5, abs=1e-7)
+
+
+def test_optimize_improves_likelihood():
+    g = load_golden("synth_window_rbfbrownian")
+    X, Y, xtr, ytr = go.slip_node_split(g["time_array"], g["slip_array"])
+    th, lml, nev = go.optimize(2, xtr, ytr[:, 0])
+    start = -go.nll_and_grad(2, np.ones(4), xtr, ytr[:, 0])[0]
+    assert lml > start and np.all(th > 0) and nev <= 1000
+    # stationarity in the transformed space
+    nll, gr = go.nll_and_grad(2, th, xtr, ytr[:, 0])
+    assert np.max(np.abs(gr * -np.expm1(-th))) < 1e-2
