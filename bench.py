@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--n", type=int, default=None, help="override window length N")
     ap.add_argument("--cpu-sample", type=int, default=6, help="fits timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="worker streams the batch is spread over")
+    ap.add_argument("--streams", type=int, default=1, help="worker streams the batch is spread over")
     args = ap.parse_args()
 
     import torch
