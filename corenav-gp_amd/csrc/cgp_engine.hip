@@ -4,6 +4,7 @@
 #include "../../include/corenav_gp.h"
 #include "cgp_kernels.hpp"
 #include "cgp_kernels_fused.hpp"
+#include "cgp_window.hpp"
 #include "gp_predictor_core.hpp"
 #include "gp_predictor.h"
 #include "lbfgs.hpp"
@@ -49,6 +50,10 @@ struct cgp_ctx {
   double *dtheta = nullptr, *djitter = nullptr, *dlogml = nullptr, *dprep = nullptr;
   long long *ddbg = nullptr;
   double *dgpart = nullptr;
+  // sliding windows (cgp_window_*)
+  WindowArgs win{};
+  int nwin = 0;
+  void *winbuf[8] = {nullptr};
   int *dinfo = nullptr;
   size_t lw_stride = 0, winv_stride = 0, alpha_stride = 0;
   // state of the last single fit (cgp_fit -> cgp_predict)
@@ -431,6 +436,8 @@ void cgp_destroy(cgp_ctx *c) {
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  for (void *wb : c->winbuf)
+    if (wb) (void)hipFree(wb);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -886,4 +893,109 @@ extern "C" int cgp_slip_node_callback_opt(cgp_ctx *c, const double *time_array, 
     if (rc != CGP_OK) return rc;
   }
   return cgp_slip_node_callback(c, time_array, slip_array, n, kid, theta, mean, sigma, cap, m_out);
+}
+
+extern "C" int cgp_window_init(cgp_ctx *c, int nwin, int N, int d, int kid, const double *theta, int theta_stride) {
+  if (!c || nwin < 1 || N < 2 || N > 2048 || d < 1 || d > CGP_MAX_D || !theta || kid < 0 || kid > 2) return CGP_EINVAL;
+  if (kid == CGP_KERNEL_RBF_BROWNIAN && d != 1) return CGP_EINVAL;
+  const int nth = ntheta(kid, d);
+  if (theta_stride < nth) return CGP_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (void *&wb : c->winbuf) {
+    if (wb) (void)hipFree(wb);
+    wb = nullptr;
+  }
+  const int CAP = 2 * N;
+  const size_t W = nwin;
+  size_t sizes[6] = {W * CAP * CAP * 8, W * CAP * 8, W * d * CAP * 8, W * CAP * 8, W * 4 * sizeof(int),
+                     W * (PREP_N + MAX_THETA) * 8};
+  for (int i = 0; i < 6; ++i)
+    if (hipMalloc(&c->winbuf[i], sizes[i]) != hipSuccess) return CGP_ENOMEM;
+  WindowArgs &wa = c->win;
+  wa = WindowArgs{};
+  wa.L = (double *)c->winbuf[0];
+  wa.z = (double *)c->winbuf[1];
+  wa.xw = (double *)c->winbuf[2];
+  wa.yw = (double *)c->winbuf[3];
+  wa.state = (int *)c->winbuf[4];
+  double *pt = (double *)c->winbuf[5];
+  wa.prep = pt;
+  wa.theta = pt + W * PREP_N;
+  wa.N = N;
+  wa.CAP = CAP;
+  wa.d = d;
+  wa.kernel_id = kid;
+  std::vector<double> h(W * (PREP_N + MAX_THETA), 0.0);
+  for (size_t w = 0; w < W; ++w) {
+    const double *th = theta + w * theta_stride;
+    double *o = h.data() + w * PREP_N;
+    for (int q = 0; q < d; ++q) o[q] = (kid == CGP_KERNEL_SE_ARD) ? 1.0 / th[1 + q] : 1.0 / th[1];
+    o[9] = th[0];
+    o[10] = (kid == CGP_KERNEL_RBF_BROWNIAN) ? th[2] : 0.0;
+    for (int q = 0; q < nth; ++q) h[W * PREP_N + w * MAX_THETA + q] = th[q];
+  }
+  HIP_TRY(c, hipMemcpy(pt, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemset(wa.state, 0, W * 4 * sizeof(int)));
+  c->nwin = nwin;
+  return CGP_OK;
+}
+
+extern "C" int cgp_window_push_device(cgp_ctx *c, int T, const double *dxs, const double *dys, int include_noise,
+                                      double *dpm, double *dpv, double *dl, void *hip_stream) {
+  if (!c || c->nwin < 1) return CGP_ESTATE;
+  if (T < 1 || !dxs || !dys || !dpm || !dpv || !dl) return CGP_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  WindowArgs a = c->win;
+  a.xs = dxs;
+  a.ys = dys;
+  a.pred_mean = dpm;
+  a.pred_var = dpv;
+  a.logml = dl;
+  a.T = T;
+  a.include_noise = include_noise;
+  const size_t lds = (size_t)(3 * a.N + 3 * WPB + MAXD + 8) * sizeof(double);
+  hipLaunchKernelGGL(k_window_ticks, dim3(c->nwin), dim3(256), lds, hip_stream ? (hipStream_t)hip_stream : c->stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return CGP_OK;
+}
+
+extern "C" int cgp_window_push(cgp_ctx *c, int T, const double *xs, const double *ys, int include_noise, double *pm,
+                               double *pv, double *logml) {
+  if (!c || c->nwin < 1) return CGP_ESTATE;
+  if (T < 1 || !xs || !ys || !pm || !pv || !logml) return CGP_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t W = c->nwin, nx = W * T * c->win.d, ny = W * T;
+  double *buf = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&buf, (nx + 4 * ny) * 8));
+  hipStream_t s = c->stream;
+  int rc = CGP_OK;
+  do {
+    if (!hip_ok(c, hipMemcpyAsync(buf, xs, nx * 8, hipMemcpyHostToDevice, s), "H2D xs")) { rc = CGP_EHIP; break; }
+    if (!hip_ok(c, hipMemcpyAsync(buf + nx, ys, ny * 8, hipMemcpyHostToDevice, s), "H2D ys")) { rc = CGP_EHIP; break; }
+    rc = cgp_window_push_device(c, T, buf, buf + nx, include_noise, buf + nx + ny, buf + nx + 2 * ny, buf + nx + 3 * ny, s);
+    if (rc != CGP_OK) break;
+    if (!hip_ok(c, hipMemcpyAsync(pm, buf + nx + ny, ny * 8, hipMemcpyDeviceToHost, s), "D2H")) { rc = CGP_EHIP; break; }
+    if (!hip_ok(c, hipMemcpyAsync(pv, buf + nx + 2 * ny, ny * 8, hipMemcpyDeviceToHost, s), "D2H")) { rc = CGP_EHIP; break; }
+    if (!hip_ok(c, hipMemcpyAsync(logml, buf + nx + 3 * ny, ny * 8, hipMemcpyDeviceToHost, s), "D2H")) { rc = CGP_EHIP; break; }
+    if (!hip_ok(c, hipStreamSynchronize(s), "sync")) { rc = CGP_EHIP; break; }
+  } while (false);
+  (void)hipFree(buf);
+  if (rc != CGP_OK) return rc;
+  std::vector<int> st(W * 4);
+  HIP_TRY(c, hipMemcpy(st.data(), c->win.state, st.size() * sizeof(int), hipMemcpyDeviceToHost));
+  for (size_t w = 0; w < W; ++w)
+    if (st[w * 4 + 2] != 0) return st[w * 4 + 2];
+  return CGP_OK;
+}
+
+extern "C" int cgp_window_state(cgp_ctx *c, int w, int *n, int *info) {
+  if (!c || c->nwin < 1) return CGP_ESTATE;
+  if (w < 0 || w >= c->nwin) return CGP_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());
+  int st[4];
+  HIP_TRY(c, hipMemcpy(st, c->win.state + w * 4, sizeof(st), hipMemcpyDeviceToHost));
+  if (n) *n = st[1];
+  if (info) *info = st[2];
+  return CGP_OK;
 }

@@ -43,6 +43,10 @@ _SIGS = {
                                                                           ctypes.c_int, _dp, _dp, _dp, _ip]),
     "cgp_fit_predict_batch_device": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5 + [_vp, _vp, _vp, _vp, _vp,
                                                                                  ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "cgp_window_init": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int]),
+    "cgp_window_push": (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, ctypes.c_int, _dp, _dp, _dp]),
+    "cgp_window_push_device": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "cgp_window_state": (ctypes.c_int, [_vp, ctypes.c_int, _ip, _ip]),
     "cgp_set_streams": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cgp_debug_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong)]),
     "cgp_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -216,6 +220,34 @@ class Context:
         return self._chk(self.lib.cgp_fit_predict_batch_device(self.h, B, N, d, M, kernel_id, dX, dy, dXs, dtheta,
                                                                djitter or None, int(include_noise), dmean, dvar,
                                                                dlogml, dinfo, stream or None))
+
+    # -- sliding windows (BASELINE configs[3]) ----------------------------------------------------
+    def window_init(self, nwin, N, d, kernel_id, theta):
+        theta = _d(theta)
+        if theta.ndim == 1:
+            theta = np.tile(theta, (nwin, 1))
+        self._win = (nwin, d)
+        self._chk(self.lib.cgp_window_init(self.h, nwin, N, d, kernel_id, _p(theta), theta.shape[1]))
+
+    def window_push(self, xs, ys, include_noise=True):
+        """xs (nwin, T, d), ys (nwin, T) -> one-step-ahead mean, variance and logML per tick, each (nwin, T)."""
+        nwin, d = self._win
+        xs, ys = _d(xs).reshape(nwin, -1, d), _d(ys).reshape(nwin, -1)
+        T = ys.shape[1]
+        pm, pv, lm = np.empty((nwin, T)), np.empty((nwin, T)), np.empty((nwin, T))
+        rc = self._chk(self.lib.cgp_window_push(self.h, T, _p(xs), _p(ys), int(include_noise), _p(pm), _p(pv), _p(lm)))
+        if rc > 0:
+            raise CgpError(rc)
+        return pm, pv, lm
+
+    def window_push_device(self, T, dxs, dys, include_noise, dpm, dpv, dlm, stream=0):
+        return self._chk(self.lib.cgp_window_push_device(self.h, T, dxs, dys, int(include_noise), dpm, dpv, dlm,
+                                                         stream or None))
+
+    def window_state(self, w=0):
+        n, info = ctypes.c_int(0), ctypes.c_int(0)
+        self._chk(self.lib.cgp_window_state(self.h, w, ctypes.byref(n), ctypes.byref(info)))
+        return n.value, info.value
 
     def debug_read(self):
         out = np.zeros(64, dtype=np.int64)

@@ -128,6 +128,24 @@ int cgp_set_streams(cgp_ctx *ctx, int n);
 /* Development aid: 64 in-kernel s_memtime stamps (100 MHz ticks) written when env CGP_DBG & 512. */
 int cgp_debug_read(cgp_ctx *ctx, long long out[64]);
 
+/* ---- online sliding-window GP (BASELINE configs[3]; not reference behaviour) -------------------
+ * `nwin` independent windows of at most N samples each live on the device.  cgp_window_push feeds
+ * T ticks to every window in ONE launch: per tick the oldest sample leaves a full window (rank-1
+ * Cholesky update), the new one enters (forward substitution), and the tick's outputs are the
+ * one-step-ahead predictive mean / variance of the incoming y BEFORE it is added, and the log
+ * marginal likelihood of the window after it.  theta (nwin, theta_stride) is fixed per window.
+ * xs (nwin, T, d), ys (nwin, T); outputs (nwin, T).  Returns 0, or the 1-based tick at which a window
+ * lost positive definiteness. */
+int cgp_window_init(cgp_ctx *ctx, int nwin, int N, int d, int kernel_id, const double *theta, int theta_stride);
+int cgp_window_push(cgp_ctx *ctx, int T, const double *xs, const double *ys, int include_noise,
+                    double *pred_mean, double *pred_var, double *logml);
+/* Device-resident variant for streaming benchmarks: dxs/dys/outputs are device pointers, enqueued on
+ * hip_stream without synchronising. */
+int cgp_window_push_device(cgp_ctx *ctx, int T, const double *dxs, const double *dys, int include_noise,
+                           double *dpred_mean, double *dpred_var, double *dlogml, void *hip_stream);
+/* Current size of window `w` and the first failing tick (0 = none). */
+int cgp_window_state(cgp_ctx *ctx, int w, int *n, int *info);
+
 /* ---- per-kernel timing for the roofline line (bench.py) --------------------------------------
  * When enabled, every launch is bracketed by hipEvents on its stream; cgp_profile_read drains them.
  * kernel index: 0 update(syrk/gemm+gram) 1 potf2(+inverse) 2 trmm 3 finalize(mean/var/logml) 4 alpha.

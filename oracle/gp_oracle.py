@@ -327,6 +327,33 @@ def sliding_window_refit(kernel_id, theta, Xwin, ywin):
     return fit(kernel_id, theta, Xwin, ywin)
 
 
+def sliding_window_stream(kernel_id, theta, N, xs, ys, include_noise=True):
+    """Tick-by-tick oracle of the sliding window: before a sample enters, predict it from the current
+    window (one-step-ahead mean / variance); then drop the oldest sample if the window is full, add
+    the new one and REFIT from scratch.  Returns (pred_mean, pred_var, logml) per tick."""
+    xs = np.asarray(xs, dtype=np.float64)
+    if xs.ndim == 1:
+        xs = xs[:, None]
+    ys = np.asarray(ys, dtype=np.float64)
+    T = len(ys)
+    pm, pv, lm = np.zeros(T), np.zeros(T), np.zeros(T)
+    Xw, yw = np.zeros((0, xs.shape[1])), np.zeros(0)
+    for t in range(T):
+        if len(yw) >= N:                      # the oldest sample leaves BEFORE the prediction of the new one
+            Xw, yw = Xw[1:], yw[1:]
+        if len(yw) == 0:
+            pm[t] = 0.0
+            v = kernel_Kdiag(kernel_id, theta, xs[t:t + 1])[0]
+            pv[t] = v + (noise_var(kernel_id, theta) if include_noise else 0.0)
+        else:
+            f = fit(kernel_id, theta, Xw, yw)
+            mu, var = predict(f, xs[t:t + 1], include_noise)
+            pm[t], pv[t] = mu[0], var[0]
+        Xw, yw = np.vstack([Xw, xs[t:t + 1]]), np.append(yw, ys[t])
+        lm[t] = fit(kernel_id, theta, Xw, yw).logml
+    return pm, pv, lm
+
+
 # --------------------------------------------------------------------------------------------------
 # a7 / f2: hyper-parameter optimisation.  gp_slip_node.py:36 `m.optimize()` = paramz 'lbfgsb'
 # (scipy fmin_l_bfgs_b, no bounds, maxfun 1000) on the Logexp-transformed parameters, objective
