@@ -58,7 +58,7 @@ __device__ __forceinline__ double win_cov(int kid, int d, const double *pr, cons
   return pr[9] * exp(-0.5 * rr * rr) * kb;
 }
 
-__global__ __launch_bounds__(256) void k_window_ticks(WindowArgs p) {
+__global__ __launch_bounds__(256, 2) void k_window_ticks(WindowArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *vv = reinterpret_cast<double *>(smem_raw);  // [N] rank-1 vector
   double *kk = vv + p.N;                               // [N] right-hand side of the append solve
@@ -119,36 +119,53 @@ __global__ __launch_bounds__(256) void k_window_ticks(WindowArgs p) {
 #pragma unroll
         for (int j = 0; j < WPB; ++j) {
           if (j < nb) {
+            // rotation (c, s) that folds v_j into the diagonal: one reciprocal and one rsqrt, both
+            // hardware-seeded + Newton (this chain is the serial critical path of the tick)
             const double ljj = rdlane(a[j], j), vj = rdlane(vi, j);
-            const double r = sqrt(ljj * ljj + vj * vj);
-            const double c = r / ljj, s = vj / ljj, ci = ljj / r;
+            double il = __builtin_amdgcn_rcp(ljj);
+            il = __builtin_fma(il, __builtin_fma(-ljj, il, 1.0), il);
+            il = __builtin_fma(il, __builtin_fma(-ljj, il, 1.0), il);
+            const double s = vj * il;
+            const double q2 = __builtin_fma(s, s, 1.0);
+            const double ci = Prec<double>::rsqrt_(q2);
+            const double c = q2 * ci;
             const double tv = (a[j] + s * vi) * ci;
             if (i > j) {
               vi = c * vi - s * tv;
               a[j] = tv;
-            } else if (i == j) a[j] = r;
+            } else if (i == j) a[j] = ljj * c;
             const double zj = rdlane(zi, j);
             const double zn = (zj + s * vz) * ci;
             vz = c * vz - s * zn;
             if (i == j) zi = zn;
             szz += zn * zn;
-            slog += log(r);
             if (lane == 0) {
               cs[j] = c;
               cs[WPB + j] = s;
               cs[2 * WPB + j] = ci;
             }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
+        // diagonal of the finished block: logs and reciprocals once per lane, in parallel
+        double dg = 1.0;
+#pragma unroll
+        for (int j = 0; j < WPB; ++j) dg = (i == j) ? a[j] : dg;
+        double lg = (lane < nb) ? log(dg) : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
+        slog += lg;
+        const double idg = 1.0 / dg;
         // forward substitution inside the block for the incoming point
 #pragma unroll
         for (int q = 0; q < WPB; ++q) {
           if (q < nb) {
-            const double lq = rdlane(ki, q) / rdlane(a[q], q);
+            const double lq = rdlane(ki, q) * rdlane(idg, q);
             if (i > q) ki -= a[q] * lq;
             sl2 += lq * lq;
             slz += lq * rdlane(zi, q);
             if (lane == 0) ll[p0 + q] = lq;
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
         if (lane < nb) {
@@ -161,6 +178,7 @@ __global__ __launch_bounds__(256) void k_window_ticks(WindowArgs p) {
       __syncthreads();
       // ---- phase B: every row below the panel takes the panel's rotations and the solve update
       for (int i = p0 + WPB + tid; i < n2; i += 256) {
+        asm volatile("" ::: "memory");  // keep the panel's 128 LDS scalars from being hoisted into registers
         double a[WPB];
 #pragma unroll
         for (int j = 0; j < WPB; ++j) a[j] = Lp[(size_t)j * CAP + i];
