@@ -8,6 +8,7 @@
 #include "gp_predictor_core.hpp"
 #include "gp_predictor.h"
 #include "lbfgs.hpp"
+#include "slip_recorder.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -998,4 +999,37 @@ extern "C" int cgp_window_state(cgp_ctx *c, int w, int *n, int *info) {
   if (n) *n = st[1];
   if (info) *info = st[2];
   return CGP_OK;
+}
+
+struct cgp_recorder {
+  corenav::SlipWindowRecorder r;
+};
+extern "C" cgp_recorder *cgp_recorder_create(void) { return new cgp_recorder(); }
+extern "C" void cgp_recorder_destroy(cgp_recorder *rec) { delete rec; }
+extern "C" int cgp_recorder_update(cgp_recorder *rec, const double wv[4], double vlin, double cmd_x, double *slip_out,
+                                   double *time_out, double *slipwin_out, int cap, int *n_out) {
+  if (!rec || !wv) return CGP_EINVAL;
+  const bool pub = rec->r.Update(wv[0], wv[1], wv[2], wv[3], vlin, cmd_x);
+  if (slip_out) *slip_out = rec->r.slip;
+  if (pub) {
+    const int n = (int)rec->r.time_array.size();
+    if (n_out) *n_out = n;
+    for (int i = 0; i < std::min(n, cap); ++i) {
+      if (time_out) time_out[i] = rec->r.time_array[i];
+      if (slipwin_out) slipwin_out[i] = rec->r.slip_array[i];
+    }
+  }
+  return pub ? 1 : 0;
+}
+extern "C" void cgp_recorder_stop_cmd(cgp_recorder *rec, double cmd_stop) {
+  if (rec) rec->r.stopCallback(cmd_stop);
+}
+extern "C" void cgp_recorder_cmd(cgp_recorder *rec, double cmd_x) {
+  if (rec) rec->r.CmdCallBack(cmd_x);
+}
+extern "C" void cgp_recorder_state(const cgp_recorder *rec, double st[8]) {
+  if (!rec || !st) return;
+  const auto &r = rec->r;
+  st[0] = r.odomUptCount; st[1] = r.startRecording; st[2] = r.stopRecording; st[3] = r.gp_flag;
+  st[4] = r.first_driving_flag; st[5] = r.new_stop_data_arrived_; st[6] = r.skipped_windows; st[7] = r.cmd_stop_;
 }

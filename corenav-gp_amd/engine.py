@@ -54,6 +54,12 @@ _SIGS = {
     "cgp_llh_to_enu": (ctypes.c_int, [ctypes.c_double] * 3 + [_dp, _dp, _dp]),
     "cgp_predict_stop": (ctypes.c_int, [_dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_double, ctypes.c_int, _dp, _dp, _ip, _dp, _ip, _dp]),
+    "cgp_recorder_create": (_vp, []),
+    "cgp_recorder_destroy": (None, [_vp]),
+    "cgp_recorder_update": (ctypes.c_int, [_vp, _dp, ctypes.c_double, ctypes.c_double, _dp, _dp, _dp, ctypes.c_int, _ip]),
+    "cgp_recorder_stop_cmd": (None, [_vp, ctypes.c_double]),
+    "cgp_recorder_cmd": (None, [_vp, ctypes.c_double]),
+    "cgp_recorder_state": (None, [_vp, _dp]),
     "cgp_gppredictor_callback": (ctypes.c_int, [_dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_double,
                                                 ctypes.c_double, ctypes.c_int, _ip, _dp]),
 }
@@ -305,3 +311,43 @@ def gppredictor_callback(mean, sigma, PvecData, QvecData, STMvecData, HvecData, 
     if rc:
         raise CgpError(rc)
     return npub.value, cmd.value
+
+
+class SlipRecorder:
+    """CoreNav's slip computation + recording-window state machine (C++ class behind the C ABI)."""
+    STATE_FIELDS = ("odomUptCount", "startRecording", "stopRecording", "gp_flag", "first_driving_flag",
+                    "new_stop_data_arrived_", "skipped_windows", "cmd_stop_")
+
+    def __init__(self):
+        self.lib = load()
+        self.h = self.lib.cgp_recorder_create()
+        self.slip = 0.0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cgp_recorder_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def update(self, vfl, vfr, vbl, vbr, vlin, cmd_x, cap=256):
+        wv = _d([vfl, vfr, vbl, vbr])
+        slip, n = ctypes.c_double(0.0), ctypes.c_int(0)
+        t, s = np.empty(cap), np.empty(cap)
+        pub = self.lib.cgp_recorder_update(self.h, _p(wv), vlin, cmd_x, ctypes.byref(slip), _p(t), _p(s), cap,
+                                           ctypes.byref(n))
+        self.slip = slip.value
+        if pub < 0:
+            raise CgpError(pub)
+        return (t[:n.value].copy(), s[:n.value].copy()) if pub == 1 else None
+
+    def stop_callback(self, cmd_stop):
+        self.lib.cgp_recorder_stop_cmd(self.h, float(cmd_stop))
+
+    def cmd_callback(self, cmd_x):
+        self.lib.cgp_recorder_cmd(self.h, float(cmd_x))
+
+    def state(self):
+        st = np.zeros(8)
+        self.lib.cgp_recorder_state(self.h, _p(st))
+        return dict(zip(self.STATE_FIELDS, st))

@@ -179,6 +179,23 @@ int cgp_gppredictor_callback(const double *mean, const double *sigma, int M, con
                              const double pos_llh[3], double arrival_time, double now,
                              int h_bug_compatible, int *published, double *stop_cmd);
 
+/* ---- producer side: slip + recording-window state machine of CoreNav::Update -----------------
+ * (core_navigation/src/CoreNav.cpp:176,244-330; stopCallback :755-759; getCmdData :794-816).
+ * cgp_recorder_update = one 10 Hz odometry update: wheel ground speeds {FL, FR, BL, BR}, INS forward
+ * speed, commanded speed.  Returns 1 when a GP_Input window is published this tick; it is then
+ * copied to time_out / slipwin_out (at most cap entries, *n_out = its length).  *slip_out = the
+ * tick's slip value (may be NULL). */
+typedef struct cgp_recorder cgp_recorder;
+cgp_recorder *cgp_recorder_create(void);
+void cgp_recorder_destroy(cgp_recorder *rec);
+int cgp_recorder_update(cgp_recorder *rec, const double wheel_vel[4], double vlin, double cmd_x, double *slip_out,
+                        double *time_out, double *slipwin_out, int cap, int *n_out);
+void cgp_recorder_stop_cmd(cgp_recorder *rec, double cmd_stop);
+void cgp_recorder_cmd(cgp_recorder *rec, double cmd_x);
+/* state[8] = {odomUptCount, startRecording, stopRecording, gp_flag, first_driving_flag,
+ *             new_stop_data_arrived_, skipped_windows, cmd_stop_} */
+void cgp_recorder_state(const cgp_recorder *rec, double state[8]);
+
 #ifdef __cplusplus
 }
 #endif

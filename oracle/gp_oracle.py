@@ -426,3 +426,70 @@ def optimize(kernel_id, X, y, theta0=None, max_evals=1000):
 
     x, fval, _ = so.fmin_l_bfgs_b(fg, logexp_inv(th0), maxfun=max_evals)
     return logexp(x), -fval, count[0]
+
+
+# --------------------------------------------------------------------------------------------------
+# f4: producer side.  CoreNav::Update slip + recording-window state machine
+# (core_navigation/src/CoreNav.cpp:176,244-330), stopCallback (:755-759), getCmdData (:794-816).
+# --------------------------------------------------------------------------------------------------
+class SlipRecorderOracle:
+    def __init__(self):
+        self.odomUptCount = 0.0
+        self.first_driving_flag, self.gp_flag = True, False
+        self.new_stop_data_arrived_, self.started_driving_again_flag = False, True
+        self.startRecording = self.stopRecording = self.saveCountOdom = 0.0
+        self.cmd_stop_ = 0.0
+        self.skipped_windows = 0
+        self.t, self.s = [], []
+        self.slip = 0.0
+
+    def update(self, vfl, vfr, vbl, vbr, vlin, cmd_x):
+        """Returns (time_array, slip_array) when a window is published, else None."""
+        out = None
+        self.odomUptCount += 1                                                       # :176
+        rear = (vbl + vbr) / 2.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cands = [np.float64(v - vlin) / np.float64(v) for v in (vfr, vbr, vfl, vbl)]
+        slip = max(max(cands[0], cands[1]), max(cands[2], cands[3]))                 # :246 (std::max, NaN-order kept)
+        if abs(rear) < 0.001:
+            slip = 0.0
+        slip = min(max(slip, -1.0), 1.0) if slip == slip else slip
+        self.slip = float(slip)
+        if slip != 0.0 and slip != -1.0 and slip != 1.0 and abs(cmd_x) > 0.2:        # :264
+            if self.first_driving_flag:
+                self.saveCountOdom = self.odomUptCount
+                self.startRecording = self.saveCountOdom + 10
+                self.stopRecording = self.startRecording + 150
+                self.first_driving_flag = False
+            if self.startRecording < self.odomUptCount < self.stopRecording and not self.gp_flag:
+                self.s.append(float(slip))
+                self.t.append(self.odomUptCount)
+            if self.odomUptCount >= self.stopRecording:
+                if not self.gp_flag:
+                    self.gp_flag = True
+                    if len(self.s) < 15:
+                        self.skipped_windows += 1
+                    else:
+                        out = (np.array(self.t), np.array(self.s))
+                    self.t, self.s = [], []
+                if self.new_stop_data_arrived_:
+                    self.new_stop_data_arrived_ = False
+                    self.startRecording = self.stopRecording + math.ceil(self.cmd_stop_) * 10 + 10 + 50
+                    self.stopRecording = self.startRecording + 150
+                    self.gp_flag = False
+            if (not self.first_driving_flag) and self.odomUptCount / 10 - self.stopRecording / 10 > 10:
+                self.t, self.s = [], []
+                self.first_driving_flag = True
+                self.gp_flag = False
+        return out
+
+    def stop_callback(self, cmd_stop):
+        self.cmd_stop_ = cmd_stop
+        self.new_stop_data_arrived_ = True
+
+    def cmd_callback(self, cmd_x):
+        if self.gp_flag and abs(cmd_x) < 0.0001:
+            self.started_driving_again_flag = False
+        if not self.started_driving_again_flag and abs(cmd_x) > 0.0001:
+            self.started_driving_again_flag = True
+            self.gp_flag = False
