@@ -1,0 +1,134 @@
+"""ROS-free closed-loop replay of the corenav-GP slip loop (the stand-in for
+BASELINE configs[4]: the Pathfinder bag is not obtainable, so the sensor stream is synthetic).
+
+    RoverSim (wheel + INS speeds, 10 Hz) --> SlipRecorder [CoreNav::Update, C++]
+        --/core_nav/core_nav/gp_input-->   GP engine [gp_slip_node.py arithmetic, HIP]
+        --/core_nav/core_nav/gp_result-->  GpPredictor [gp_predictor.cpp, C++]  <-- stopping_service
+        --/core_nav/core_nav/stop_cmd-->   SlipRecorder.stopCallback + DriveStraightWithStop FSM
+                                           (pathfinder_control/src/drive_straight_with_stop.cpp:28-66)
+
+An ensemble of trajectories (Monte-Carlo) is stepped in lock-step; the windows published at a tick
+are fitted together through the batched C ABI.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import engine, synth
+
+DT_ODO = 0.1            # odometry period, parameters.yaml:46-47 (10 Hz)
+STOP_DURATION = 5.0     # drive_straight_with_stop.cpp:7
+DRIVE_SPEED = 0.8       # m/s; gp_predictor.cpp:73 assumes 0.8 / (1 - slip)
+
+
+class RoverSim:
+    """Straight drive with a slowly varying + impulsive slip process; wheel speeds are the commanded
+    speed plus encoder noise, the INS forward speed is wheel * (1 - slip)."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.tick = 0
+
+    def step(self, driving):
+        self.tick += 1
+        if not driving:
+            return (0.0, 0.0, 0.0, 0.0), 0.0
+        t = float(self.tick)
+        slip = 0.1 * np.sin(2.0 * np.pi * t / 40.0) + 0.05 * (self.rng.random() < 0.04) + self.rng.normal(0.0, 0.03)
+        wheels = tuple(DRIVE_SPEED * (1.0 + 0.002 * self.rng.normal()) for _ in range(4))
+        vlin = float(np.mean(wheels)) * (1.0 - float(np.clip(slip, -0.9, 0.9)))
+        return wheels, vlin
+
+
+class DriveStraightWithStop:
+    """drive_straight_with_stop.cpp FSM: after stop_cmd, wait until time_to_stop, publish zero
+    velocity for 5 s, then resume."""
+
+    def __init__(self):
+        self.state, self.stop_commanded, self.time_to_stop, self.stopped_time = "waiting", False, 0.0, 0.0
+
+    def stop_callback(self, now, delta):          # :60-66
+        self.time_to_stop = now + delta
+        self.stop_commanded = True
+
+    def cmd(self, now):                           # :28-51
+        if self.state == "waiting":
+            if self.stop_commanded and now > self.time_to_stop:
+                self.stopped_time, self.state = now, "stopped"
+        elif now - self.stopped_time > STOP_DURATION:
+            self.state, self.stop_commanded = "waiting", False
+        return 0.0 if self.state == "stopped" else 1.0
+
+
+class Trajectory:
+    def __init__(self, seed):
+        self.sim = RoverSim(seed)
+        self.rec = engine.SlipRecorder()
+        self.drv = DriveStraightWithStop()
+        fs = synth.filter_state(seed)
+        self.P, self.Q, self.STM, self.Hvec, self.pos = fs
+        self.windows, self.results, self.stop_cmds, self.stops = [], [], [], 0
+        self._was_stopped = False
+
+    def tick(self, now):
+        cmd = self.drv.cmd(now)
+        if cmd == 0.0 and not self._was_stopped:
+            self.stops += 1
+        self._was_stopped = cmd == 0.0
+        self.rec.cmd_callback(cmd)
+        wheels, vlin = self.sim.step(cmd != 0.0)
+        return self.rec.update(*wheels, vlin, cmd)
+
+
+class ClosedLoopEnsemble:
+    def __init__(self, n_traj, theta=(0.5, 30.0, 0.01, 0.002), optimize=False, device=0, seed=synth.SEED_BASE + 5):
+        self.traj = [Trajectory(seed + 31 * i) for i in range(n_traj)]
+        self.theta = np.asarray(theta, dtype=np.float64)
+        self.optimize = optimize
+        self.ctx = engine.Context(device=device, max_n=256, max_m=1024, max_d=1, max_batch=max(n_traj, 1))
+        self.now = 0.0
+
+    def _fit_windows(self, idx, wins):
+        """gp_slip_node.py:16-63 for every window published this tick (batched when theta is fixed)."""
+        outs = []
+        if self.optimize:
+            for t, s in wins:
+                m, sg, th = self.ctx.slip_node_callback_opt(t, s, np.ones(4))
+                outs.append((m, sg, th))
+            return outs
+        same = len({len(t) for t, _ in wins}) == 1
+        if same and len(wins) > 1:
+            n = len(wins[0][0])
+            ntr = int(0.9 * n)
+            X = np.stack([t[:ntr, None] for t, _ in wins])
+            y = np.stack([s[:ntr] for _, s in wins])
+            Xs = np.stack([(t.min() + n + np.arange(int(np.ceil(t.max() + 600 - t.min())) - n))[:, None] for t, _ in wins])
+            th = np.tile(self.theta, (len(wins), 1))
+            rc, mean, var, _, info = self.ctx.fit_predict_batch(X, y, Xs, th, engine.KERNEL_RBF_BROWNIAN)
+            assert rc == 0, info
+            return [(mean[i], 2.0 * np.sqrt(var[i]), self.theta) for i in range(len(wins))]
+        for t, s in wins:
+            m, sg = self.ctx.slip_node_callback(t, s, self.theta)
+            outs.append((m, sg, self.theta))
+        return outs
+
+    def step(self):
+        self.now += DT_ODO
+        pubs = [(i, w) for i, tr in enumerate(self.traj) if (w := tr.tick(self.now)) is not None]
+        if not pubs:
+            return 0
+        outs = self._fit_windows([i for i, _ in pubs], [w for _, w in pubs])
+        for (i, w), (mean, sigma, th) in zip(pubs, outs):
+            tr = self.traj[i]
+            tr.windows.append(w)
+            tr.results.append((mean, sigma, th))
+            # gp_predictor.cpp:17-132 with the service answered from the trajectory's filter state
+            npub, cmd = engine.gppredictor_callback(mean, sigma, tr.P, tr.Q, tr.STM, tr.Hvec, tr.pos, self.now, self.now)
+            if npub:
+                tr.stop_cmds.append(cmd)
+                tr.rec.stop_callback(cmd)            # CoreNav::stopCallback
+                tr.drv.stop_callback(self.now, cmd)  # drive_straight_with_stop stopCallback
+        return len(pubs)
+
+    def run(self, n_ticks):
+        return sum(self.step() for _ in range(n_ticks))

@@ -84,3 +84,27 @@ def reference_window(n=149, tick0=11, seed=SEED_BASE):
     rng = np.random.default_rng(seed)
     t = np.arange(tick0, tick0 + n, dtype=np.float64)
     return t, _slip_series(rng, t)
+
+
+def filter_state(seed):
+    """A plausible 15-state filter snapshot for the SetStopping response (P, Q, STM row-major 225
+    each, HvecData[60] packed with the reference's r*4+c indexing, LLH position): position error
+    grows through the velocity states so the 3 m horizontal threshold is crossed after some tens of
+    seconds (gp_predictor.cpp:58-130)."""
+    rng = np.random.default_rng(seed + 99)
+    A = rng.normal(0, 1e-3, (15, 15))
+    A[6:8, :] *= 1e-7
+    A[:, 6:8] *= 1e-2
+    STM = np.eye(15) + A * 0.02
+    STM[6:9, 3:6] += np.diag([1.6e-9, 2.0e-9, -0.02])
+    P = np.diag(np.concatenate([np.full(3, 1e-6), np.full(3, 2e-3), [1e-15, 1e-15, 0.04], np.full(6, 1e-8)]))
+    Q = np.diag(np.concatenate([np.full(3, 1e-9), np.full(3, 3e-5), [4e-19, 6e-19, 1e-6], np.full(6, 1e-12)]))
+    H = np.zeros((4, 15))
+    H[0, 3], H[1, 2], H[2, 4], H[3, 5] = 1.0, 1.0, 1.0, 1.0
+    H += rng.normal(0, 1e-3, H.shape)
+    hvec = np.zeros(60)
+    for r in range(4):                      # CoreNav.cpp:669-673 packing
+        for c in range(15):
+            hvec[r * 4 + c] = H[r, c]
+    pos = np.array([0.693457963620326, -1.39498384275845, 334.993517334743]) + np.array([1e-6, -2e-6, 1.5])
+    return P.reshape(225), Q.reshape(225), STM.reshape(225), hvec, pos
