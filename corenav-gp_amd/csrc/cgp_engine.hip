@@ -5,6 +5,7 @@
 #include "cgp_kernels.hpp"
 #include "cgp_kernels_fused.hpp"
 #include "cgp_window.hpp"
+#include "cgp_lookahead.hpp"
 #include "gp_predictor_core.hpp"
 #include "gp_predictor.h"
 #include "lbfgs.hpp"
@@ -1032,4 +1033,71 @@ extern "C" void cgp_recorder_state(const cgp_recorder *rec, double st[8]) {
   const auto &r = rec->r;
   st[0] = r.odomUptCount; st[1] = r.startRecording; st[2] = r.stopRecording; st[3] = r.gp_flag;
   st[4] = r.first_driving_flag; st[5] = r.new_stop_data_arrived_; st[6] = r.skipped_windows; st[7] = r.cmd_stop_;
+}
+
+extern "C" int cgp_predict_stop_batch(cgp_ctx *c, int ntraj, int M, const double *mean, const double *sigma,
+                                      const double *P, const double *Q, const double *STM, const double *Hvec,
+                                      const double *pos, const double *arrival, const double *now, double threshold,
+                                      int h_bug, const double init_llh[3], const double init_ecef[3], int *fired,
+                                      double *stop_cmd, int *i_out, double *xy_err) {
+  if (!c || ntraj < 1 || M < 0 || !mean || !sigma || !P || !Q || !STM || !Hvec || !pos || !arrival || !now ||
+      !init_llh || !init_ecef || !fired || !stop_cmd || !i_out || !xy_err)
+    return CGP_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t T = ntraj;
+  const size_t nd = T * (2 * (size_t)M + 3 * 225 + 60 + 3 + 2 + 2);  // doubles in, incl. 2 double outputs
+  double *buf = nullptr;
+  int *ibuf = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&buf, nd * sizeof(double)));
+  if (hipMalloc((void **)&ibuf, T * 2 * sizeof(int)) != hipSuccess) {
+    (void)hipFree(buf);
+    return CGP_ENOMEM;
+  }
+  hipStream_t s = c->stream;
+  double *d = buf;
+  LookaheadArgs a{};
+  auto put = [&](const double *src, size_t n) {
+    double *dst = d;
+    (void)hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, s);
+    d += n;
+    return dst;
+  };
+  a.mean = put(mean, T * M);
+  a.sigma = put(sigma, T * M);
+  a.P = put(P, T * 225);
+  a.Q = put(Q, T * 225);
+  a.STM = put(STM, T * 225);
+  a.Hvec = put(Hvec, T * 60);
+  a.pos = put(pos, T * 3);
+  a.arrival = put(arrival, T);
+  a.now = put(now, T);
+  a.stop_cmd = d;
+  a.xy_err = d + T;
+  a.fired = ibuf;
+  a.i_out = ibuf + T;
+  a.ntraj = ntraj;
+  a.M = M;
+  a.h_bug_compatible = h_bug;
+  a.threshold = threshold;
+  for (int i = 0; i < 3; ++i) {
+    a.init_llh[i] = init_llh[i];
+    a.init_ecef[i] = init_ecef[i];
+  }
+  hipLaunchKernelGGL(k_lookahead, dim3(cdiv(ntraj, LA_WAVES)), dim3(64 * LA_WAVES),
+                     (size_t)LA_WAVES * LA_PER_WAVE * sizeof(double), s, a);
+  int rc = CGP_OK;
+  if (!hip_ok(c, hipGetLastError(), "k_lookahead")) rc = CGP_EHIP;
+  std::vector<int> hi(T * 2);
+  if (rc == CGP_OK && !hip_ok(c, hipMemcpyAsync(stop_cmd, a.stop_cmd, T * 8, hipMemcpyDeviceToHost, s), "D2H")) rc = CGP_EHIP;
+  if (rc == CGP_OK && !hip_ok(c, hipMemcpyAsync(xy_err, a.xy_err, T * 8, hipMemcpyDeviceToHost, s), "D2H")) rc = CGP_EHIP;
+  if (rc == CGP_OK && !hip_ok(c, hipMemcpyAsync(hi.data(), ibuf, T * 2 * sizeof(int), hipMemcpyDeviceToHost, s), "D2H")) rc = CGP_EHIP;
+  if (!hip_ok(c, hipStreamSynchronize(s), "sync")) rc = CGP_EHIP;
+  (void)hipFree(buf);
+  (void)hipFree(ibuf);
+  if (rc != CGP_OK) return rc;
+  for (size_t i = 0; i < T; ++i) {
+    fired[i] = hi[i];
+    i_out[i] = hi[T + i];
+  }
+  return CGP_OK;
 }

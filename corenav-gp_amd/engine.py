@@ -54,6 +54,8 @@ _SIGS = {
     "cgp_llh_to_enu": (ctypes.c_int, [ctypes.c_double] * 3 + [_dp, _dp, _dp]),
     "cgp_predict_stop": (ctypes.c_int, [_dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_double, ctypes.c_int, _dp, _dp, _ip, _dp, _ip, _dp]),
+    "cgp_predict_stop_batch": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int] + [_dp] * 9 + [ctypes.c_double, ctypes.c_int,
+                                                                                            _dp, _dp, _ip, _dp, _ip, _dp]),
     "cgp_recorder_create": (_vp, []),
     "cgp_recorder_destroy": (None, [_vp]),
     "cgp_recorder_update": (ctypes.c_int, [_vp, _dp, ctypes.c_double, ctypes.c_double, _dp, _dp, _dp, ctypes.c_int, _ip]),
@@ -254,6 +256,22 @@ class Context:
         n, info = ctypes.c_int(0), ctypes.c_int(0)
         self._chk(self.lib.cgp_window_state(self.h, w, ctypes.byref(n), ctypes.byref(info)))
         return n.value, info.value
+
+    def predict_stop_batch(self, mean, sigma, P, Q, STM, Hvec, pos, arrival, now, threshold=3.0, h_bug_compatible=True,
+                           init_llh=None, init_ecef=None):
+        """Batched GPU look-ahead (one wave per trajectory); returns (fired, stop_cmd, i, xy_err) arrays."""
+        mean, sigma = _d(mean), _d(sigma)
+        T, M = mean.shape
+        P, Q, STM, Hvec, pos = (_d(a).reshape(T, -1) for a in (P, Q, STM, Hvec, pos))
+        arrival, now = _d(np.broadcast_to(arrival, (T,))), _d(np.broadcast_to(now, (T,)))
+        fired, iout = np.zeros(T, dtype=np.int32), np.zeros(T, dtype=np.int32)
+        cmd, xy = np.zeros(T), np.zeros(T)
+        illh, iecef = _d(init_llh if init_llh is not None else INIT_LLH), _d(init_ecef if init_ecef is not None else INIT_ECEF)
+        self._chk(self.lib.cgp_predict_stop_batch(self.h, T, M, _p(mean), _p(sigma), _p(P), _p(Q), _p(STM), _p(Hvec),
+                                                  _p(pos), _p(arrival), _p(now), threshold, int(h_bug_compatible),
+                                                  _p(illh), _p(iecef), fired.ctypes.data_as(_ip), _p(cmd),
+                                                  iout.ctypes.data_as(_ip), _p(xy)))
+        return fired.astype(bool), cmd, iout, xy
 
     def debug_read(self):
         out = np.zeros(64, dtype=np.int64)

@@ -119,11 +119,21 @@ class ClosedLoopEnsemble:
             return 0
         outs = self._fit_windows([i for i, _ in pubs], [w for _, w in pubs])
         for (i, w), (mean, sigma, th) in zip(pubs, outs):
-            tr = self.traj[i]
-            tr.windows.append(w)
-            tr.results.append((mean, sigma, th))
-            # gp_predictor.cpp:17-132 with the service answered from the trajectory's filter state
-            npub, cmd = engine.gppredictor_callback(mean, sigma, tr.P, tr.Q, tr.STM, tr.Hvec, tr.pos, self.now, self.now)
+            self.traj[i].windows.append(w)
+            self.traj[i].results.append((mean, sigma, th))
+        trs = [self.traj[i] for i, _ in pubs]
+        if len(pubs) > 1 and len({len(o[0]) for o in outs}) == 1:
+            # the ensemble's look-aheads in one launch (one wavefront per trajectory)
+            fired, cmds, _, _ = self.ctx.predict_stop_batch(
+                np.stack([o[0] for o in outs]), np.stack([o[1] for o in outs]), np.stack([t.P for t in trs]),
+                np.stack([t.Q for t in trs]), np.stack([t.STM for t in trs]), np.stack([t.Hvec for t in trs]),
+                np.stack([t.pos for t in trs]), self.now, self.now)
+            answers = [(int(f), float(c)) for f, c in zip(fired, cmds)]
+        else:
+            # gp_predictor.cpp:17-132 through the C++ class, service answered from the filter state
+            answers = [engine.gppredictor_callback(o[0], o[1], t.P, t.Q, t.STM, t.Hvec, t.pos, self.now, self.now)
+                       for o, t in zip(outs, trs)]
+        for tr, (npub, cmd) in zip(trs, answers):
             if npub:
                 tr.stop_cmds.append(cmd)
                 tr.rec.stop_callback(cmd)            # CoreNav::stopCallback

@@ -170,6 +170,15 @@ int cgp_predict_stop(const double *mean, const double *sigma, int M, const doubl
                      int h_bug_compatible, const double init_llh[3], const double init_ecef[3],
                      int *fired, double *stop_cmd, int *i_out, double *xy_err);
 
+/* cgp_predict_stop_batch: the same look-ahead for `ntraj` trajectories at once ON THE DEVICE (one
+ * wavefront per trajectory): mean/sigma (ntraj, M), P/Q/STM (ntraj, 225), HvecData
+ * (ntraj, 60), pos_llh (ntraj, 3), arrival_time/now (ntraj); outputs (ntraj) each.  Host buffers. */
+int cgp_predict_stop_batch(cgp_ctx *ctx, int ntraj, int M, const double *mean, const double *sigma,
+                           const double *PvecData, const double *QvecData, const double *STMvecData,
+                           const double *HvecData, const double *pos_llh, const double *arrival_time,
+                           const double *now, double threshold, int h_bug_compatible, const double init_llh[3],
+                           const double init_ecef[3], int *fired, double *stop_cmd, int *i_out, double *xy_err);
+
 /* One GpPredictor::GPCallBack (gp_predictor.cpp:17-132) through the C++ class in
  * csrc/gp_predictor.h with an in-process NodeHandle: the SetStopping service answers with the given
  * arrays, the clock returns `arrival_time` on the first read (:22) and `now` afterwards (:107), and
