@@ -734,7 +734,7 @@ int cgp_gppredictor_callback(const double *mean, const double *sigma, int M, con
   int clock_reads = 0, npub = 0;
   double last = 0.0;
   nh.now = [&]() { return clock_reads++ == 0 ? arrival_time : now; };
-  nh.call_set_stopping = [&](core_nav::SetStopping &srv) {
+  nh.call_set_stopping = [&](corenav_pod::core_nav::SetStopping &srv) {
     std::copy(P, P + 225, srv.response.PvecData.begin());
     std::copy(Q, Q + 225, srv.response.QvecData.begin());
     std::copy(STM, STM + 225, srv.response.STMvecData.begin());
@@ -744,13 +744,13 @@ int cgp_gppredictor_callback(const double *mean, const double *sigma, int M, con
     srv.response.PosData.z = pos_llh[2];
     return srv.request.stopping;
   };
-  nh.publish_stop_cmd = [&](const std_msgs::Float64 &m) {
+  nh.publish_stop_cmd = [&](const corenav_pod::std_msgs::Float64 &m) {
     ++npub;
     last = m.data;
   };
   GpPredictor node(nh);
   node.h_bug_compatible = h_bug_compatible != 0;
-  auto msg = std::make_shared<core_nav::GP_Output>();
+  auto msg = std::make_shared<corenav_pod::core_nav::GP_Output>();
   msg->mean.assign(mean, mean + M);
   msg->sigma.assign(sigma, sigma + M);
   node.GPCallBack(msg);

@@ -13,6 +13,9 @@
 #include <string>
 #include <vector>
 
+// The mirrors live in namespace corenav_pod so they can coexist with the generated ROS classes
+// (::std_msgs, ::core_nav) inside a catkin build; everything here names them explicitly.
+namespace corenav_pod {
 namespace std_msgs {
 struct Header { uint32_t seq = 0; double stamp = 0.0; std::string frame_id; };
 struct Float64 { double data = 0.0; };
@@ -44,6 +47,8 @@ struct SetStopping {
 };
 }  // namespace core_nav
 
+}  // namespace corenav_pod
+
 namespace corenav {
 // What GpPredictor needs from its middleware: the three endpoints of gp_predictor.cpp:11-13 and a
 // clock.  ros_shell.cpp implements it over roscpp; tests and the replay harness implement it in
@@ -53,8 +58,8 @@ struct NodeHandle {
   static constexpr const char *kStoppingService = "/core_nav/core_nav/stopping_service";
   static constexpr const char *kStopCmdTopic = "/core_nav/core_nav/stop_cmd";
   static constexpr const char *kGpInputTopic = "/core_nav/core_nav/gp_input";
-  std::function<bool(core_nav::SetStopping &)> call_set_stopping;   // service client (:12,:26)
-  std::function<void(const std_msgs::Float64 &)> publish_stop_cmd;  // publisher, queue 1 (:13,:118)
+  std::function<bool(corenav_pod::core_nav::SetStopping &)> call_set_stopping;   // service client (:12,:26)
+  std::function<void(const corenav_pod::std_msgs::Float64 &)> publish_stop_cmd;  // publisher, queue 1 (:13,:118)
   std::function<double()> now;                                      // ros::Time::now().toSec()
   std::function<bool(const std::string &, double &)> get_param;     // ros::param::get (:135-140)
 };

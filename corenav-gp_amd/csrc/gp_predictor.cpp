@@ -9,14 +9,14 @@
 GpPredictor::GpPredictor(corenav::NodeHandle &nh) : nh_(nh) {}
 
 void GpPredictor::mobility(bool flag) { gp_flag = flag; }
-void GpPredictor::mobilityCallback(const std_msgs::Int64::ConstPtr &msg) { mobility(msg && msg->data != 0); }
+void GpPredictor::mobilityCallback(const corenav_pod::std_msgs::Int64::ConstPtr &msg) { mobility(msg && msg->data != 0); }
 
-void GpPredictor::GPCallBack(const core_nav::GP_Output::ConstPtr &gp_data_in_) {
+void GpPredictor::GPCallBack(const corenav_pod::core_nav::GP_Output::ConstPtr &gp_data_in_) {
   gp_data_.mean = gp_data_in_->mean;     // :18-19
   gp_data_.sigma = gp_data_in_->sigma;
   gp_arrived_time_ = nh_.now ? nh_.now() : 0.0;  // :22
 
-  core_nav::SetStopping srv;
+  corenav_pod::core_nav::SetStopping srv;
   srv.request.stopping = true;           // :25
   if (nh_.call_set_stopping && nh_.call_set_stopping(srv)) {  // :26
     std::copy(srv.response.PvecData.begin(), srv.response.PvecData.end(), P_pred.begin());   // :30-36

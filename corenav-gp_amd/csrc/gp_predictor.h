@@ -17,13 +17,13 @@ class GpPredictor {
   // Declared but never defined in the reference (gp_predictor.h:28-29); defined here as no-ops that
   // record the flag so a caller linking against them still links.
   void mobility(bool flag);
-  void mobilityCallback(const std_msgs::Int64::ConstPtr &msg);
-  void GPCallBack(const core_nav::GP_Output::ConstPtr &gp_data_in_);
+  void mobilityCallback(const corenav_pod::std_msgs::Int64::ConstPtr &msg);
+  void GPCallBack(const corenav_pod::core_nav::GP_Output::ConstPtr &gp_data_in_);
   bool LoadParameters(const corenav::NodeHandle &nh_);
   GpPredictor::Vector3 llh_to_enu(const double latitude, const double longitude, const double height);
 
-  core_nav::GP_Input slip_msg;
-  core_nav::GP_Output gp_data_;
+  corenav_pod::core_nav::GP_Input slip_msg;
+  corenav_pod::core_nav::GP_Output gp_data_;
 
   std::array<double, 16> R_IP{}, R_IP_1{}, R_IP_2{};  // 4x4
   std::array<double, 60> K_pred{};                    // 15x4
@@ -31,7 +31,7 @@ class GpPredictor {
   std::array<double, 225> P_pred{}, STM_{}, Q_{};     // 15x15
 
   GpPredictor::Vector3 savePos{}, ins_enu_slip{}, ins_enu_slip3p{}, ins_enu_slip_3p{};
-  std_msgs::Float64 stop_cmd_msg_;
+  corenav_pod::std_msgs::Float64 stop_cmd_msg_;
 
   bool new_gp_data_arrived_ = false;  // uninitialised in the reference (gp_predictor.h:48)
   bool gp_flag = false;
