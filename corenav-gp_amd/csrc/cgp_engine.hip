@@ -45,6 +45,7 @@ struct cgp_ctx {
   static constexpr int kMaxStreams = 8;
   hipStream_t wstream[kMaxStreams] = {nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr};
+  hipEvent_t ev_look[3 * 64] = {nullptr};  // look-ahead schedule: diag / P1 / P2 completion per step
   int nstreams = 4;
   // device buffers
   void *Lw = nullptr, *Winv = nullptr, *dX = nullptr, *dXs = nullptr, *dy = nullptr;
@@ -218,6 +219,51 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   if (in_rows)
     for (int g = 0; g < G; ++g) HIP_TRY(c, hipMemsetAsync(ga[g].info, 0, sizeof(int) * gb[g], gs[g]));
   static const bool classic = [] { const char *e = getenv("CGP_SCHED"); return e && std::string(e) == "classic"; }();
+  static const bool overlap = [] { const char *e = getenv("CGP_SCHED"); return e && std::string(e) == "overlap"; }();
+  if (overlap && in_rows && G == 1 && !c->prof && a.NT >= 2) {
+    // Look-ahead schedule on two streams: the panel launch of step k is cut into P1 = the tile right
+    // below the diagonal (the only one the next diagonal tile needs) and P2 = all the others, and
+    //     sA:  P1(k) -> diag(k+1)            sB:  P2(k)
+    // run concurrently; events carry the cross dependencies.
+    hipStream_t sA = c->wstream[0], sB = c->wstream[1];
+    auto ev = [&](int i) { return c->ev_look[i]; };
+    HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+    HIP_TRY(c, hipStreamWaitEvent(sA, c->ev_fork, 0));
+    HIP_TRY(c, hipStreamWaitEvent(sB, c->ev_fork, 0));
+    FitArgs a1 = ga[0], a2 = ga[0];
+    a1.tile_off = 0;
+    a2.tile_off = 1;
+    const int B = gb[0], NT = a.NT;
+    hipLaunchKernelGGL(k_diag<T>, dim3(B), dim3(256), tile_lds, sA, ga[0], 0);
+    HIP_TRY(c, hipEventRecord(ev(0), sA));                         // evD[0]
+    for (int k = 0; k < NT; ++k) {
+      const int nin = NT - k - 1;                                  // in-matrix tiles below the diagonal
+      const bool has_p1 = nin >= 1;
+      const int n2 = (has_p1 ? nin - 1 : 0) + a.ET;                // P2: everything but the first tile
+      if (has_p1) {
+        if (k > 0) HIP_TRY(c, hipStreamWaitEvent(sA, ev(3 * (k - 1) + 2), 0));  // P2(k-1)
+        hipLaunchKernelGGL(k_panel<T>, dim3(1, B), dim3(256), upd_lds, sA, a1, k);
+        HIP_TRY(c, hipEventRecord(ev(3 * k + 1), sA));             // evP1[k]
+      }
+      HIP_TRY(c, hipStreamWaitEvent(sB, ev(3 * k), 0));            // diag(k)
+      if (k > 0 && NT - k >= 1) HIP_TRY(c, hipStreamWaitEvent(sB, ev(3 * (k - 1) + 1), 0));  // P1(k-1)
+      FitArgs ap = has_p1 ? a2 : a1;
+      hipLaunchKernelGGL(k_panel<T>, dim3(n2, B), dim3(256), upd_lds, sB, ap, k);
+      HIP_TRY(c, hipEventRecord(ev(3 * k + 2), sB));               // evP2[k]
+      if (k + 1 < NT) {
+        if (!has_p1 && k > 0) HIP_TRY(c, hipStreamWaitEvent(sA, ev(3 * (k - 1) + 2), 0));
+        hipLaunchKernelGGL(k_diag<T>, dim3(B), dim3(256), tile_lds, sA, ga[0], k + 1);
+        HIP_TRY(c, hipEventRecord(ev(3 * (k + 1)), sA));           // evD[k+1]
+      }
+    }
+    HIP_TRY(c, hipStreamWaitEvent(sA, ev(3 * (NT - 1) + 2), 0));
+    hipLaunchKernelGGL(k_finalize<T>, dim3(cdiv(a.M, 64) + 1, B), dim3(256), 0, sA, ga[0], 1);
+    if (want_alpha) hipLaunchKernelGGL(k_alpha<T>, dim3(B), dim3(256), (a.NT * TS + TS) * sizeof(double), sA, ga[0]);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_join[0], sA));
+    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[0], 0));
+    return CGP_OK;
+  }
   for (int k = 0; k < a.NT; ++k) {
     const int gx_u = (in_rows ? a.NT - k : 0) + a.ET;
     const int gx_t = (in_rows ? a.NT - k - 1 : 0) + a.ET;
@@ -396,6 +442,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
     ok = ok && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
   }
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+  for (auto &e : c->ev_look) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc(&c->Lw, B * c->lw_stride * c->esz) == hipSuccess;
   ok = ok && hipMalloc(&c->Winv, B * c->winv_stride * c->esz) == hipSuccess;
   ok = ok && hipMalloc(&c->dX, B * max_d * max_n * c->esz) == hipSuccess;
@@ -438,6 +485,8 @@ void cgp_destroy(cgp_ctx *c) {
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  for (auto e : c->ev_look)
+    if (e) (void)hipEventDestroy(e);
   for (void *wb : c->winbuf)
     if (wb) (void)hipFree(wb);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1100,4 +1149,24 @@ extern "C" int cgp_predict_stop_batch(cgp_ctx *c, int ntraj, int M, const double
     i_out[i] = hi[T + i];
   }
   return CGP_OK;
+}
+
+extern "C" int cgp_selftest_lbfgs(double *x, int n, int max_evals, double *f_out) {
+  if (!x || n < 2 || n > 16) return CGP_EINVAL;
+  std::vector<double> xv(x, x + n);
+  auto fg = [n](const std::vector<double> &v, std::vector<double> &g) {
+    double f = 0.0;
+    for (int i = 0; i < n; ++i) g[i] = 0.0;
+    for (int i = 0; i + 1 < n; ++i) {
+      const double a = v[i + 1] - v[i] * v[i], b = 1.0 - v[i];
+      f += 100.0 * a * a + b * b;
+      g[i] += -400.0 * a * v[i] - 2.0 * b;
+      g[i + 1] += 200.0 * a;
+    }
+    return f;
+  };
+  corenav::LbfgsResult r = corenav::lbfgs_minimize(fg, xv, max_evals > 0 ? max_evals : 1000, 1e-8, 10.0);
+  for (int i = 0; i < n; ++i) x[i] = xv[i];
+  if (f_out) *f_out = r.f;
+  return r.status == 3 ? -1 : r.evals;
 }

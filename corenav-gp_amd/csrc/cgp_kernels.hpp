@@ -56,6 +56,7 @@ struct FitArgs {
   size_t alpha_stride;
   int N, d, M, NT, ET, kernel_id, include_noise;
   int rows_from_extra;   // 1: only the extra (test/y) row tiles are processed (predict after fit)
+  int tile_off;          // first block-tile index of this launch (split panel launches)
   int xid;               // 1: the M (= N) "test rows" are the identity, so the extra block becomes (L^-1)^T (gradient mode)
   double *gpart;         // [batch][pairs][GRAD_N] per-tile-pair partial sums of k_grad
   long long *dbgbuf;     // 64 slots of s_memtime stamps (block 0, CGP_DBG & 512)

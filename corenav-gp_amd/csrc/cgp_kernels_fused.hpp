@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
   T *smem = reinterpret_cast<T *>(smem_raw);
   int bt, b;
   tile_fit_of_block(bt, b);
-  const int rt = row_tile_of(bt, k + 1, p.NT, p.rows_from_extra);
+  const int rt = row_tile_of(bt + p.tile_off, k + 1, p.NT, p.rows_from_extra);
   T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
   const int ld = p.ld;
   const int tid = threadIdx.x, lane = tid & 63;

@@ -56,6 +56,7 @@ _SIGS = {
                                         ctypes.c_double, ctypes.c_double, ctypes.c_int, _dp, _dp, _ip, _dp, _ip, _dp]),
     "cgp_predict_stop_batch": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int] + [_dp] * 9 + [ctypes.c_double, ctypes.c_int,
                                                                                             _dp, _dp, _ip, _dp, _ip, _dp]),
+    "cgp_selftest_lbfgs": (ctypes.c_int, [_dp, ctypes.c_int, ctypes.c_int, _dp]),
     "cgp_recorder_create": (_vp, []),
     "cgp_recorder_destroy": (None, [_vp]),
     "cgp_recorder_update": (ctypes.c_int, [_vp, _dp, ctypes.c_double, ctypes.c_double, _dp, _dp, _dp, ctypes.c_int, _ip]),

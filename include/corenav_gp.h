@@ -84,6 +84,11 @@ int cgp_nll_grad(cgp_ctx *ctx, const double *X, const double *y, int N, int d, i
 int cgp_optimize(cgp_ctx *ctx, const double *X, const double *y, int N, int d, int kernel_id,
                  double *theta_inout, int max_evals, double *logml, int *n_evals);
 
+/* Host-only self-test of the L-BFGS used by cgp_optimize: minimises the n-dimensional Rosenbrock
+ * function from x0 (n <= 16); writes the minimiser, returns the number of evaluations (< 0 on
+ * failure).  Lets the optimiser be tested without a GPU. */
+int cgp_selftest_lbfgs(double *x_inout, int n, int max_evals, double *f_out);
+
 /* ---- the node callback in one call -------------------------------------------------------------
  * Everything gp_slip_node.py:16-63 computes between "GP Input Arrived" and pub.publish(), at fixed
  * theta: first int(0.9 n) samples train (:27-29), grid arange(min, max + 600, 1) (:45), output

@@ -105,3 +105,20 @@ def test_gppredictor_class_callback():
     npub, cmd = engine.gppredictor_callback(np.zeros(0), np.zeros(0), g["PvecData"], g["QvecData"], g["STMvecData"],
                                             g["HvecData"], g["PosData"], 0.0, 0.0)
     assert npub == 0
+
+
+@pytest.mark.parametrize("n", [2, 5, 10])
+def test_lbfgs_selftest_rosenbrock(n):
+    """The host L-BFGS behind cgp_optimize (csrc/lbfgs.hpp) on Rosenbrock, against scipy's L-BFGS-B."""
+    import ctypes
+    import scipy.optimize as so
+    x = np.full(n, -1.2)
+    x[1::2] = 1.0
+    f = ctypes.c_double(0.0)
+    dp = ctypes.POINTER(ctypes.c_double)
+    nev = engine.load().cgp_selftest_lbfgs(x.ctypes.data_as(dp), n, 2000, ctypes.byref(f))
+    assert 0 < nev <= 2000
+    np.testing.assert_allclose(x, np.ones(n), atol=1e-5)
+    assert f.value < 1e-10
+    ref = so.minimize(so.rosen, np.where(np.arange(n) % 2, 1.0, -1.2), jac=so.rosen_der, method="L-BFGS-B")
+    assert nev < 4 * ref.nfev + 50      # same order of work as the reference optimiser
