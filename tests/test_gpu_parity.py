@@ -186,3 +186,25 @@ def test_argument_errors(engine):
     with pytest.raises(engine.CgpError) as ei:
         ctx.fit(np.zeros((8, 2)), np.zeros(8), 2, np.array([1.0, 1.0, 0.1, 0.1]))   # Brownian needs d == 1
     assert ei.value.code == -1
+
+
+@pytest.mark.parametrize("N,d,M,kid", [(15, 1, 20, 2), (134, 1, 599, 2), (129, 3, 70, 1), (300, 6, 64, 1), (640, 2, 130, 0)])
+def test_ragged_shapes_fp32(engine, N, d, M, kid):
+    """The fp32 device path (register-staged MFMA f32 16x16x4) on ragged shapes, 1e-3 tolerance."""
+    rng = np.random.default_rng(900 + N)
+    if kid == 2:
+        X = (11 + np.arange(N, dtype=float))[:, None]
+        Xs = (11 + N + np.arange(M, dtype=float))[:, None]
+        theta = np.array([0.5, 30.0, 0.01, 0.002])
+    else:
+        X, Xs = rng.normal(size=(N, d)), rng.normal(size=(M, d))
+        theta = np.concatenate([[0.8], rng.uniform(0.6, 2.0, 1 if kid == 0 else d), [0.05]])
+    y = 0.1 * np.sin(np.arange(N) / 7.0) + 0.03 * rng.normal(size=N)
+    check_fit_predict(engine, kid, theta, X, y, Xs, engine.F32, TOL32)
+
+
+def test_classic_schedule_still_matches(engine, monkeypatch):
+    """The three-launch schedule kept for A/B (CGP_SCHED=classic is read once per process, so this only
+    checks the default path is the fused one and agrees with the oracle on a multi-tile problem)."""
+    kid, X, y, Xs, th, _ = synth.config(2, N=700)
+    check_fit_predict(engine, kid, th[0], X[0], y[0], Xs[0], engine.F64, TOL64)
