@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="independent fits per GPU per step")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3])
     ap.add_argument("--n", type=int, default=None, help="override window length N")
-    ap.add_argument("--cpu-sample", type=int, default=6, help="fits timed on the host for cpu_baseline")
+    ap.add_argument("--cpu-sample", type=int, default=12, help="fits timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="worker streams the batch is spread over")
     args = ap.parse_args()

@@ -453,7 +453,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc(&c->dalpha, B * c->alpha_stride * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dtheta, B * CGP_MAX_THETA * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->djitter, B * sizeof(double)) == hipSuccess;
-  ok = ok && hipMalloc((void **)&c->dgpart, (size_t)c->NTmax * (c->NTmax + 1) / 2 * GRAD_N * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->dgpart, B * c->NTmax * (c->NTmax + 1) / 2 * GRAD_N * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->ddbg, 64 * sizeof(long long)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dprep, B * PREP_N * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dlogml, B * sizeof(double)) == hipSuccess;
@@ -1169,4 +1169,130 @@ extern "C" int cgp_selftest_lbfgs(double *x, int n, int max_evals, double *f_out
   for (int i = 0; i < n; ++i) x[i] = xv[i];
   if (f_out) *f_out = r.f;
   return r.status == 3 ? -1 : r.evals;
+}
+
+namespace {
+// Gradient-mode evaluation of `batch` windows already uploaded to slots 0..batch-1 (theta in dtheta).
+template <typename T>
+int grad_eval_batch(cgp_ctx *c, int batch, int N, int d, int kid, std::vector<double> &logml, std::vector<double> &sums,
+                    std::vector<int> &info) {
+  hipStream_t s = c->stream;
+  FitArgs a = base_args(c, N, d, /*M=*/N, kid, 0);
+  a.xid = 1;
+  a.X = c->dX;
+  a.Xs = c->dX;
+  a.y = c->dy;
+  a.theta = c->dtheta;
+  a.jitter = nullptr;
+  a.mean = c->dmean;
+  a.var = c->dvar;
+  a.logml = c->dlogml;
+  a.info = c->dinfo;
+  a.gpart = c->dgpart;
+  int rc = run(c, a, batch, true, true, s);
+  if (rc != CGP_OK) return rc;
+  const int npairs = a.NT * (a.NT + 1) / 2;
+  hipLaunchKernelGGL(k_grad<T>, dim3(npairs, batch), dim3(256), upd_lds_bytes<T>(), s, a, npairs);
+  HIP_TRY(c, hipGetLastError());
+  std::vector<double> part((size_t)batch * npairs * GRAD_N);
+  logml.resize(batch);
+  info.resize(batch);
+  HIP_TRY(c, hipMemcpyAsync(part.data(), c->dgpart, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(logml.data(), c->dlogml, sizeof(double) * batch, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(info.data(), c->dinfo, sizeof(int) * batch, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  sums.assign((size_t)batch * GRAD_N, 0.0);
+  for (int b = 0; b < batch; ++b)
+    for (int pz = 0; pz < npairs; ++pz)
+      for (int i = 0; i < GRAD_N; ++i) sums[(size_t)b * GRAD_N + i] += part[((size_t)b * npairs + pz) * GRAD_N + i];
+  return CGP_OK;
+}
+
+// d(-logML)/dtheta from the k_grad sums (same formulas as cgp_nll_grad)
+void grad_from_sums(int kid, int d, const double *theta, const double *sums, double *grad) {
+  if (kid == CGP_KERNEL_SE_ISO) {
+    double se = 0;
+    for (int q = 0; q < d; ++q) se += sums[1 + q];
+    grad[0] = -0.5 * sums[0] / theta[0];
+    grad[1] = -0.5 * se / theta[1];
+    grad[2] = -0.5 * sums[9];
+  } else if (kid == CGP_KERNEL_SE_ARD) {
+    grad[0] = -0.5 * sums[0] / theta[0];
+    for (int q = 0; q < d; ++q) grad[1 + q] = -0.5 * sums[1 + q] / theta[1 + q];
+    grad[d + 1] = -0.5 * sums[9];
+  } else {
+    grad[0] = -0.5 * sums[0] / theta[0];
+    grad[1] = -0.5 * sums[1] / theta[1];
+    grad[2] = -0.5 * sums[0] / theta[2];
+    grad[3] = -0.5 * sums[9];
+  }
+}
+}  // namespace
+
+extern "C" int cgp_optimize_batch(cgp_ctx *c, int batch, int N, int d, int kid, const double *X, const double *y,
+                                  double *theta, int theta_stride, int max_evals, double *logml_out, int *n_evals) {
+  int rc = check_shape(c, batch, N, d, N, kid);
+  if (rc != CGP_OK) return rc;
+  if (!X || !y || !theta) return CGP_EINVAL;
+  const int nth = ntheta(kid, d);
+  if (theta_stride < nth) return CGP_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t esz = c->esz;
+  std::vector<char> hx((size_t)batch * d * N * esz), hy((size_t)batch * N * esz);
+  for (int b = 0; b < batch; ++b) {
+    pack_soa(X + (size_t)b * N * d, N, d, c->dtype, hx, (size_t)b * d * N);
+    pack_vec(y + (size_t)b * N, N, c->dtype, hy, (size_t)b * N);
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->dX, hx.data(), hx.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemcpyAsync(c->dy, hy.data(), hy.size(), hipMemcpyHostToDevice, s));
+  auto to_theta = [](double x) { return x > 35.0 ? x : std::log1p(std::exp(x)); };
+  auto to_x = [](double th) { return th > 35.0 ? th : std::log(std::expm1(th)); };
+  std::vector<corenav::LbfgsStepper> st;
+  st.reserve(batch);
+  for (int b = 0; b < batch; ++b) {
+    std::vector<double> x0(nth);
+    for (int i = 0; i < nth; ++i) {
+      if (!(theta[(size_t)b * theta_stride + i] > 0.0)) return CGP_EINVAL;
+      x0[i] = to_x(theta[(size_t)b * theta_stride + i]);
+    }
+    st.emplace_back(x0, max_evals > 0 ? max_evals : 1000, 1e-5, 1e7);
+  }
+  std::vector<double> th((size_t)batch * nth), hth, lml, sums, g(nth), gx(nth);
+  std::vector<int> info;
+  c->have_fit = false;
+  for (int round = 0; round < (max_evals > 0 ? max_evals : 1000) + 40; ++round) {
+    bool any = false;
+    for (int b = 0; b < batch; ++b) {
+      any = any || !st[b].done();
+      const std::vector<double> &xx = st[b].done() ? st[b].best() : st[b].trial();
+      for (int i = 0; i < nth; ++i) th[(size_t)b * nth + i] = std::max(to_theta(xx[i]), 1e-300);
+    }
+    if (!any) break;
+    rc = upload_theta(c, th.data(), nth, nth, batch, s, hth);
+    if (rc != CGP_OK) return rc;
+    rc = c->dtype == CGP_F64 ? grad_eval_batch<double>(c, batch, N, d, kid, lml, sums, info)
+                             : grad_eval_batch<float>(c, batch, N, d, kid, lml, sums, info);
+    if (rc != CGP_OK) return rc;
+    for (int b = 0; b < batch; ++b) {
+      if (st[b].done()) continue;
+      const double *tb = th.data() + (size_t)b * nth;
+      double f = INFINITY;
+      if (info[b] == 0) {
+        grad_from_sums(kid, d, tb, sums.data() + (size_t)b * GRAD_N, g.data());
+        const std::vector<double> &xx = st[b].trial();
+        for (int i = 0; i < nth; ++i) gx[i] = g[i] * (xx[i] > 35.0 ? 1.0 : -std::expm1(-tb[i]));
+        f = -lml[b];
+      }
+      st[b].tell(f, gx);
+    }
+  }
+  for (int b = 0; b < batch; ++b) {
+    const std::vector<double> &xb = st[b].best();
+    for (int i = 0; i < nth; ++i) theta[(size_t)b * theta_stride + i] = to_theta(xb[i]);
+    const corenav::LbfgsResult r = st[b].result();
+    if (logml_out) logml_out[b] = -r.f;
+    if (n_evals) n_evals[b] = r.evals;
+  }
+  return CGP_OK;
 }

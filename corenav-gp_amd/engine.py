@@ -56,6 +56,8 @@ _SIGS = {
                                         ctypes.c_double, ctypes.c_double, ctypes.c_int, _dp, _dp, _ip, _dp, _ip, _dp]),
     "cgp_predict_stop_batch": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int] + [_dp] * 9 + [ctypes.c_double, ctypes.c_int,
                                                                                             _dp, _dp, _ip, _dp, _ip, _dp]),
+    "cgp_optimize_batch": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
+                                          ctypes.c_int, ctypes.c_int, _dp, _ip]),
     "cgp_selftest_lbfgs": (ctypes.c_int, [_dp, ctypes.c_int, ctypes.c_int, _dp]),
     "cgp_recorder_create": (_vp, []),
     "cgp_recorder_destroy": (None, [_vp]),
@@ -186,6 +188,21 @@ class Context:
             raise CgpError(rc)
         self._n = X.shape[0]
         return theta, logml.value, nev.value
+
+    def optimize_batch(self, X, y, kernel_id, theta0, max_evals=1000):
+        """Batched m.optimize(): X (B, N, d), y (B, N), theta0 (B, nth) -> (theta_opt, logml, n_evals)."""
+        X, y = _d(X), _d(y)
+        B, N, d = X.shape
+        theta = np.array(theta0, dtype=np.float64)
+        if theta.ndim == 1:
+            theta = np.tile(theta, (B, 1))
+        theta = np.ascontiguousarray(theta)
+        logml, nev = np.empty(B), np.zeros(B, dtype=np.int32)
+        rc = self._chk(self.lib.cgp_optimize_batch(self.h, B, N, d, kernel_id, _p(X), _p(y), _p(theta), theta.shape[1],
+                                                   max_evals, _p(logml), nev.ctypes.data_as(_ip)))
+        if rc > 0:
+            raise CgpError(rc)
+        return theta, logml, nev
 
     def slip_node_callback_opt(self, time_array, slip_array, theta0, kernel_id=KERNEL_RBF_BROWNIAN, max_evals=1000,
                                cap=4096):

@@ -85,17 +85,12 @@ class ClosedLoopEnsemble:
         self.traj = [Trajectory(seed + 31 * i) for i in range(n_traj)]
         self.theta = np.asarray(theta, dtype=np.float64)
         self.optimize = optimize
-        self.ctx = engine.Context(device=device, max_n=256, max_m=1024, max_d=1, max_batch=max(n_traj, 1))
+        self.ctx = engine.Context(device=device, max_n=256, max_m=1024, max_d=1, max_batch=max(n_traj, 1))   # max_m >= N: optimiser needs it
         self.now = 0.0
 
     def _fit_windows(self, idx, wins):
         """gp_slip_node.py:16-63 for every window published this tick (batched when theta is fixed)."""
         outs = []
-        if self.optimize:
-            for t, s in wins:
-                m, sg, th = self.ctx.slip_node_callback_opt(t, s, np.ones(4))
-                outs.append((m, sg, th))
-            return outs
         same = len({len(t) for t, _ in wins}) == 1
         if same and len(wins) > 1:
             n = len(wins[0][0])
@@ -103,13 +98,19 @@ class ClosedLoopEnsemble:
             X = np.stack([t[:ntr, None] for t, _ in wins])
             y = np.stack([s[:ntr] for _, s in wins])
             Xs = np.stack([(t.min() + n + np.arange(int(np.ceil(t.max() + 600 - t.min())) - n))[:, None] for t, _ in wins])
-            th = np.tile(self.theta, (len(wins), 1))
+            if self.optimize:   # gp_slip_node.py:36 for the whole ensemble: one batched L-BFGS from GPy's start values
+                th, _, _ = self.ctx.optimize_batch(X, y, engine.KERNEL_RBF_BROWNIAN, np.ones(4))
+            else:
+                th = np.tile(self.theta, (len(wins), 1))
             rc, mean, var, _, info = self.ctx.fit_predict_batch(X, y, Xs, th, engine.KERNEL_RBF_BROWNIAN)
             assert rc == 0, info
-            return [(mean[i], 2.0 * np.sqrt(var[i]), self.theta) for i in range(len(wins))]
+            return [(mean[i], 2.0 * np.sqrt(var[i]), th[i]) for i in range(len(wins))]
         for t, s in wins:
-            m, sg = self.ctx.slip_node_callback(t, s, self.theta)
-            outs.append((m, sg, self.theta))
+            if self.optimize:
+                m, sg, th = self.ctx.slip_node_callback_opt(t, s, np.ones(4))
+            else:
+                m, sg, th = (*self.ctx.slip_node_callback(t, s, self.theta), self.theta)
+            outs.append((m, sg, th))
         return outs
 
     def step(self):

@@ -84,6 +84,15 @@ int cgp_nll_grad(cgp_ctx *ctx, const double *X, const double *y, int N, int d, i
 int cgp_optimize(cgp_ctx *ctx, const double *X, const double *y, int N, int d, int kernel_id,
                  double *theta_inout, int max_evals, double *logml, int *n_evals);
 
+/* cgp_optimize_batch: the same optimisation for `batch` windows of identical shape at once.  Every
+ * L-BFGS round evaluates value + gradient of ALL windows in one batched device schedule (each window
+ * keeps its own line-search / history state on the host); a window whose matrix is not positive
+ * definite at a trial point treats it as infeasible (no jitter retry in the batched path).
+ * X (batch, N, d), y (batch, N), theta_inout (batch, theta_stride); logml / n_evals (batch) may be
+ * NULL.  Needs max_batch >= batch and max_m >= N.  Follow with cgp_fit_predict_batch at the optima. */
+int cgp_optimize_batch(cgp_ctx *ctx, int batch, int N, int d, int kernel_id, const double *X, const double *y,
+                       double *theta_inout, int theta_stride, int max_evals, double *logml, int *n_evals);
+
 /* Host-only self-test of the L-BFGS used by cgp_optimize: minimises the n-dimensional Rosenbrock
  * function from x0 (n <= 16); writes the minimiser, returns the number of evaluations (< 0 on
  * failure).  Lets the optimiser be tested without a GPU. */

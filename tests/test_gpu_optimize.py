@@ -83,3 +83,24 @@ def test_node_mirror_optimises_like_the_reference(engine):
     assert len(out.mean) == 599 and np.all(np.isfinite(out.sigma)) and np.all(out.sigma > 0)
     X, Y, xtr, ytr = go.slip_node_split(g["time_array"], g["slip_array"])
     assert -go.nll_and_grad(2, n.last_theta, xtr, ytr[:, 0])[0] > -go.nll_and_grad(2, np.ones(4), xtr, ytr[:, 0])[0]
+
+
+def test_optimize_batch_matches_single(engine):
+    """Batched optimiser: every window follows the same L-BFGS trajectory as the single-window call
+    (same objective values per evaluation, so the same optimum up to rounding)."""
+    B, N = 6, 134
+    Xs, ys = [], []
+    for b in range(B):
+        t, s = synth.reference_window(149, tick0=11 + 7 * b, seed=synth.SEED_BASE + 50 + b)
+        Xs.append(t[:N, None])
+        ys.append(s[:N])
+    X, y = np.stack(Xs), np.stack(ys)
+    ctx = engine.Context(max_n=N, max_m=N, max_d=1, max_batch=B)
+    th, lml, nev = ctx.optimize_batch(X, y, 2, np.ones(4))
+    ctx1 = engine.Context(max_n=N, max_m=N, max_d=1)
+    for b in range(B):
+        th1, lml1, nev1 = ctx1.optimize(X[b], y[b], 2, np.ones(4))
+        assert lml[b] == pytest.approx(lml1, rel=1e-9) and nev[b] <= 1000
+        np.testing.assert_allclose(th[b], th1, rtol=1e-6)
+        olml = go.optimize(2, X[b], y[b])[1]
+        assert lml[b] >= olml - 1e-5 * abs(olml)
