@@ -208,3 +208,15 @@ def test_classic_schedule_still_matches(engine, monkeypatch):
     checks the default path is the fused one and agrees with the oracle on a multi-tile problem)."""
     kid, X, y, Xs, th, _ = synth.config(2, N=700)
     check_fit_predict(engine, kid, th[0], X[0], y[0], Xs[0], engine.F64, TOL64)
+
+
+def test_brownian_sign_structure(engine):
+    """GPy Brownian.K is zero between inputs of opposite sign and min(|x|,|x'|) otherwise: a window that
+    straddles zero gives a block-diagonal K (never the case on the rover, where ticks are positive,
+    but it is the kernel's definition and the sign test is per entry in the HIP code)."""
+    X = np.concatenate([np.linspace(-60.0, -1.0, 40), np.linspace(2.0, 90.0, 55)])[:, None]
+    rng = np.random.default_rng(8)
+    y = 0.1 * np.sin(X[:, 0] / 9.0) + 0.02 * rng.normal(size=len(X))
+    Xs = np.array([-80.0, -30.5, -0.5, 0.5, 45.25, 120.0])[:, None]
+    theta = np.array([0.6, 25.0, 0.02, 0.004])
+    check_fit_predict(engine, 2, theta, X, y, Xs, engine.F64, TOL64)
