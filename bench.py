@@ -57,11 +57,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # CGP_BENCH_BACKEND=gloo + CGP_BENCH_SAME_DEVICE=1: self-test of the N > 1 flow on a 1-GPU box
+    backend = os.environ.get("CGP_BENCH_BACKEND", "nccl")
+    if os.environ.get("CGP_BENCH_SAME_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")   # where collective tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B = args.batch
     # every rank owns its own shard of windows (weak scaling: per-GPU work fixed)
@@ -111,7 +119,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -120,7 +128,7 @@ def main():
 
     # per-fit summaries gathered over RCCL (the only collective on the path: SURVEY.md 8e)
     summ = torch.stack([dlogml, 2.0 * dvar.to(torch.float64).max(1).values.sqrt(), dinfo.to(torch.float64)], 1)
-    table = sharding.gather_summaries(summ, B * world)
+    table = sharding.gather_summaries(summ.to(cdev), B * world)
     ens = sharding.ensemble_stats(table)
 
     # ---- roofline of the dominant kernel (k_panel: trailing syrk/gemm + Gram + trmm), HIP events per launch
