@@ -220,3 +220,48 @@ def test_brownian_sign_structure(engine):
     Xs = np.array([-80.0, -30.5, -0.5, 0.5, 45.25, 120.0])[:, None]
     theta = np.array([0.6, 25.0, 0.02, 0.004])
     check_fit_predict(engine, 2, theta, X, y, Xs, engine.F64, TOL64)
+
+
+def test_batch_jitter_retry_is_per_fit(engine):
+    """One window of a batch needs GPy's jitter, the others must come back untouched (and bitwise equal
+    to a batch without the bad window)."""
+    rng = np.random.default_rng(21)
+    N, d, M, B = 40, 1, 7, 3
+    X = np.stack([np.sort(rng.normal(size=(N, d)), 0) for _ in range(B)])
+    X[1, :, 0] = np.repeat(np.arange(N // 2, dtype=float), 2)         # duplicated inputs -> rank deficient K
+    y = np.sin(X[:, :, 0])
+    Xs = np.tile(np.linspace(-1, 1, M)[None, :, None], (B, 1, 1))
+    th = np.array([[1.0, 1.0, 0.05], [1.0, 3.0, -1e-8 - 2e-7], [1.0, 1.0, 0.05]])   # window 1: slightly indefinite
+    ctx = engine.Context(max_n=64, max_m=8, max_d=1, max_batch=B)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, 0)
+    f1 = None
+    try:
+        f1 = go.fit(0, th[1], X[1], y[1])
+    except np.linalg.LinAlgError:
+        pass
+    if f1 is not None:
+        assert rc == 0 and info[1] == 0 and f1.jitter > 0
+        omu, ovar = go.predict(f1, Xs[1])
+        assert relmax(mean[1], omu) < 1e-5 and abs(logml[1] - f1.logml) < 1e-5 * abs(f1.logml)
+    else:
+        assert info[1] > 0
+    for b in (0, 2):
+        f = go.fit(0, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        assert info[b] == 0 and relmax(mean[b], omu) < TOL64 and releach(var[b], ovar) < TOL64
+
+
+def test_stream_groups_do_not_change_results(engine):
+    """The batch is cut into worker-stream groups (cgp_set_streams); any grouping gives bitwise the
+    same answers, including an odd batch that does not divide evenly."""
+    kid, X, y, Xs, th, _ = synth.config(2, batch=5, N=300)
+    ref = None
+    for ns in (1, 2, 3):
+        ctx = engine.Context(max_n=300, max_m=599, max_d=6, max_batch=5)
+        ctx.set_streams(ns)
+        rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+        assert rc == 0
+        if ref is None:
+            ref = (mean, var, logml)
+        else:
+            assert np.array_equal(mean, ref[0]) and np.array_equal(var, ref[1]) and np.array_equal(logml, ref[2])
