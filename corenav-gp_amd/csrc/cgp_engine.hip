@@ -118,6 +118,7 @@ struct Launcher {
 };
 
 template <typename T> constexpr int upd_lds_bytes() { return 4 * KT * LDST * (int)sizeof(T); }
+template <typename T> constexpr int paneldiag_lds_bytes() { return std::max(upd_lds_bytes<T>(), diag_lds_elems<T>() * (int)sizeof(T)); }
 template <typename T> constexpr int potf2_lds_bytes() {
   return (TS * LDP + 8 * DB * DB + 4 * DB * DB) * (int)sizeof(T) + 16;
 }
@@ -129,7 +130,8 @@ template <typename T> int set_lds_attrs() {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trmm<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, paneldiag_lds_bytes<T>()) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
   done = true;
@@ -219,6 +221,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   if (in_rows)
     for (int g = 0; g < G; ++g) HIP_TRY(c, hipMemsetAsync(ga[g].info, 0, sizeof(int) * gb[g], gs[g]));
   static const bool classic = [] { const char *e = getenv("CGP_SCHED"); return e && std::string(e) == "classic"; }();
+  static const bool split = [] { const char *e = getenv("CGP_SCHED"); return !(e && std::string(e) == "fuseddiag"); }();
   static const bool overlap = [] { const char *e = getenv("CGP_SCHED"); return e && std::string(e) == "overlap"; }();
   if (overlap && in_rows && G == 1 && !c->prof && a.NT >= 2) {
     // Look-ahead schedule on two streams: the panel launch of step k is cut into P1 = the tile right
@@ -242,13 +245,13 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       const int n2 = (has_p1 ? nin - 1 : 0) + a.ET;                // P2: everything but the first tile
       if (has_p1) {
         if (k > 0) HIP_TRY(c, hipStreamWaitEvent(sA, ev(3 * (k - 1) + 2), 0));  // P2(k-1)
-        hipLaunchKernelGGL(k_panel<T>, dim3(1, B), dim3(256), upd_lds, sA, a1, k);
+        hipLaunchKernelGGL((k_panel<T, false>), dim3(1, B), dim3(256), upd_lds, sA, a1, k);
         HIP_TRY(c, hipEventRecord(ev(3 * k + 1), sA));             // evP1[k]
       }
       HIP_TRY(c, hipStreamWaitEvent(sB, ev(3 * k), 0));            // diag(k)
       if (k > 0 && NT - k >= 1) HIP_TRY(c, hipStreamWaitEvent(sB, ev(3 * (k - 1) + 1), 0));  // P1(k-1)
       FitArgs ap = has_p1 ? a2 : a1;
-      hipLaunchKernelGGL(k_panel<T>, dim3(n2, B), dim3(256), upd_lds, sB, ap, k);
+      hipLaunchKernelGGL((k_panel<T, false>), dim3(n2, B), dim3(256), upd_lds, sB, ap, k);
       HIP_TRY(c, hipEventRecord(ev(3 * k + 2), sB));               // evP2[k]
       if (k + 1 < NT) {
         if (!has_p1 && k > 0) HIP_TRY(c, hipStreamWaitEvent(sA, ev(3 * (k - 1) + 2), 0));
@@ -281,13 +284,19 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
         hipLaunchKernelGGL(k_trmm<T>, dim3(gx_t, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
         L[g].end();
       } else {
-        if (in_rows) {
+        // default: one k_diag launch per step.  CGP_SCHED=fuseddiag: diagonal tile k+1 rides in the
+        // panel launch of step k (measured: +0.6 % fp64 N=2048, -5 % fp32 N=1024 -- DESIGN.md).
+        const bool fuse_next = !split && in_rows && k + 1 < a.NT;
+        if (in_rows && (split || k == 0)) {
           L[g].begin(1, diag_flops(a.N, a.d, k, gb[g]));
           hipLaunchKernelGGL(k_diag<T>, dim3(gb[g]), dim3(256), tile_lds, gs[g], ga[g], k);
           L[g].end();
         }
-        L[g].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, gb[g]));
-        hipLaunchKernelGGL(k_panel<T>, dim3(gx_t, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
+        L[g].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, gb[g]) + (fuse_next ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0));
+        if (fuse_next)
+          hipLaunchKernelGGL((k_panel<T, true>), dim3(gx_t, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ga[g], k);
+        else
+          hipLaunchKernelGGL((k_panel<T, false>), dim3(gx_t, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
         L[g].end();
       }
     }
@@ -521,6 +530,8 @@ int cgp_profile_read(cgp_ctx *c, double ms[CGP_PROF_KERNELS], double flops[CGP_P
     HIP_TRY(c, hipEventSynchronize(r.b));
     float t = 0;
     HIP_TRY(c, hipEventElapsedTime(&t, r.a, r.b));
+    static const bool dump = getenv("CGP_PROF_DUMP") != nullptr;
+    if (dump) fprintf(stderr, "cgp prof: kernel %d  %.4f ms\n", r.kernel, t);
     c->prof_ms[r.kernel] += t;
     c->prof_flops[r.kernel] += r.flops;
     c->prof_n[r.kernel] += 1;

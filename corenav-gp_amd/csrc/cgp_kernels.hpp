@@ -124,6 +124,28 @@ __device__ __forceinline__ void tile_fit_of_block(int &t, int &b) {
   }
 }
 
+// Same, for launches whose tile slot 0 is a long-running workgroup (k_panel with the next diagonal
+// tile fused in): the slot-0 workgroup of every fit gets the lowest linear ids, i.e. is dispatched
+// first, and the other slots follow in the XCD-steered order.
+__device__ __forceinline__ void tile_fit_of_block_first(int &t, int &b) {
+  const int T = gridDim.x, B = gridDim.y;
+  const int lin = blockIdx.y * T + blockIdx.x;
+  if (lin < B) {
+    t = 0;
+    b = lin;
+    return;
+  }
+  const int l2 = lin - B;
+  if ((B & 7) == 0) {
+    const int xcd = l2 & 7, slot = l2 >> 3;
+    t = 1 + slot % (T - 1);
+    b = (slot / (T - 1)) * 8 + xcd;
+  } else {
+    t = 1 + l2 % (T - 1);
+    b = l2 / (T - 1);
+  }
+}
+
 // readlane for scalars of either precision (lane index must be wave-uniform)
 __device__ __forceinline__ float rdlane(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
@@ -462,6 +484,38 @@ __global__ __launch_bounds__(256, 2) void k_trmm(FitArgs p, int k) {
   }
 }
 
+// One 16x16 diagonal block in the registers of a wavefront: lane holds row (lane & 15) of the block
+// in a[] (replicated over the four 16-lane groups).  On return a[] holds the row of the Cholesky
+// factor and w[i] = Dinv[i][lane & 15] (column (lane & 15) of the block's inverse, by forward
+// substitution).  A non-positive pivot is replaced by 1 and reported in `bad` (1-based global index).
+template <typename T>
+__device__ __forceinline__ void factor_block16(T (&a)[DB], T (&w)[DB], int &bad, int pivot_base, int l15) {
+  using P = Prec<T>;
+  T rinv[DB];
+#pragma unroll
+  for (int j = 0; j < DB; ++j) {
+    T dj = rdlane(a[j], j);
+    if (!(dj > T(0))) {
+      if (bad == 0) bad = pivot_base + j + 1;
+      dj = T(1);
+    }
+    const T rs = P::rsqrt_(dj);
+    rinv[j] = rs;
+    const T l = (l15 == j) ? dj * rs : a[j] * rs;
+    a[j] = l;
+#pragma unroll
+    for (int c = j + 1; c < DB; ++c) a[c] -= l * rdlane(l, c);
+  }
+#pragma unroll
+  for (int i = 0; i < DB; ++i) {
+    T s = 0;
+#pragma unroll
+    for (int q = 0; q < DB; ++q)
+      if (q < i) s += rdlane(a[q], i) * w[q];
+    w[i] = (i < l15) ? T(0) : ((i == l15) ? rinv[i] : -s * rinv[i]);
+  }
+}
+
 // --------------------------------------------------------------------------------------------------
 // k_potf2: factor the 128x128 diagonal tile (a3 "potf2_diag") and invert the factor, one workgroup
 // per fit, everything resident in LDS:
@@ -487,39 +541,16 @@ __device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, i
     long long s0 = __builtin_amdgcn_s_memtime();
     if (wave == 0) {
       // (a) lane holds row (lane & 15) of the diagonal block (replicated over the four 16-lane groups)
-      T a[DB], rinv[DB];
+      T a[DB], w[DB];
 #pragma unroll
       for (int c = 0; c < DB; ++c) a[c] = At[(j0 + c) * LDP + j0 + l15];
       int bad = 0;
-#pragma unroll
-      for (int j = 0; j < DB; ++j) {
-        T dj = rdlane(a[j], j);
-        if (!(dj > T(0))) {
-          if (bad == 0) bad = k * TS + j0 + j + 1;
-          dj = T(1);
-        }
-        const T rs = P::rsqrt_(dj);
-        rinv[j] = rs;
-        const T l = (l15 == j) ? dj * rs : a[j] * rs;
-        a[j] = l;
-#pragma unroll
-        for (int c = j + 1; c < DB; ++c) a[c] -= l * rdlane(l, c);
-      }
+      factor_block16<T>(a, w, bad, k * TS + j0, l15);
       if (bad != 0 && lane == 0 && *flag == 0) *flag = bad;
       if (lane < DB) {
 #pragma unroll
         for (int c = 0; c < DB; ++c)
           if (l15 >= c) At[(j0 + c) * LDP + j0 + l15] = a[c];
-      }
-      // inverse of the block: lane x computes column x of Dinv by forward substitution
-      T w[DB];
-#pragma unroll
-      for (int i = 0; i < DB; ++i) {
-        T s = 0;
-#pragma unroll
-        for (int q = 0; q < DB; ++q)
-          if (q < i) s += rdlane(a[q], i) * w[q];
-        w[i] = (i < l15) ? T(0) : ((i == l15) ? rinv[i] : -s * rinv[i]);
       }
       if (lane < DB) {
 #pragma unroll

@@ -301,9 +301,209 @@ __device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::a
 }
 
 // --------------------------------------------------------------------------------------------------
+// Diagonal tile inside the panel launch (schedule "fused", the default).  The workgroup that owns
+// tile (k+1, k) of step k is the only one the next diagonal tile waits for, so it carries on and
+// updates, factors and inverts tile (k+1, k+1) itself while the rest of the step-k launch keeps the
+// other CUs busy: no diagonal launch sits between two panel launches any more.  To share a CU with a
+// second panel workgroup it has to live in the panel's LDS budget, so the tile is held as its 36
+// lower 16x16 blocks only (72 KB) and L^-1 grows in the blocks the factorisation has finished with:
+//   step jb:  (a)  wave 0: L_jj, Dinv_jb in registers            | waves 1-3: (e) of step jb-1
+//             (b)  L_i,jb = A_i,jb Dinv_jb^T      (i > jb)        (b') W_jb,j = -Dinv_jb T_jb,j   (j < jb)
+//             (c)  A_bi,bj -= L_bi,jb L_bj,jb^T   (bi >= bj > jb) (c') T_i,j += L_i,jb W_jb,j     (i > jb > j)
+//             (e)  L_i,jb -> HBM, then T_i,jb = L_i,jb Dinv_jb overwrites it
+// with T_i,j = sum_{j <= q < current step} L_i,q W_q,j the running right-looking sum of the forward
+// substitution L W = I; when step i arrives it is complete and (b') turns it into W_i,j.  A blocks
+// are stored [col][row], T / W blocks [row][col]: every MFMA operand read and accumulator access
+// below is then a contiguous 512-byte run per wavefront (no LDS bank conflicts).
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ constexpr int tri_blk(int i, int j) { return (i * (i + 1) / 2 + j) * DB * DB; }
+template <typename T> constexpr int diag_lds_elems() { return 36 * DB * DB + 3 * DB * DB; }
+
+template <typename T>
+__device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restrict__ Bk, T *__restrict__ tile, int ld,
+                                                   T *__restrict__ Wk, int b, int k, int tid) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
+  constexpr int NB = TS / DB;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  T *Dv = Bk + 36 * DB * DB;  // Dv[q][x]  = Dinv_jb[x][q]
+  T *DvT = Dv + DB * DB;      // DvT[jb & 1][q][c] = Dinv_jb[q][c]
+  int bad = 0;
+  for (int jb = 0; jb < NB; ++jb) {
+    const int j0 = jb * DB;
+    if (wave == 0) {
+      T *Djj = Bk + tri_blk(jb, jb);
+      T a[DB], w[DB];
+#pragma unroll
+      for (int c = 0; c < DB; ++c) a[c] = Djj[c * DB + l15];
+      factor_block16<T>(a, w, bad, k * TS + j0, l15);
+      if (lane < DB) {
+        T *dvt = DvT + (jb & 1) * DB * DB;
+#pragma unroll
+        for (int i = 0; i < DB; ++i) {
+          Dv[l15 * DB + i] = w[i];
+          dvt[i * DB + l15] = w[i];
+          Wk[(size_t)(j0 + l15) * TS + j0 + i] = w[i];
+        }
+#pragma unroll
+        for (int c = 0; c < DB; ++c) tile[(size_t)(j0 + c) * ld + j0 + l15] = (l15 >= c) ? a[c] : T(0);
+      }
+    } else if (jb > 0) {
+      const int pj = jb - 1;
+      const T *dvt = DvT + (pj & 1) * DB * DB;
+      for (int i = jb + wave - 1; i < NB; i += 3) {
+        T *blk = Bk + tri_blk(i, pj);
+        T fa[4], fb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          fa[ks] = blk[(ks * 4 + lq) * DB + l15];  // L_i,pj[r = l15][q]
+          fb[ks] = dvt[(ks * 4 + lq) * DB + l15];  // Dinv_pj[q][c = l15]
+          tile[(size_t)(pj * DB + ks * 4 + lq) * ld + i * DB + l15] = fa[ks];
+        }
+        acc_t acc = acc_t{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) blk[P::drow(lane, r) * DB + l15] = acc[r];  // T_i,pj[r][c]
+      }
+    }
+    __syncthreads();
+    // (b) and (b'): NB - 1 independent 16x16 products
+    for (int t = wave; t < NB - 1; t += 4) {
+      const bool below = t < NB - 1 - jb;
+      T *blk = below ? Bk + tri_blk(jb + 1 + t, jb) : Bk + tri_blk(jb, t - (NB - 1 - jb));
+      T fa[4], fb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        fa[ks] = Dv[(ks * 4 + lq) * DB + l15];   // Dinv_jb[x = l15][q]
+        fb[ks] = blk[(ks * 4 + lq) * DB + l15];  // A_i,jb[r = l15][q]   or   T_jb,j[q][c = l15]
+      }
+      acc_t acc = acc_t{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) blk[P::drow(lane, r) * DB + l15] = below ? acc[r] : -acc[r];
+    }
+    __syncthreads();
+    // (c) and (c')
+    const int nb = NB - 1 - jb;
+    const int nc = nb * (nb + 1) / 2;
+    for (int idx = wave; idx < nc + nb * jb; idx += 4) {
+      T *cblk;
+      const T *ablk, *bblk;
+      bool neg;
+      if (idx < nc) {
+        int bj = 0, rem = idx;
+        while (rem >= nb - bj) {
+          rem -= nb - bj;
+          ++bj;
+        }
+        const int bi = bj + rem + jb + 1;
+        bj += jb + 1;
+        cblk = Bk + tri_blk(bi, bj);
+        ablk = Bk + tri_blk(bj, jb);
+        bblk = Bk + tri_blk(bi, jb);
+        neg = true;
+      } else {
+        const int e = idx - nc;
+        const int i = jb + 1 + e / jb, j = e % jb;
+        cblk = Bk + tri_blk(i, j);
+        ablk = Bk + tri_blk(i, jb);
+        bblk = Bk + tri_blk(jb, j);
+        neg = false;
+      }
+      acc_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = cblk[P::drow(lane, r) * DB + l15];
+      T fa[4], fb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const T av = ablk[(ks * 4 + lq) * DB + l15];
+        fa[ks] = neg ? -av : av;
+        fb[ks] = bblk[(ks * 4 + lq) * DB + l15];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cblk[P::drow(lane, r) * DB + l15] = acc[r];
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && bad != 0 && p.info[b] == 0) p.info[b] = bad;
+  // strictly lower blocks of W -> HBM (column-major 128 x 128, as the panel kernels stage it)
+  for (int idx = tid; idx < 28 * DB * DB; idx += 256) {
+    const int blk = idx >> 8, e = idx & 255;
+    int i = 1, rem = blk;
+    while (rem >= i) {
+      rem -= i;
+      ++i;
+    }
+    const int j = rem, c = e >> 4, r = e & 15;
+    Wk[(size_t)(j * DB + c) * TS + i * DB + r] = Bk[tri_blk(i, j) + r * DB + c];
+  }
+}
+
+// acc = -S(kn, kn) on entry state "free": Gram + update of the diagonal tile kn, then the packed
+// factorisation.  Called by the whole workgroup that has just stored tile (kn, kn - 1).
+template <typename T>
+__device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
+                                          T *__restrict__ Lw, int b, int kn, int tid) {
+  using P = Prec<T>;
+  using vec2 = T __attribute__((ext_vector_type(2)));
+  const int ld = p.ld;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15;
+  constexpr int CH2 = 2 * KT * LDST;
+  // tile (kn, kn-1), written by this workgroup a moment ago, is the last chunk of the row panel
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const T *gR = Lw + (size_t)kn * TS;
+  const int nchunk = (kn * TS) / KT;
+  {
+    GramPre<T> gp;
+    gram_prefetch<T>(p, b, kn, kn, tid, gp);
+    stage_first_chunk<T>(gR, (size_t)ld, gR, (size_t)ld, smem, tid);
+    gram_apply<T>(p, acc, smem + CH2, b, kn, kn, tid, gp);
+  }
+  mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gR, (size_t)ld, nchunk, smem, tid);
+  __syncthreads();
+  T *tile = Lw + (size_t)(kn * TS) * ld + (size_t)kn * TS;
+  // S = -acc -> the 36 lower blocks; rows 32 wave + 2 l15 + {0, 1} live in block row 2 wave + (l15 >> 3)
+  const int rb = 2 * wave + (l15 >> 3), rin = (2 * l15) & 15;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+    if (cb <= rb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        vec2 v;
+        v[0] = -acc[cb][0][r];
+        v[1] = -acc[cb][1][r];
+        *reinterpret_cast<vec2 *>(smem + tri_blk(rb, cb) + P::drow(lane, r) * DB + rin) = v;
+      }
+    }
+  // the strictly upper blocks of the tile in HBM are zero
+  for (int idx = tid; idx < 28 * DB * DB; idx += 256) {
+    const int blk = idx >> 8, e = idx & 255;
+    int i = 1, rem = blk;
+    while (rem >= i) {
+      rem -= i;
+      ++i;
+    }
+    tile[(size_t)(i * DB + (e >> 4)) * ld + rem * DB + (e & 15)] = T(0);
+  }
+  __syncthreads();
+  T *Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)kn * TS * TS;
+  diag_factor_packed<T>(p, smem, tile, ld, Wk, b, kn, tid);
+}
+
+// --------------------------------------------------------------------------------------------------
 // k_panel: L(rt, k) = (G(rt,k) - sum_{j<k} L(rt,j) L(k,j)^T) W_k^T   (a2 + a3 syrk/gemm + trsm + a8)
 // --------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool DIAGNEXT = false>
 __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
@@ -311,7 +511,8 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   int bt, b;
-  tile_fit_of_block(bt, b);
+  if constexpr (DIAGNEXT) tile_fit_of_block_first(bt, b);  // the long-running (k+1, k) workgroups start first
+  else tile_fit_of_block(bt, b);
   const int rt = row_tile_of(bt + p.tile_off, k + 1, p.NT, p.rows_from_extra);
   T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
   const int ld = p.ld;
@@ -381,6 +582,9 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
       v[1] = acc[cb][1][r];
       *reinterpret_cast<vec2 *>(out + (size_t)(cb * DB + P::drow(lane, r)) * ld) = v;
     }
+  if constexpr (DIAGNEXT) {
+    if (rt == k + 1) diag_next<T>(p, acc, smem, Lw, b, k + 1, tid);
+  }
 }
 
 // --------------------------------------------------------------------------------------------------

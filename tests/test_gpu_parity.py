@@ -210,6 +210,34 @@ def test_classic_schedule_still_matches(engine, monkeypatch):
     check_fit_predict(engine, kid, th[0], X[0], y[0], Xs[0], engine.F64, TOL64)
 
 
+@pytest.mark.parametrize("sched", ["classic", "overlap", "fuseddiag"])
+def test_alternate_schedules_match_oracle(sched):
+    """The schedules kept behind CGP_SCHED for A/B measurements (read once per process, hence the child
+    process): three launches per step, two-stream look-ahead, next diagonal tile fused into the panel
+    launch.  Same parity bar as the default schedule, multi-tile fp64 and fp32 problems."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from corenav_gp_amd import engine, synth\n"
+        "from oracle import gp_oracle as go\n"
+        "for dtype, tol, N in ((engine.F64, 1e-6, 700), (engine.F32, 1e-3, 300)):\n"
+        "    kid, X, y, Xs, th, _ = synth.config(2, N=N)\n"
+        "    ctx = engine.Context(max_n=N, max_m=Xs.shape[1], max_d=X.shape[2], max_batch=2, dtype=dtype)\n"
+        "    Xb, yb, Xsb, thb = (np.repeat(a[:1], 2, 0) for a in (X, y, Xs, th))\n"
+        "    rc, mean, var, logml, info = ctx.fit_predict_batch(Xb, yb, Xsb, thb, kid)\n"
+        "    assert rc == 0 and not info.any(), (rc, info)\n"
+        "    f = go.fit(kid, th[0], X[0], y[0]); mu, v = go.predict(f, Xs[0])\n"
+        "    assert np.abs(mean - mu).max() < tol * np.abs(mu).max(), np.abs(mean - mu).max()\n"
+        "    assert (np.abs(var - v) / np.abs(v)).max() < tol\n"
+        "    assert abs(logml[0] - f.logml) <= tol * abs(f.logml) and logml[0] == logml[1]\n"
+        "print('ok')\n" % root)
+    env = dict(os.environ, CGP_SCHED=sched)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_brownian_sign_structure(engine):
     """GPy Brownian.K is zero between inputs of opposite sign and min(|x|,|x'|) otherwise: a window that
     straddles zero gives a block-diagonal K (never the case on the rover, where ticks are positive,
