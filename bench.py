@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="independent fits per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="independent fits per GPU per step (2 per CU)")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3])
     ap.add_argument("--n", type=int, default=None, help="override window length N")
     ap.add_argument("--cpu-sample", type=int, default=12, help="fits timed on the host for cpu_baseline")
@@ -174,13 +174,14 @@ def pmc_traffic(B, N, dts):
     FETCH_SIZE and WRITE_SIZE in separate --pmc runs, FETCH doubled for the gfx950 half-count).  Only valid
     for the configuration the profile was taken on (default workload); otherwise null."""
     import glob
-    if (B, N, dts) != (256, 2048, "f64"):
-        return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
         return None
     try:
         d = json.load(open(files[-1]))
+        w = d.get("_workload", {"batch": 256, "N": 2048, "dtype": "f64"})
+        if (B, N, dts) != (w["batch"], w["N"], w["dtype"]):
+            return None
         return d.get("k_panel", d.get("k_update"))["hbm_bytes_per_launch"]
     except Exception:
         return None

@@ -134,6 +134,7 @@ template <typename T> int set_lds_attrs() {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, paneldiag_lds_bytes<T>()) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag_lean<T>), hipFuncAttributeMaxDynamicSharedMemorySize, paneldiag_lds_bytes<T>()) != hipSuccess) return -1;
   done = true;
   return 0;
 }
@@ -222,6 +223,10 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     for (int g = 0; g < G; ++g) HIP_TRY(c, hipMemsetAsync(ga[g].info, 0, sizeof(int) * gb[g], gs[g]));
   static const bool classic = [] { const char *e = getenv("CGP_SCHED"); return e && std::string(e) == "classic"; }();
   static const bool split = [] { const char *e = getenv("CGP_SCHED"); return !(e && std::string(e) == "fuseddiag"); }();
+  static const int diag_env = [] { const char *e = getenv("CGP_DIAG"); return !e ? 0 : (std::string(e) == "lean" ? 1 : 2); }();
+  // default: k_diag_lean (two diagonal workgroups per CU: with >= 2 fits per CU one's factorisation
+  // latency runs under the other's MFMA loop; 3.8 vs 5.1 ms per 512 fits).  CGP_DIAG=fat: k_diag.
+  const bool lean_diag = diag_env != 2;
   static const bool overlap = [] { const char *e = getenv("CGP_SCHED"); return e && std::string(e) == "overlap"; }();
   if (overlap && in_rows && G == 1 && !c->prof && a.NT >= 2) {
     // Look-ahead schedule on two streams: the panel launch of step k is cut into P1 = the tile right
@@ -289,7 +294,8 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
         const bool fuse_next = !split && in_rows && k + 1 < a.NT;
         if (in_rows && (split || k == 0)) {
           L[g].begin(1, diag_flops(a.N, a.d, k, gb[g]));
-          hipLaunchKernelGGL(k_diag<T>, dim3(gb[g]), dim3(256), tile_lds, gs[g], ga[g], k);
+          if (lean_diag) hipLaunchKernelGGL(k_diag_lean<T>, dim3(gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ga[g], k);
+          else hipLaunchKernelGGL(k_diag<T>, dim3(gb[g]), dim3(256), tile_lds, gs[g], ga[g], k);
           L[g].end();
         }
         L[g].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, gb[g]) + (fuse_next ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0));

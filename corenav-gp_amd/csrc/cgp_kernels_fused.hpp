@@ -125,11 +125,11 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
 //   acc[cb][j][reg] = C[row = rb_j*16 + (lane&15)][col = cb*16 + drow(lane, reg)],  rb_0 = w, rb_1 = 7-w,
 // defined for cb <= rb_j only.
 // --------------------------------------------------------------------------------------------------
-// LDS ring of the triangular loop: buffers 0 and 1 in front of the Gram staging area (which occupies
-// [2, 4) * KT * LDST elements), the others behind it; the first TRI_PD chunks are in flight while the
-// Gram tile is built.
+// LDS ring of the triangular loop: three chunk buffers; chunks 0 and 1 are in flight while the Gram
+// tile is built.  The Gram staging area starts at 2 * KT * LDST elements, i.e. on buffer 2, which is
+// first written in iteration 0 after the barrier every wave reaches only when its Gram tile is done.
 constexpr int TRI_PD = 2;  // chunks in flight ahead of the one being multiplied
-__device__ __forceinline__ constexpr int tri_buf(int i) { return (i < 2 ? i : i + 2) * KT * LDST; }
+__device__ __forceinline__ constexpr int tri_buf(int i) { return i * KT * LDST; }
 
 template <typename T>
 __device__ __forceinline__ void stage_chunk_tri(const T *gR, size_t ldR, int chunk, T *buf, int tid) {
@@ -173,9 +173,8 @@ __device__ __forceinline__ void syrk_tri_wave(typename Prec<T>::acc_t (&acc)[NCB
   // prefetch distance TRI_PD over a ring of TRI_PD + 1: one workgroup per CU, so nothing else hides the HBM latency
   static_assert(sizeof(T) == 8, "LDS-DMA staging: fp64 only");
   for (int c = 0; c < nchunk; ++c) {
-    const int younger = nchunk - 1 - c;  // chunks issued after chunk c and possibly still in flight (4 loads each)
-    if (younger >= TRI_PD - 1 && TRI_PD == 3) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    else if (younger >= 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    // chunk c has landed when at most the 4 loads of chunk c + 1 are still in flight
+    if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (c + TRI_PD < nchunk) stage_chunk_tri<T>(gR, ldR, c + TRI_PD, smem + tri_buf((c + TRI_PD) % (TRI_PD + 1)), tid);
     compute(smem + tri_buf(c % (TRI_PD + 1)));
@@ -532,9 +531,10 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
   }
 }
 
-// acc = -S(kn, kn) on entry state "free": Gram + update of the diagonal tile kn, then the packed
-// factorisation.  Called by the whole workgroup that has just stored tile (kn, kn - 1).
-template <typename T>
+// Gram + update of the diagonal tile kn, then the packed factorisation, in <= 78 KB of LDS.
+// FUSED: called by the workgroup that has just stored tile (kn, kn - 1) inside the panel launch.
+// TRI (fp64): triangular update loop, see mfma_syrk_tri_loop.
+template <typename T, bool FUSED, bool TRI>
 __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
                                           T *__restrict__ Lw, int b, int kn, int tid) {
   using P = Prec<T>;
@@ -544,34 +544,54 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15;
   constexpr int CH2 = 2 * KT * LDST;
-  // tile (kn, kn-1), written by this workgroup a moment ago, is the last chunk of the row panel
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if constexpr (FUSED) {
+    // tile (kn, kn-1), written by this workgroup a moment ago, is the last chunk of the row panel
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   const T *gR = Lw + (size_t)kn * TS;
   const int nchunk = (kn * TS) / KT;
   {
     GramPre<T> gp;
     gram_prefetch<T>(p, b, kn, kn, tid, gp);
-    stage_first_chunk<T>(gR, (size_t)ld, gR, (size_t)ld, smem, tid);
-    gram_apply<T>(p, acc, smem + CH2, b, kn, kn, tid, gp);
+    if constexpr (TRI) {
+      if (nchunk > 0) stage_chunk_tri<T>(gR, (size_t)ld, 0, smem + tri_buf(0), tid);
+      if (nchunk > 1) stage_chunk_tri<T>(gR, (size_t)ld, 1, smem + tri_buf(1), tid);
+    } else if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gR, (size_t)ld, smem, tid);
+    gram_apply<T, TRI>(p, acc, smem + CH2, b, kn, kn, tid, gp);
   }
-  mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gR, (size_t)ld, nchunk, smem, tid);
+  if constexpr (TRI) mfma_syrk_tri_loop<T>(acc, gR, (size_t)ld, nchunk, smem, tid);
+  else mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gR, (size_t)ld, nchunk, smem, tid);
   __syncthreads();
   T *tile = Lw + (size_t)(kn * TS) * ld + (size_t)kn * TS;
-  // S = -acc -> the 36 lower blocks; rows 32 wave + 2 l15 + {0, 1} live in block row 2 wave + (l15 >> 3)
-  const int rb = 2 * wave + (l15 >> 3), rin = (2 * l15) & 15;
+  // S = -acc -> the 36 lower blocks
+  if constexpr (TRI) {
 #pragma unroll
-  for (int cb = 0; cb < NCB; ++cb)
-    if (cb <= rb) {
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        vec2 v;
-        v[0] = -acc[cb][0][r];
-        v[1] = -acc[cb][1][r];
-        *reinterpret_cast<vec2 *>(smem + tri_blk(rb, cb) + P::drow(lane, r) * DB + rin) = v;
+      for (int j = 0; j < 2; ++j) {
+        const int rb = j ? NCB - 1 - wave : wave;
+        if (cb <= rb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) smem[tri_blk(rb, cb) + P::drow(lane, r) * DB + l15] = -acc[cb][j][r];
+        }
       }
-    }
+  } else {
+    // rows 32 wave + 2 l15 + {0, 1} live in block row 2 wave + (l15 >> 3)
+    const int rb = 2 * wave + (l15 >> 3), rin = (2 * l15) & 15;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+      if (cb <= rb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vec2 v;
+          v[0] = -acc[cb][0][r];
+          v[1] = -acc[cb][1][r];
+          *reinterpret_cast<vec2 *>(smem + tri_blk(rb, cb) + P::drow(lane, r) * DB + rin) = v;
+        }
+      }
+  }
   // the strictly upper blocks of the tile in HBM are zero
   for (int idx = tid; idx < 28 * DB * DB; idx += 256) {
     const int blk = idx >> 8, e = idx & 255;
@@ -585,6 +605,18 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
   __syncthreads();
   T *Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)kn * TS * TS;
   diag_factor_packed<T>(p, smem, tile, ld, Wk, b, kn, tid);
+}
+
+// k_diag_lean: the diagonal tile in the LDS budget of a panel workgroup (two per CU), so that with
+// two or more fits per CU one workgroup's factorisation latency runs under the other's MFMA loop.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_diag_lean(FitArgs p, int k) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  const int b = blockIdx.x;
+  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+  typename Prec<T>::acc_t acc[NCB][2];
+  diag_next<T, false, sizeof(T) == 8>(p, acc, smem, Lw, b, k, threadIdx.x);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -670,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
       *reinterpret_cast<vec2 *>(out + (size_t)(cb * DB + P::drow(lane, r)) * ld) = v;
     }
   if constexpr (DIAGNEXT) {
-    if (rt == k + 1) diag_next<T>(p, acc, smem, Lw, b, k + 1, tid);
+    if (rt == k + 1) diag_next<T, true, false>(p, acc, smem, Lw, b, k + 1, tid);
   }
 }
 
@@ -705,7 +737,6 @@ __global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
     if constexpr (TRI) {
       if (nchunk > 0) stage_chunk_tri<T>(gR, (size_t)ld, 0, smem + tri_buf(0), tid);
       if (nchunk > 1) stage_chunk_tri<T>(gR, (size_t)ld, 1, smem + tri_buf(1), tid);
-      if (nchunk > 2 && TRI_PD == 3) stage_chunk_tri<T>(gR, (size_t)ld, 2, smem + tri_buf(2), tid);
     } else if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gR, (size_t)ld, smem, tid);
     gram_apply<T, TRI>(p, acc, smem + CH2, b, k, k, tid, gp);
   }

@@ -210,11 +210,13 @@ def test_classic_schedule_still_matches(engine, monkeypatch):
     check_fit_predict(engine, kid, th[0], X[0], y[0], Xs[0], engine.F64, TOL64)
 
 
-@pytest.mark.parametrize("sched", ["classic", "overlap", "fuseddiag"])
-def test_alternate_schedules_match_oracle(sched):
-    """The schedules kept behind CGP_SCHED for A/B measurements (read once per process, hence the child
-    process): three launches per step, two-stream look-ahead, next diagonal tile fused into the panel
-    launch.  Same parity bar as the default schedule, multi-tile fp64 and fp32 problems."""
+@pytest.mark.parametrize("var,val", [("CGP_SCHED", "classic"), ("CGP_SCHED", "overlap"), ("CGP_SCHED", "fuseddiag"),
+                                     ("CGP_DIAG", "fat")])
+def test_alternate_schedules_match_oracle(var, val):
+    """The schedules kept behind CGP_SCHED / CGP_DIAG for A/B measurements (read once per process, hence
+    the child process): three launches per step, two-stream look-ahead, next diagonal tile fused into
+    the panel launch, the 157 KB one-per-CU diagonal kernel.  Same parity bar as the default schedule,
+    multi-tile fp64 and fp32 problems."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
@@ -233,7 +235,7 @@ def test_alternate_schedules_match_oracle(sched):
         "    assert (np.abs(var - v) / np.abs(v)).max() < tol\n"
         "    assert abs(logml[0] - f.logml) <= tol * abs(f.logml) and logml[0] == logml[1]\n"
         "print('ok')\n" % root)
-    env = dict(os.environ, CGP_SCHED=sched)
+    env = dict(os.environ, **{var: val})
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 

@@ -10,6 +10,7 @@ import shutil
 import sys
 
 tag, rnd = sys.argv[1], sys.argv[2]          # e.g. r1 r01
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 512   # fits per step of the profiled bench command
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -47,5 +48,6 @@ for k, v in agg.items():
     if "TCC_HIT_sum" in v:
         e["L2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
     out[k] = e
+out["_workload"] = {"batch": batch, "N": 2048, "dtype": "f64", "command": "python3 bench.py --no-cpu"}
 json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
