@@ -118,6 +118,114 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
 }
 
 // --------------------------------------------------------------------------------------------------
+// fp64 panel loop with the row panel kept out of LDS.  A wave's B operand is its own 32 rows of the
+// row panel and nobody else reads them, so they are loaded straight into registers (one 16-byte
+// load per lane and k-step: rows 2 l15 + {0,1}, column 4 ks + lq -- 256-byte runs per 16 lanes);
+// only the column panel, which all four waves share, goes through LDS (LDS-DMA, 4 chunk buffers).
+// Both streams run two chunks ahead; the waits are hand-placed (`s_waitcnt vmcnt(8)`: everything but
+// the 4 + 4 loads of chunk c + 1 has landed) because a __syncthreads() would drain the queue.
+//   prologue (before the Gram phase):  C(0) R(0) C(1) R(1)
+//   iteration c: wait, barrier, issue C(c+2) R(c+2), multiply chunk c.
+// nchunk is a multiple of 4 (k * 128 / 16).  The Gram staging area (smem + 2 chunk buffers) is
+// buffer 2 / 3, first written after the barrier of iteration 0, i.e. after every wave's Gram phase.
+// --------------------------------------------------------------------------------------------------
+struct RowFrag {
+  using vec2 = double __attribute__((ext_vector_type(2)));
+  vec2 r[4][KT / 4];
+};
+
+template <int SLOT>
+__device__ __forceinline__ void rfrag_load(RowFrag &f, const double *gRl, size_t ldR, int chunk, int lq) {
+  // Issued as raw instructions: with an LDS-DMA load in flight the compiler's waitcnt pass treats
+  // every later use of a loaded register as "flat pending" and inserts vmcnt(0), which would wait
+  // for the whole prefetch queue.  The hand-placed vmcnt waits in rdirect_step cover these loads.
+#pragma unroll
+  for (int ks = 0; ks < KT / 4; ++ks) {
+    const double *src = gRl + (size_t)(chunk * KT + ks * 4 + lq) * ldR;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(f.r[SLOT][ks]) : "v"(src));
+  }
+}
+
+__device__ __forceinline__ void cpanel_stage(const double *gC, size_t ldC, int chunk, double *buf, int lane, int wave) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
+#pragma unroll
+  for (int i = 0; i < KT / 4; ++i) {
+    const int col = wave * (KT / 4) + i;
+    __builtin_amdgcn_global_load_lds((gbl_void *)(gC + (size_t)(chunk * KT + col) * ldC + lane * 2),
+                                     (lds_void *)(buf + col * LDST), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void rdirect_prologue(RowFrag &f, const double *gR, size_t ldR, const double *gC, size_t ldC,
+                                                 int nchunk, double *smem, int tid) {
+  constexpr int CH = KT * LDST;
+  if (nchunk <= 0) return;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double *gRl = gR + wave * 32 + 2 * (lane & 15);
+  cpanel_stage(gC, ldC, 0, smem, lane, wave);
+  rfrag_load<0>(f, gRl, ldR, 0, lane >> 4);
+  cpanel_stage(gC, ldC, 1, smem + CH, lane, wave);
+  rfrag_load<1>(f, gRl, ldR, 1, lane >> 4);
+}
+
+// ISSUE / LAST are compile-time so that no data-dependent branch sits between a load and its use:
+// the compiler's own s_waitcnt insertion then counts the loads in flight exactly (with a branch it
+// falls back to vmcnt(0) at the first use of the row fragments, which serialises the pipeline).
+template <int S, bool ISSUE, bool LAST>
+__device__ __forceinline__ void rdirect_step(Prec<double>::acc_t (&acc)[NCB][2], RowFrag &f, const double *gRl, size_t ldR,
+                                             const double *gC, size_t ldC, int c, double *smem, int lane, int wave) {
+  using P = Prec<double>;
+  constexpr int CH = KT * LDST;
+  const int l15 = lane & 15, lq = lane >> 4;
+  if constexpr (LAST) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  if constexpr (ISSUE) {
+    cpanel_stage(gC, ldC, c + 2, smem + ((S + 2) & 3) * CH, lane, wave);
+    rfrag_load<(S + 2) & 3>(f, gRl, ldR, c + 2, lq);
+  }
+  // column fragments one k-step ahead of the MFMAs that consume them (two register sets)
+  const double *cur = smem + S * CH + lq * LDST + l15;
+  double fa[2][NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) fa[0][cb] = cur[cb * DB];
+#pragma unroll
+  for (int ks = 0; ks < KT / 4; ++ks) {
+    if (ks + 1 < KT / 4) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) fa[(ks + 1) & 1][cb] = cur[(ks + 1) * 4 * LDST + cb * DB];
+    }
+    const RowFrag::vec2 fb = f.r[S][ks];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      acc[cb][0] = P::mfma(fa[ks & 1][cb], fb[0], acc[cb][0]);
+      acc[cb][1] = P::mfma(fa[ks & 1][cb], fb[1], acc[cb][1]);
+    }
+  }
+}
+
+__device__ __forceinline__ void mfma_rowpanel_loop_rdirect(Prec<double>::acc_t (&acc)[NCB][2], RowFrag &f, const double *gR,
+                                                           size_t ldR, const double *gC, size_t ldC, int nchunk,
+                                                           double *smem, int tid) {
+  if (nchunk <= 0) return;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double *gRl = gR + wave * 32 + 2 * (lane & 15);
+  int c = 0;
+  for (; c + 4 < nchunk; c += 4) {
+    rdirect_step<0, true, false>(acc, f, gRl, ldR, gC, ldC, c, smem, lane, wave);
+    rdirect_step<1, true, false>(acc, f, gRl, ldR, gC, ldC, c + 1, smem, lane, wave);
+    rdirect_step<2, true, false>(acc, f, gRl, ldR, gC, ldC, c + 2, smem, lane, wave);
+    rdirect_step<3, true, false>(acc, f, gRl, ldR, gC, ldC, c + 3, smem, lane, wave);
+  }
+  rdirect_step<0, true, false>(acc, f, gRl, ldR, gC, ldC, c, smem, lane, wave);
+  rdirect_step<1, true, false>(acc, f, gRl, ldR, gC, ldC, c + 1, smem, lane, wave);
+  rdirect_step<2, false, false>(acc, f, gRl, ldR, gC, ldC, c + 2, smem, lane, wave);
+  rdirect_step<3, false, true>(acc, f, gRl, ldR, gC, ldC, c + 3, smem, lane, wave);
+}
+
+// --------------------------------------------------------------------------------------------------
 // Diagonal-tile update: C(kk) -= sum_j L(k,j) L(k,j)^T is symmetric and only its lower 16x16 blocks
 // are factored, so the row panel is staged ONCE per chunk (it is both operands) and wave w owns the
 // 16-row blocks w and 7 - w: block row rb needs column blocks 0..rb, i.e. (w + 1) + (8 - w) = 9
@@ -622,6 +730,8 @@ __global__ __launch_bounds__(256, 2) void k_diag_lean(FitArgs p, int k) {
 // --------------------------------------------------------------------------------------------------
 // k_panel: L(rt, k) = (G(rt,k) - sum_{j<k} L(rt,j) L(k,j)^T) W_k^T   (a2 + a3 syrk/gemm + trsm + a8)
 // --------------------------------------------------------------------------------------------------
+constexpr bool RDIRECT = true;  // fp64 k_panel: row panel straight to registers (mfma_rowpanel_loop_rdirect)
+
 template <typename T, bool DIAGNEXT = false>
 __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
   using P = Prec<T>;
@@ -645,13 +755,24 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
   acc_t acc[NCB][2];
   const T *gR = Lw + (size_t)rt * TS, *gC = Lw + (size_t)k * TS;
   const int nchunk = (k * TS) / KT;
-  {
-    GramPre<T> gp;
-    gram_prefetch<T>(p, b, k, rt, tid, gp);
-    if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
-    gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
+  if constexpr (sizeof(T) == 8 && RDIRECT) {
+    RowFrag rf;
+    {
+      GramPre<T> gp;
+      gram_prefetch<T>(p, b, k, rt, tid, gp);
+      rdirect_prologue(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+      gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
+    }
+    mfma_rowpanel_loop_rdirect(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+  } else {
+    {
+      GramPre<T> gp;
+      gram_prefetch<T>(p, b, k, rt, tid, gp);
+      if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
+      gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
+    }
+    mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
   }
-  mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
   __syncthreads();  // every wave is done with the staged inputs before W_k overwrites them
   if (!(p.dbg & 64)) {
 
