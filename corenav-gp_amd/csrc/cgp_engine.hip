@@ -242,7 +242,8 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     a1.tile_off = 0;
     a2.tile_off = 1;
     const int B = gb[0], NT = a.NT;
-    hipLaunchKernelGGL(k_diag<T>, dim3(B), dim3(256), tile_lds, sA, ga[0], 0);
+    if (lean_diag) hipLaunchKernelGGL(k_diag_lean<T>, dim3(B), dim3(256), paneldiag_lds_bytes<T>(), sA, ga[0], 0);
+    else hipLaunchKernelGGL(k_diag<T>, dim3(B), dim3(256), tile_lds, sA, ga[0], 0);
     HIP_TRY(c, hipEventRecord(ev(0), sA));                         // evD[0]
     for (int k = 0; k < NT; ++k) {
       const int nin = NT - k - 1;                                  // in-matrix tiles below the diagonal
@@ -260,7 +261,8 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       HIP_TRY(c, hipEventRecord(ev(3 * k + 2), sB));               // evP2[k]
       if (k + 1 < NT) {
         if (!has_p1 && k > 0) HIP_TRY(c, hipStreamWaitEvent(sA, ev(3 * (k - 1) + 2), 0));
-        hipLaunchKernelGGL(k_diag<T>, dim3(B), dim3(256), tile_lds, sA, ga[0], k + 1);
+        if (lean_diag) hipLaunchKernelGGL(k_diag_lean<T>, dim3(B), dim3(256), paneldiag_lds_bytes<T>(), sA, ga[0], k + 1);
+        else hipLaunchKernelGGL(k_diag<T>, dim3(B), dim3(256), tile_lds, sA, ga[0], k + 1);
         HIP_TRY(c, hipEventRecord(ev(3 * (k + 1)), sA));           // evD[k+1]
       }
     }
