@@ -126,6 +126,22 @@ def main():
     if not os.environ.get("CGP_DBG"):   # timing ablations produce wrong factors on purpose
         assert int(dinfo.abs().sum().item()) == 0, "a fit reported a non-positive pivot"
 
+    # latency of ONE fit of the same shape (BASELINE configs[1] reads "single GP fit"): the engine
+    # switches to its split-K latency schedule for <= 4 fits; synchronised per call
+    def one():
+        ctx.fit_predict_batch_device(1, N, d, M_TEST, kid, dX.data_ptr(), dy.data_ptr(), dXs.data_ptr(),
+                                     dth.data_ptr(), 0, True, dmean.data_ptr(), dvar.data_ptr(), dlogml.data_ptr(),
+                                     dinfo.data_ptr(), stream)
+        torch.cuda.synchronize()
+    keep = (dmean[0].clone(), dvar[0].clone(), dlogml[0].clone())
+    for _ in range(3):
+        one()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        one()
+    single_ms = (time.perf_counter() - t1) / 10 * 1e3
+    dmean[0], dvar[0], dlogml[0] = keep      # the batch outputs are what the summaries / oracle check read
+
     # per-fit summaries gathered over RCCL (the only collective on the path: SURVEY.md 8e)
     summ = torch.stack([dlogml, 2.0 * dvar.to(torch.float64).max(1).values.sqrt(), dinfo.to(torch.float64)], 1)
     table = sharding.gather_summaries(summ.to(cdev), B * world)
@@ -153,6 +169,7 @@ def main():
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: batch of independent fixed-theta GP fits, "
                                    f"N={N} d={d} M={M_TEST} kernel={'SE-ARD' if kid == 1 else 'SE-iso'} {dts}",
                        "fits_per_gpu_per_step": B, "streams": args.streams, "N": N, "d": d, "M": M_TEST,
+                       "single_fit_latency_ms": single_ms,
                        "fit_tflops": value * f_fit / 1e12, "cholesky_roofline_frac": value * f_chol / 1e12 / world / peak,
                        "inputs": "resident in HBM", "ensemble": ens},
             "roofline": {"bound": "mfma", "kernel": "k_panel (syrk/gemm trailing update + fused Gram + in-register trmm)",

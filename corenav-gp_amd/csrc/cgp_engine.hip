@@ -53,6 +53,9 @@ struct cgp_ctx {
   double *dtheta = nullptr, *djitter = nullptr, *dlogml = nullptr, *dprep = nullptr;
   long long *ddbg = nullptr;
   double *dgpart = nullptr;
+  void *dpart = nullptr;   // latency schedule: partial tiles [LAT_FITS][slots][SK_MAX][128*128]
+  int *dticket = nullptr;  //                   arrival tickets [LAT_FITS][slots]
+  int sk_slots = 0;
   // sliding windows (cgp_window_*)
   WindowArgs win{};
   int nwin = 0;
@@ -117,6 +120,8 @@ struct Launcher {
   }
 };
 
+constexpr int LAT_FITS = 4;  // batches up to this size take the latency schedule
+
 template <typename T> constexpr int upd_lds_bytes() { return 4 * KT * LDST * (int)sizeof(T); }
 template <typename T> constexpr int paneldiag_lds_bytes() { return std::max(upd_lds_bytes<T>(), diag_lds_elems<T>() * (int)sizeof(T)); }
 template <typename T> constexpr int potf2_lds_bytes() {
@@ -134,6 +139,8 @@ template <typename T> int set_lds_attrs() {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, paneldiag_lds_bytes<T>()) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sk<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trmm_sk<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag_lean<T>), hipFuncAttributeMaxDynamicSharedMemorySize, paneldiag_lds_bytes<T>()) != hipSuccess) return -1;
   done = true;
   return 0;
@@ -203,6 +210,9 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   const int tile_lds = potf2_lds_bytes<T>();
   int G = std::max(1, std::min(std::min(c->nstreams, (int)cgp_ctx::kMaxStreams), batch));
   if (c->prof || !in_rows) G = 1;  // per-kernel timing wants isolated launches
+  static const bool no_latency = [] { const char *e = getenv("CGP_SCHED"); return e && (std::string(e) == "throughput" || std::string(e) == "classic" || std::string(e) == "overlap" || std::string(e) == "fuseddiag"); }();
+  const bool latency = !no_latency && batch <= LAT_FITS && a.NT >= 3;
+  if (latency) G = 1;
   std::vector<FitArgs> ga(G);
   std::vector<int> gb(G);
   std::vector<hipStream_t> gs(G);
@@ -272,6 +282,35 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_join[0], sA));
     HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[0], 0));
+    return CGP_OK;
+  }
+  // Latency schedule for a handful of fits (k_tile_sk): the diagonal tile and
+  // the panel tiles of a step in one launch, inner dimension split over up to SK_MAX workgroups.
+  if (latency) {
+    SplitArgs q{c->dpart, c->dticket, c->sk_slots, 1, in_rows ? 1 : 0};
+    for (int k = 0; k < a.NT; ++k) {
+      const int tiles = (in_rows ? a.NT - k - 1 : 0) + a.ET;
+      const int nslots = tiles + (in_rows ? 1 : 0);
+      // >= 8 chunks of 16 columns per range; a function of k only, so a fit's result does not
+      // depend on how many fits share the call (the partial sums are added in range order)
+      const int sk = std::max(1, std::min(SK_MAX, k));
+      q.sk = sk;
+      L[0].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, batch) + (in_rows ? diag_flops(a.N, a.d, k, batch) : 0.0));
+      hipLaunchKernelGGL(k_tile_sk<T>, dim3(nslots, batch, sk), dim3(256), in_rows ? tile_lds : upd_lds, s, ga[0], q, k);
+      L[0].end();
+      L[0].begin(2, trsm_flops(a.N, a.M, k, in_rows, batch));
+      hipLaunchKernelGGL(k_trmm_sk<T>, dim3(tiles, batch), dim3(256), upd_lds, s, ga[0], k);
+      L[0].end();
+    }
+    L[0].begin(3, batch * (4.0 * a.M * a.N + 2.0 * a.N));
+    hipLaunchKernelGGL(k_finalize<T>, dim3(cdiv(a.M, 64) + 1, batch), dim3(256), 0, s, ga[0], in_rows ? 1 : 0);
+    L[0].end();
+    if (want_alpha) {
+      L[0].begin(4, batch * (double)a.N * a.N);
+      hipLaunchKernelGGL(k_alpha<T>, dim3(batch), dim3(256), (a.NT * TS + TS) * sizeof(double), s, ga[0]);
+      L[0].end();
+    }
+    HIP_TRY(c, hipGetLastError());
     return CGP_OK;
   }
   for (int k = 0; k < a.NT; ++k) {
@@ -471,6 +510,10 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc((void **)&c->dtheta, B * CGP_MAX_THETA * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->djitter, B * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dgpart, B * c->NTmax * (c->NTmax + 1) / 2 * GRAD_N * sizeof(double)) == hipSuccess;
+  c->sk_slots = c->NTmax + c->ETmax + 1;
+  ok = ok && hipMalloc(&c->dpart, (size_t)LAT_FITS * c->sk_slots * SK_MAX * TS * TS * c->esz) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->dticket, sizeof(int) * LAT_FITS * c->sk_slots) == hipSuccess;
+  ok = ok && hipMemset(c->dticket, 0, sizeof(int) * LAT_FITS * c->sk_slots) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->ddbg, 64 * sizeof(long long)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dprep, B * PREP_N * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dlogml, B * sizeof(double)) == hipSuccess;
@@ -491,7 +534,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {

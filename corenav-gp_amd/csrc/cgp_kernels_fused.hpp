@@ -730,52 +730,14 @@ __global__ __launch_bounds__(256, 2) void k_diag_lean(FitArgs p, int k) {
 // --------------------------------------------------------------------------------------------------
 // k_panel: L(rt, k) = (G(rt,k) - sum_{j<k} L(rt,j) L(k,j)^T) W_k^T   (a2 + a3 syrk/gemm + trsm + a8)
 // --------------------------------------------------------------------------------------------------
-constexpr bool RDIRECT = true;  // fp64 k_panel: row panel straight to registers (mfma_rowpanel_loop_rdirect)
-
-template <typename T, bool DIAGNEXT = false>
-__global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
+// L(:, k) = S W_k^T on a tile held as acc = -S (layout of mfma_rowpanel_loop), W_k staged in LDS.
+// Every wave must be done with `smem` before the call.
+template <typename T>
+__device__ __forceinline__ void trmm_in_registers(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
+                                                  int b, int k, int tid) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
-  using vec2 = T __attribute__((ext_vector_type(2)));
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T *smem = reinterpret_cast<T *>(smem_raw);
-  int bt, b;
-  if constexpr (DIAGNEXT) tile_fit_of_block_first(bt, b);  // the long-running (k+1, k) workgroups start first
-  else tile_fit_of_block(bt, b);
-  const int rt = row_tile_of(bt + p.tile_off, k + 1, p.NT, p.rows_from_extra);
-  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
-  const int ld = p.ld;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15;
-
-  // Gram first: acc = -G(rt, k) while nothing else is live in the register file, with chunk 0 of the
-  // panels already in flight into LDS buffer 0 (the Gram inputs are staged in buffer 1's space).
-  constexpr int CH2 = 2 * KT * LDST;
-  acc_t acc[NCB][2];
-  const T *gR = Lw + (size_t)rt * TS, *gC = Lw + (size_t)k * TS;
-  const int nchunk = (k * TS) / KT;
-  if constexpr (sizeof(T) == 8 && RDIRECT) {
-    RowFrag rf;
-    {
-      GramPre<T> gp;
-      gram_prefetch<T>(p, b, k, rt, tid, gp);
-      rdirect_prologue(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
-      gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
-    }
-    mfma_rowpanel_loop_rdirect(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
-  } else {
-    {
-      GramPre<T> gp;
-      gram_prefetch<T>(p, b, k, rt, tid, gp);
-      if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
-      gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
-    }
-    mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
-  }
-  __syncthreads();  // every wave is done with the staged inputs before W_k overwrites them
-  if (!(p.dbg & 64)) {
-
+  const int lane = tid & 63, l15 = lane & 15;
   // W_k (lower triangular) -> LDS as 36 blocks of 16x16: Wl[blk(cb,qb)][q][c] = W[cb*16 + c][qb*16 + q]
   const T *__restrict__ Wk = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * TS * TS;
   {
@@ -810,9 +772,16 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
     acc[cb][1] = t1;
     __builtin_amdgcn_sched_barrier(0);  // one column block at a time: bounds the live W fragments
   }
-  }
+}
 
-  T *__restrict__ out = Lw + (size_t)(k * TS) * ld + (size_t)rt * TS + wave * 32 + 2 * l15;
+// acc (rows 32 wave + 2 l15 + {0,1}, columns cb*16 + drow) <-> a column-major 128 x 128 tile, 16-byte accesses
+template <typename T>
+__device__ __forceinline__ void store_tile(const typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ tile, int ld, int tid) {
+  using P = Prec<T>;
+  using vec2 = T __attribute__((ext_vector_type(2)));
+  const int lane = tid & 63, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  T *__restrict__ out = tile + wave * 32 + 2 * l15;
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -822,6 +791,67 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
       v[1] = acc[cb][1][r];
       *reinterpret_cast<vec2 *>(out + (size_t)(cb * DB + P::drow(lane, r)) * ld) = v;
     }
+}
+template <typename T, bool ADD>
+__device__ __forceinline__ void load_tile(typename Prec<T>::acc_t (&acc)[NCB][2], const T *tile, int ld, int tid) {
+  using P = Prec<T>;
+  using vec2 = T __attribute__((ext_vector_type(2)));
+  const int lane = tid & 63, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const T *src = tile + wave * 32 + 2 * l15;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const vec2 v = *reinterpret_cast<const vec2 *>(src + (size_t)(cb * DB + P::drow(lane, r)) * ld);
+      acc[cb][0][r] = ADD ? acc[cb][0][r] + v[0] : v[0];
+      acc[cb][1][r] = ADD ? acc[cb][1][r] + v[1] : v[1];
+    }
+}
+
+constexpr bool RDIRECT = true;  // fp64 k_panel: row panel straight to registers (mfma_rowpanel_loop_rdirect)
+
+template <typename T, bool DIAGNEXT = false>
+__global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  int bt, b;
+  if constexpr (DIAGNEXT) tile_fit_of_block_first(bt, b);  // the long-running (k+1, k) workgroups start first
+  else tile_fit_of_block(bt, b);
+  const int rt = row_tile_of(bt + p.tile_off, k + 1, p.NT, p.rows_from_extra);
+  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const int ld = p.ld;
+  const int tid = threadIdx.x;
+
+  // Gram first: acc = -G(rt, k) while nothing else is live in the register file, with chunk 0 of the
+  // panels already in flight into LDS buffer 0 (the Gram inputs are staged in buffer 1's space).
+  constexpr int CH2 = 2 * KT * LDST;
+  acc_t acc[NCB][2];
+  const T *gR = Lw + (size_t)rt * TS, *gC = Lw + (size_t)k * TS;
+  const int nchunk = (k * TS) / KT;
+  if constexpr (sizeof(T) == 8 && RDIRECT) {
+    RowFrag rf;
+    {
+      GramPre<T> gp;
+      gram_prefetch<T>(p, b, k, rt, tid, gp);
+      rdirect_prologue(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+      gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
+    }
+    mfma_rowpanel_loop_rdirect(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+  } else {
+    {
+      GramPre<T> gp;
+      gram_prefetch<T>(p, b, k, rt, tid, gp);
+      if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
+      gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
+    }
+    mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+  }
+  __syncthreads();  // every wave is done with the staged inputs before W_k overwrites them
+  if (!(p.dbg & 64)) trmm_in_registers<T>(p, acc, smem, b, k, tid);
+  store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
   if constexpr (DIAGNEXT) {
     if (rt == k + 1) diag_next<T, true, false>(p, acc, smem, Lw, b, k + 1, tid);
   }
@@ -899,6 +929,117 @@ __global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
   potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, (p.dbg & 512) ? p.dbgbuf : nullptr);
   potf2_store<T>(p, At, Dv, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
   if ((p.dbg & 512) && tid == 0 && b == 0) { p.dbgbuf[5] = __builtin_amdgcn_s_memtime() - tq; p.dbgbuf[6] = tq - tstart; }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Latency schedule (a handful of fits: the throughput schedule would leave most CUs idle and walk
+// every tile's inner dimension in one workgroup).  Per block step two launches:
+//   k_tile_sk(k) : grid (1 + tiles, fits, SK).  Tile slot 0 is the diagonal tile, the others the
+//                  panel / extra tiles of step k; the inner dimension (128 k columns) is cut into SK
+//                  ranges, one workgroup each.  Range 0 starts from -G (Gram first), the others from
+//                  0.  Partial tiles go to a scratch slab; the workgroup that arrives last (atomic
+//                  ticket) adds them in fixed order 0..SK-1 -- results do not depend on arrival
+//                  order -- and finishes the tile: the diagonal tile is factored and inverted in
+//                  LDS (potf2_lds_body), the others are stored as -S into their slot of the panel.
+//                  The diagonal update and the panel updates of a step thus run side by side.
+//   k_trmm_sk(k) : L(i,k) = S(i,k) W_k^T in registers, as the tail of k_panel.
+// --------------------------------------------------------------------------------------------------
+struct SplitArgs {
+  void *part;       // [fits][slots][SK_MAX][128*128] partial tiles
+  int *ticket;      // [fits][slots], zero between launches (the finishing workgroup resets it)
+  int slots;        // tile slots per fit in `part` / `ticket`
+  int sk;           // ranges the inner dimension is cut into (1..SK_MAX)
+  int has_diag;     // fit: slot 0 is the diagonal tile; predict-only: extra tiles only
+};
+constexpr int SK_MAX = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
+  using vec2 = T __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  __shared__ int s_last;
+  const int t = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+  const bool diag = q.has_diag && t == 0;
+  const int rt = diag ? k : row_tile_of(t - (q.has_diag ? 1 : 0), k + 1, p.NT, p.rows_from_extra);
+  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const int ld = p.ld;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15;
+  constexpr int CH2 = 2 * KT * LDST;
+
+  acc_t acc[NCB][2];
+  if (sp == 0) {
+    GramPre<T> gp;
+    gram_prefetch<T>(p, b, k, rt, tid, gp);
+    gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = acc_t{0, 0, 0, 0};
+  }
+  const int n = (k * TS) / KT;
+  const int c0 = (int)((long long)sp * n / q.sk), c1 = (int)((long long)(sp + 1) * n / q.sk);
+  const T *gR = Lw + (size_t)rt * TS + (size_t)(c0 * KT) * ld, *gC = Lw + (size_t)k * TS + (size_t)(c0 * KT) * ld;
+  mfma_rowpanel_loop<T, false>(acc, gR, (size_t)ld, gC, (size_t)ld, c1 - c0, smem, tid);
+
+  if (q.sk > 1) {
+    T *slab = reinterpret_cast<T *>(q.part) + ((size_t)(b * q.slots + t) * SK_MAX) * TS * TS;
+    store_tile<T>(acc, slab + (size_t)sp * TS * TS, TS, tid);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      const int old = atomicAdd(q.ticket + b * q.slots + t, 1);
+      s_last = old == q.sk - 1;
+      if (s_last) q.ticket[b * q.slots + t] = 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    load_tile<T, false>(acc, slab, TS, tid);
+    for (int s2 = 1; s2 < q.sk; ++s2) load_tile<T, true>(acc, slab + (size_t)s2 * TS * TS, TS, tid);
+  }
+  __syncthreads();
+
+  if (!diag) {
+    store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
+    return;
+  }
+  T *At = smem;  // element (r, c) at At[c * LDP + r]
+  T *Dv = At + TS * LDP;
+  T *Ts = Dv + 8 * DB * DB;
+  int *flag = reinterpret_cast<int *>(Ts + 4 * DB * DB);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vec2 v;
+      v[0] = -acc[cb][0][r];
+      v[1] = -acc[cb][1][r];
+      *reinterpret_cast<vec2 *>(At + (cb * DB + P::drow(lane, r)) * LDP + wave * 32 + 2 * l15) = v;
+    }
+  if (tid == 0) *flag = 0;
+  __syncthreads();
+  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid);
+  potf2_store<T>(p, At, Dv, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_trmm_sk(FitArgs p, int k) {
+  using acc_t = typename Prec<T>::acc_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  const int b = blockIdx.y;
+  const int rt = row_tile_of(blockIdx.x, k + 1, p.NT, p.rows_from_extra);
+  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+  T *tile = Lw + (size_t)(k * TS) * p.ld + (size_t)rt * TS;
+  acc_t acc[NCB][2];
+  load_tile<T, false>(acc, tile, p.ld, threadIdx.x);
+  trmm_in_registers<T>(p, acc, smem, b, k, threadIdx.x);
+  store_tile<T>(acc, tile, p.ld, threadIdx.x);
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -210,9 +210,31 @@ def test_classic_schedule_still_matches(engine, monkeypatch):
     check_fit_predict(engine, kid, th[0], X[0], y[0], Xs[0], engine.F64, TOL64)
 
 
-@pytest.mark.parametrize("var,val", [("CGP_SCHED", "classic"), ("CGP_SCHED", "overlap"), ("CGP_SCHED", "fuseddiag"),
-                                     ("CGP_DIAG", "fat")])
-def test_alternate_schedules_match_oracle(var, val):
+@pytest.mark.parametrize("dtype_name,N", [("F64", 700), ("F32", 300)])
+def test_throughput_schedule_matches_oracle(engine, dtype_name, N):
+    """Batches above 4 fits take the throughput schedule (k_diag_lean + k_panel, what bench.py times);
+    smaller ones the latency schedule (k_tile_sk / k_trmm_sk).  Same parity bar for both, and a fit's
+    result must not depend on which other fits share the batch (bitwise, within a schedule)."""
+    dtype, tol = getattr(engine, dtype_name), (TOL64 if dtype_name == "F64" else TOL32)
+    kid, X, y, Xs, th, _ = synth.config(2, batch=6, N=N)
+    ctx = engine.Context(max_n=N, max_m=Xs.shape[1], max_d=X.shape[2], max_batch=6, dtype=dtype)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not info.any()
+    for b in range(6):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        assert relmax(mean[b], omu) < tol and releach(var[b], ovar) < tol
+        assert abs(logml[b] - f.logml) <= tol * abs(f.logml)
+    rc, m5, v5, l5, _ = ctx.fit_predict_batch(X[1:], y[1:], Xs[1:], th[1:], kid)       # still throughput (5 fits)
+    assert np.array_equal(m5, mean[1:]) and np.array_equal(v5, var[1:]) and np.array_equal(l5, logml[1:])
+    rc, m2, v2, l2, _ = ctx.fit_predict_batch(X[:2], y[:2], Xs[:2], th[:2], kid)       # latency schedule
+    assert relmax(m2, mean[:2]) < tol and np.max(np.abs(l2 - logml[:2]) / np.abs(logml[:2])) < tol
+
+
+@pytest.mark.parametrize("env", [{"CGP_SCHED": "classic"}, {"CGP_SCHED": "overlap"}, {"CGP_SCHED": "fuseddiag"},
+                                 {"CGP_SCHED": "throughput"}, {"CGP_SCHED": "throughput", "CGP_DIAG": "fat"}],
+                         ids=lambda e: "-".join(e.values()))
+def test_alternate_schedules_match_oracle(env):
     """The schedules kept behind CGP_SCHED / CGP_DIAG for A/B measurements (read once per process, hence
     the child process): three launches per step, two-stream look-ahead, next diagonal tile fused into
     the panel launch, the 157 KB one-per-CU diagonal kernel.  Same parity bar as the default schedule,
@@ -235,7 +257,7 @@ def test_alternate_schedules_match_oracle(var, val):
         "    assert (np.abs(var - v) / np.abs(v)).max() < tol\n"
         "    assert abs(logml[0] - f.logml) <= tol * abs(f.logml) and logml[0] == logml[1]\n"
         "print('ok')\n" % root)
-    env = dict(os.environ, **{var: val})
+    env = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
