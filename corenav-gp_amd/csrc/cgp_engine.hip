@@ -277,7 +277,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       }
     }
     HIP_TRY(c, hipStreamWaitEvent(sA, ev(3 * (NT - 1) + 2), 0));
-    hipLaunchKernelGGL(k_finalize<T>, dim3(cdiv(a.M, 64) + 1, B), dim3(256), 0, sA, ga[0], 1);
+    hipLaunchKernelGGL((k_finalize<T, 64>), dim3(cdiv(a.M, 64) + 1, B), dim3(256), 0, sA, ga[0], 1);
     if (want_alpha) hipLaunchKernelGGL(k_alpha<T>, dim3(B), dim3(256), (a.NT * TS + TS) * sizeof(double), sA, ga[0]);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_join[0], sA));
@@ -303,7 +303,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       L[0].end();
     }
     L[0].begin(3, batch * (4.0 * a.M * a.N + 2.0 * a.N));
-    hipLaunchKernelGGL(k_finalize<T>, dim3(cdiv(a.M, 64) + 1, batch), dim3(256), 0, s, ga[0], in_rows ? 1 : 0);
+    hipLaunchKernelGGL((k_finalize<T, 16>), dim3(cdiv(a.M, 16) + 1, batch), dim3(256), 0, s, ga[0], in_rows ? 1 : 0);
     L[0].end();
     if (want_alpha) {
       L[0].begin(4, batch * (double)a.N * a.N);
@@ -350,7 +350,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   }
   for (int g = 0; g < G; ++g) {
     L[g].begin(3, gb[g] * (4.0 * a.M * a.N + 2.0 * a.N));
-    hipLaunchKernelGGL(k_finalize<T>, dim3(cdiv(a.M, 64) + 1, gb[g]), dim3(256), 0, gs[g], ga[g], in_rows ? 1 : 0);
+    hipLaunchKernelGGL((k_finalize<T, 64>), dim3(cdiv(a.M, 64) + 1, gb[g]), dim3(256), 0, gs[g], ga[g], in_rows ? 1 : 0);
     L[g].end();
     if (want_alpha) {
       L[g].begin(4, gb[g] * (double)a.N * a.N);

@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void k_potf2(FitArgs p, int k) {
 // logML = -0.5 z'z - sum log L_ii - N/2 log 2pi   (a5 z-part, a6, a8).  grid (ceil(M/64)+1, batch):
 // the last block of each fit does the scalar reductions.
 // --------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int RB = 64>
 __global__ __launch_bounds__(256) void k_finalize(FitArgs p, int do_logml) {
   using P = Prec<T>;
   __shared__ double red[2][256];
@@ -705,13 +705,15 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs p, int do_logml) {
   const double *th = p.theta + (size_t)b * MAX_THETA;
   const int kid = p.kernel_id;
   const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? p.d + 2 : 4);
-  const int nmb = (M + 63) / 64;
+  // RB test rows per block, 256 / RB column groups (RB = 16 for the latency schedule: 4x the blocks)
+  constexpr int NG = 256 / RB;
+  const int nmb = (M + RB - 1) / RB;
   if ((int)blockIdx.x < nmb) {
-    const int ml = tid & 63, g = tid >> 6;
-    const int m = blockIdx.x * 64 + ml;
+    const int ml = tid % RB, g = tid / RB;
+    const int m = blockIdx.x * RB + ml;
     double smu = 0, sq = 0;
     if (m < M) {
-      for (int c = g; c < NP; c += 4) {
+      for (int c = g; c < NP; c += NG) {
         const double v = (double)Lw[(size_t)c * ld + rb + m];
         const double z = (double)Lw[(size_t)c * ld + rb + M];
         smu += v * z;
@@ -722,8 +724,18 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs p, int do_logml) {
     red[1][tid] = sq;
     __syncthreads();
     if (g == 0 && m < M) {
-      const double mu = (red[0][ml] + red[0][64 + ml]) + (red[0][128 + ml] + red[0][192 + ml]);
-      const double q = (red[1][ml] + red[1][64 + ml]) + (red[1][128 + ml] + red[1][192 + ml]);
+      double mu, q;
+      if constexpr (NG == 4) {
+        mu = (red[0][ml] + red[0][64 + ml]) + (red[0][128 + ml] + red[0][192 + ml]);
+        q = (red[1][ml] + red[1][64 + ml]) + (red[1][128 + ml] + red[1][192 + ml]);
+      } else {
+        mu = q = 0;
+#pragma unroll
+        for (int g2 = 0; g2 < NG; ++g2) {
+          mu += red[0][g2 * RB + ml];
+          q += red[1][g2 * RB + ml];
+        }
+      }
       double kss;
       if (kid == K_RBF_BROWNIAN) {
         const double xs = (double)reinterpret_cast<const T *>(p.Xs)[(size_t)b * p.d * M + m];
