@@ -231,6 +231,18 @@ def test_throughput_schedule_matches_oracle(engine, dtype_name, N):
     assert relmax(m2, mean[:2]) < tol and np.max(np.abs(l2 - logml[:2]) / np.abs(logml[:2])) < tol
 
 
+def test_latency_schedule_is_deterministic(engine):
+    """k_tile_sk adds the split-K partial tiles in range order whichever workgroup arrives last: repeated
+    calls are bitwise identical (tools/stress_latency.py is the long version)."""
+    kid, X, y, Xs, th, _ = synth.config(2, batch=3, N=1000)
+    ctx = engine.Context(max_n=1000, max_m=599, max_d=6, max_batch=3)
+    ref = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert ref[0] == 0
+    for _ in range(25):
+        r = ctx.fit_predict_batch(X, y, Xs, th, kid)
+        assert np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3])
+
+
 @pytest.mark.parametrize("env", [{"CGP_SCHED": "classic"}, {"CGP_SCHED": "overlap"}, {"CGP_SCHED": "fuseddiag"},
                                  {"CGP_SCHED": "throughput"}, {"CGP_SCHED": "throughput", "CGP_DIAG": "fat"}],
                          ids=lambda e: "-".join(e.values()))
