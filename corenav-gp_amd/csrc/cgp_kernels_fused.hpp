@@ -129,65 +129,80 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
 // nchunk is a multiple of 4 (k * 128 / 16).  The Gram staging area (smem + 2 chunk buffers) is
 // buffer 2 / 3, first written after the barrier of iteration 0, i.e. after every wave's Gram phase.
 // --------------------------------------------------------------------------------------------------
-struct RowFrag {
-  using vec2 = double __attribute__((ext_vector_type(2)));
+template <typename T> struct RowFrag {
+  using vec2 = T __attribute__((ext_vector_type(2)));
   vec2 r[4][KT / 4];
 };
 
-template <int SLOT>
-__device__ __forceinline__ void rfrag_load(RowFrag &f, const double *gRl, size_t ldR, int chunk, int lq) {
+template <typename T, int SLOT>
+__device__ __forceinline__ void rfrag_load(RowFrag<T> &f, const T *gRl, size_t ldR, int chunk, int lq) {
   // Issued as raw instructions: with an LDS-DMA load in flight the compiler's waitcnt pass treats
   // every later use of a loaded register as "flat pending" and inserts vmcnt(0), which would wait
   // for the whole prefetch queue.  The hand-placed vmcnt waits in rdirect_step cover these loads.
 #pragma unroll
   for (int ks = 0; ks < KT / 4; ++ks) {
-    const double *src = gRl + (size_t)(chunk * KT + ks * 4 + lq) * ldR;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(f.r[SLOT][ks]) : "v"(src));
+    const T *src = gRl + (size_t)(chunk * KT + ks * 4 + lq) * ldR;
+    if constexpr (sizeof(T) == 8) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(f.r[SLOT][ks]) : "v"(src));
+    else asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(f.r[SLOT][ks]) : "v"(src));
   }
 }
 
-__device__ __forceinline__ void cpanel_stage(const double *gC, size_t ldC, int chunk, double *buf, int lane, int wave) {
+// One chunk (KT columns of 128 rows) of the column panel, HBM -> LDS by LDS-DMA.  fp64: a column is
+// one 1 KiB dwordx4 wave-instruction; fp32: two 256-byte dword wave-instructions (gfx950 has no
+// 8-byte LDS-DMA).  Loads per wave and chunk: CLOADS.
+template <typename T> constexpr int cpanel_loads() { return sizeof(T) == 8 ? KT / 4 : KT / 2; }
+template <typename T>
+__device__ __forceinline__ void cpanel_stage(const T *gC, size_t ldC, int chunk, T *buf, int lane, int wave) {
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void gbl_void;
 #pragma unroll
   for (int i = 0; i < KT / 4; ++i) {
     const int col = wave * (KT / 4) + i;
-    __builtin_amdgcn_global_load_lds((gbl_void *)(gC + (size_t)(chunk * KT + col) * ldC + lane * 2),
-                                     (lds_void *)(buf + col * LDST), 16, 0, 0);
+    const T *src = gC + (size_t)(chunk * KT + col) * ldC;
+    if constexpr (sizeof(T) == 8) {
+      __builtin_amdgcn_global_load_lds((gbl_void *)(src + lane * 2), (lds_void *)(buf + col * LDST), 16, 0, 0);
+    } else {
+      __builtin_amdgcn_global_load_lds((gbl_void *)(src + lane), (lds_void *)(buf + col * LDST), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void *)(src + 64 + lane), (lds_void *)(buf + col * LDST + 64), 4, 0, 0);
+    }
   }
 }
 
-__device__ __forceinline__ void rdirect_prologue(RowFrag &f, const double *gR, size_t ldR, const double *gC, size_t ldC,
-                                                 int nchunk, double *smem, int tid) {
+template <typename T>
+__device__ __forceinline__ void rdirect_prologue(RowFrag<T> &f, const T *gR, size_t ldR, const T *gC, size_t ldC,
+                                                 int nchunk, T *smem, int tid) {
   constexpr int CH = KT * LDST;
   if (nchunk <= 0) return;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const double *gRl = gR + wave * 32 + 2 * (lane & 15);
-  cpanel_stage(gC, ldC, 0, smem, lane, wave);
-  rfrag_load<0>(f, gRl, ldR, 0, lane >> 4);
-  cpanel_stage(gC, ldC, 1, smem + CH, lane, wave);
-  rfrag_load<1>(f, gRl, ldR, 1, lane >> 4);
+  const T *gRl = gR + wave * 32 + 2 * (lane & 15);
+  cpanel_stage<T>(gC, ldC, 0, smem, lane, wave);
+  rfrag_load<T, 0>(f, gRl, ldR, 0, lane >> 4);
+  cpanel_stage<T>(gC, ldC, 1, smem + CH, lane, wave);
+  rfrag_load<T, 1>(f, gRl, ldR, 1, lane >> 4);
 }
 
 // ISSUE / LAST are compile-time so that no data-dependent branch sits between a load and its use:
 // the compiler's own s_waitcnt insertion then counts the loads in flight exactly (with a branch it
 // falls back to vmcnt(0) at the first use of the row fragments, which serialises the pipeline).
-template <int S, bool ISSUE, bool LAST>
-__device__ __forceinline__ void rdirect_step(Prec<double>::acc_t (&acc)[NCB][2], RowFrag &f, const double *gRl, size_t ldR,
-                                             const double *gC, size_t ldC, int c, double *smem, int lane, int wave) {
-  using P = Prec<double>;
+template <typename T, int S, bool ISSUE, bool LAST>
+__device__ __forceinline__ void rdirect_step(typename Prec<T>::acc_t (&acc)[NCB][2], RowFrag<T> &f, const T *gRl, size_t ldR,
+                                             const T *gC, size_t ldC, int c, T *smem, int lane, int wave) {
+  using P = Prec<T>;
   constexpr int CH = KT * LDST;
   const int l15 = lane & 15, lq = lane >> 4;
+  // everything but the loads of chunk c + 1 (cpanel_loads + 4 row fragments) has landed
   if constexpr (LAST) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  else if constexpr (sizeof(T) == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+  static_assert(cpanel_loads<double>() + KT / 4 == 8 && cpanel_loads<float>() + KT / 4 == 12, "vmcnt constants");
   if constexpr (ISSUE) {
-    cpanel_stage(gC, ldC, c + 2, smem + ((S + 2) & 3) * CH, lane, wave);
-    rfrag_load<(S + 2) & 3>(f, gRl, ldR, c + 2, lq);
+    cpanel_stage<T>(gC, ldC, c + 2, smem + ((S + 2) & 3) * CH, lane, wave);
+    rfrag_load<T, (S + 2) & 3>(f, gRl, ldR, c + 2, lq);
   }
   // column fragments one k-step ahead of the MFMAs that consume them (two register sets)
-  const double *cur = smem + S * CH + lq * LDST + l15;
-  double fa[2][NCB];
+  const T *cur = smem + S * CH + lq * LDST + l15;
+  T fa[2][NCB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) fa[0][cb] = cur[cb * DB];
 #pragma unroll
@@ -196,7 +211,7 @@ __device__ __forceinline__ void rdirect_step(Prec<double>::acc_t (&acc)[NCB][2],
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) fa[(ks + 1) & 1][cb] = cur[(ks + 1) * 4 * LDST + cb * DB];
     }
-    const RowFrag::vec2 fb = f.r[S][ks];
+    const typename RowFrag<T>::vec2 fb = f.r[S][ks];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
       acc[cb][0] = P::mfma(fa[ks & 1][cb], fb[0], acc[cb][0]);
@@ -205,24 +220,24 @@ __device__ __forceinline__ void rdirect_step(Prec<double>::acc_t (&acc)[NCB][2],
   }
 }
 
-__device__ __forceinline__ void mfma_rowpanel_loop_rdirect(Prec<double>::acc_t (&acc)[NCB][2], RowFrag &f, const double *gR,
-                                                           size_t ldR, const double *gC, size_t ldC, int nchunk,
-                                                           double *smem, int tid) {
+template <typename T>
+__device__ __forceinline__ void mfma_rowpanel_loop_rdirect(typename Prec<T>::acc_t (&acc)[NCB][2], RowFrag<T> &f, const T *gR,
+                                                           size_t ldR, const T *gC, size_t ldC, int nchunk, T *smem, int tid) {
   if (nchunk <= 0) return;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const double *gRl = gR + wave * 32 + 2 * (lane & 15);
+  const T *gRl = gR + wave * 32 + 2 * (lane & 15);
   int c = 0;
   for (; c + 4 < nchunk; c += 4) {
-    rdirect_step<0, true, false>(acc, f, gRl, ldR, gC, ldC, c, smem, lane, wave);
-    rdirect_step<1, true, false>(acc, f, gRl, ldR, gC, ldC, c + 1, smem, lane, wave);
-    rdirect_step<2, true, false>(acc, f, gRl, ldR, gC, ldC, c + 2, smem, lane, wave);
-    rdirect_step<3, true, false>(acc, f, gRl, ldR, gC, ldC, c + 3, smem, lane, wave);
+    rdirect_step<T, 0, true, false>(acc, f, gRl, ldR, gC, ldC, c, smem, lane, wave);
+    rdirect_step<T, 1, true, false>(acc, f, gRl, ldR, gC, ldC, c + 1, smem, lane, wave);
+    rdirect_step<T, 2, true, false>(acc, f, gRl, ldR, gC, ldC, c + 2, smem, lane, wave);
+    rdirect_step<T, 3, true, false>(acc, f, gRl, ldR, gC, ldC, c + 3, smem, lane, wave);
   }
-  rdirect_step<0, true, false>(acc, f, gRl, ldR, gC, ldC, c, smem, lane, wave);
-  rdirect_step<1, true, false>(acc, f, gRl, ldR, gC, ldC, c + 1, smem, lane, wave);
-  rdirect_step<2, false, false>(acc, f, gRl, ldR, gC, ldC, c + 2, smem, lane, wave);
-  rdirect_step<3, false, true>(acc, f, gRl, ldR, gC, ldC, c + 3, smem, lane, wave);
+  rdirect_step<T, 0, true, false>(acc, f, gRl, ldR, gC, ldC, c, smem, lane, wave);
+  rdirect_step<T, 1, true, false>(acc, f, gRl, ldR, gC, ldC, c + 1, smem, lane, wave);
+  rdirect_step<T, 2, false, false>(acc, f, gRl, ldR, gC, ldC, c + 2, smem, lane, wave);
+  rdirect_step<T, 3, false, true>(acc, f, gRl, ldR, gC, ldC, c + 3, smem, lane, wave);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -809,7 +824,11 @@ __device__ __forceinline__ void load_tile(typename Prec<T>::acc_t (&acc)[NCB][2]
     }
 }
 
-constexpr bool RDIRECT = true;  // fp64 k_panel: row panel straight to registers (mfma_rowpanel_loop_rdirect)
+// k_panel fp64: row panel straight to registers (mfma_rowpanel_loop_rdirect).  The loop is written for
+// both precisions, but fp32 measured 4.5 % slower with it (85.1k vs 89.1k fits/s at N = 1024: 156 VGPRs
+// cost an occupancy step and a 512-byte column needs two 256-byte LDS-DMA instructions), so fp32
+// keeps the register-staged loop.
+constexpr bool RDIRECT = true;
 
 template <typename T, bool DIAGNEXT = false>
 __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
@@ -831,15 +850,15 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
   acc_t acc[NCB][2];
   const T *gR = Lw + (size_t)rt * TS, *gC = Lw + (size_t)k * TS;
   const int nchunk = (k * TS) / KT;
-  if constexpr (sizeof(T) == 8 && RDIRECT) {
-    RowFrag rf;
+  if constexpr (RDIRECT && sizeof(T) == 8) {
+    RowFrag<T> rf;
     {
       GramPre<T> gp;
       gram_prefetch<T>(p, b, k, rt, tid, gp);
-      rdirect_prologue(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+      rdirect_prologue<T>(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
       gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
     }
-    mfma_rowpanel_loop_rdirect(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+    mfma_rowpanel_loop_rdirect<T>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
   } else {
     {
       GramPre<T> gp;
