@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace cgp {
 
@@ -488,31 +489,105 @@ __global__ __launch_bounds__(256, 2) void k_trmm(FitArgs p, int k) {
 // in a[] (replicated over the four 16-lane groups).  On return a[] holds the row of the Cholesky
 // factor and w[i] = Dinv[i][lane & 15] (column (lane & 15) of the block's inverse, by forward
 // substitution).  A non-positive pivot is replaced by 1 and reported in `bad` (1-based global index).
+// This is the serial critical path of the factorisation (128 dependent pivots per tile) and it is
+// bound by instruction issue, not latency (tools/potf2_block_bench.hip), so the fp64 form uses the
+// 64-bit DPP row_newbcast of gfx90a+: "times lane c's value" is ONE v_fmac_f64_dpp instead of two
+// v_readlane_b32 and an fma (the four rows hold identical copies, a row-local broadcast is the right
+// one).  3.76 -> 2.42 us per block with two such waves per SIMD.  A DPP read of a VGPR needs two wait
+// states after the VALU write: the first DPP instruction after each producer carries an s_nop 1.
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+template <int C, bool NOP> __device__ __forceinline__ void fmac_bcast(float &acc, float src, float own) {
+  if constexpr (NOP) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own), "n"(C));
+  else asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own), "n"(C));
+}
+template <int C> __device__ __forceinline__ float mov_bcast(float src) {
+  float d;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(src), "n"(C));
+  return d;
+}
+template <int C, bool NOP> __device__ __forceinline__ void fmac_bcast(double &acc, double src, double own) {  // acc += src[lane C of the row] * own
+  if constexpr (NOP) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own), "n"(C));
+  else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own), "n"(C));
+}
+template <int C> __device__ __forceinline__ double mov_bcast(double src) {
+  double d;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(src), "n"(C));
+  return d;
+}
+// 1/sqrt(x): hardware seed (~2^-23 relative) and one third-order step, error ~ e^3
+__device__ __forceinline__ double rsqrt3(double x) {
+  const double r = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-(x * r), r, 1.0);
+  const double q = __builtin_fma(0.375, e, 0.5) * e;
+  return __builtin_fma(r, q, r);
+}
+
 template <typename T>
 __device__ __forceinline__ void factor_block16(T (&a)[DB], T (&w)[DB], int &bad, int pivot_base, int l15) {
   using P = Prec<T>;
   T rinv[DB];
+  if constexpr (true) {
+    static_for<0, DB>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      T dj = mov_bcast<J>(a[J]);
+      const bool ok = dj > T(0);
+      if (!ok && bad == 0) bad = pivot_base + J + 1;
+      dj = ok ? dj : T(1);
+      T rs;
+      if constexpr (sizeof(T) == 8) rs = rsqrt3(dj);
+      else rs = P::rsqrt_(dj);
+      rinv[J] = rs;
+      const T l = (ok ? a[J] : ((l15 == J) ? T(1) : a[J])) * rs;   // lane J's a[J] is the pivot itself
+      a[J] = l;
+      const T nl = -l;
+      static_for<J + 1, DB>([&](auto cc) {
+        constexpr int C = decltype(cc)::value;
+        fmac_bcast<C, C == J + 1>(a[C], l, nl);
+      });
+    });
+    // right-looking forward substitution for column l15 of the inverse: independent updates per step
+    T t[DB];
 #pragma unroll
-  for (int j = 0; j < DB; ++j) {
-    T dj = rdlane(a[j], j);
-    if (!(dj > T(0))) {
-      if (bad == 0) bad = pivot_base + j + 1;
-      dj = T(1);
+    for (int i = 0; i < DB; ++i) t[i] = (i == l15) ? T(1) : T(0);
+    static_for<0, DB>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      w[Q] = t[Q] * rinv[Q];
+      const T nw = -w[Q];
+      static_for<Q + 1, DB>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        fmac_bcast<I, false>(t[I], a[Q], nw);
+      });
+    });
+#pragma unroll
+    for (int i = 0; i < DB; ++i) w[i] = (i < l15) ? T(0) : w[i];
+  } else {
+#pragma unroll
+    for (int j = 0; j < DB; ++j) {
+      T dj = rdlane(a[j], j);
+      if (!(dj > T(0))) {
+        if (bad == 0) bad = pivot_base + j + 1;
+        dj = T(1);
+      }
+      const T rs = P::rsqrt_(dj);
+      rinv[j] = rs;
+      const T l = (l15 == j) ? dj * rs : a[j] * rs;
+      a[j] = l;
+#pragma unroll
+      for (int c = j + 1; c < DB; ++c) a[c] -= l * rdlane(l, c);
     }
-    const T rs = P::rsqrt_(dj);
-    rinv[j] = rs;
-    const T l = (l15 == j) ? dj * rs : a[j] * rs;
-    a[j] = l;
 #pragma unroll
-    for (int c = j + 1; c < DB; ++c) a[c] -= l * rdlane(l, c);
-  }
+    for (int i = 0; i < DB; ++i) {
+      T s = 0;
 #pragma unroll
-  for (int i = 0; i < DB; ++i) {
-    T s = 0;
-#pragma unroll
-    for (int q = 0; q < DB; ++q)
-      if (q < i) s += rdlane(a[q], i) * w[q];
-    w[i] = (i < l15) ? T(0) : ((i == l15) ? rinv[i] : -s * rinv[i]);
+      for (int q = 0; q < DB; ++q)
+        if (q < i) s += rdlane(a[q], i) * w[q];
+      w[i] = (i < l15) ? T(0) : ((i == l15) ? rinv[i] : -s * rinv[i]);
+    }
   }
 }
 
