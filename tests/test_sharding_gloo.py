@@ -34,7 +34,7 @@ def _worker(rank, world, port, n_total, q):
     table = sharding.gather_summaries(local, n_total)
     stats = sharding.ensemble_stats(table)
     dist.barrier()
-    q.put((rank, table.clone(), stats))
+    q.put((rank, table.tolist(), stats))      # plain lists: a tensor in a Queue needs the sender alive until it is read
     dist.destroy_process_group()
 
 
@@ -55,6 +55,7 @@ def test_gather_summaries_world2(n_total):
     idx = torch.arange(n_total, dtype=torch.float64)
     expect = torch.stack([-100.0 - idx, 0.1 + 0.001 * idx, (idx == 3).to(torch.float64)], 1)
     for rank, table, stats in got:
+        table = torch.tensor(table, dtype=torch.float64)
         assert torch.equal(table, expect)                      # global fit order on every rank
         assert stats["n"] == n_total and stats["n_failed"] == 1
         ok = expect[:, 2] == 0
