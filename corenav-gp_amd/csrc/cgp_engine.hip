@@ -55,6 +55,7 @@ struct cgp_ctx {
   double *dgpart = nullptr;
   void *dpart = nullptr;   // latency schedule: partial tiles [LAT_FITS][slots][SK_MAX][128*128]
   int *dticket = nullptr;  //                   arrival tickets [LAT_FITS][slots]
+  int *dwready = nullptr;  //                   published block steps [LAT_FITS]
   int sk_slots = 0;
   // sliding windows (cgp_window_*)
   WindowArgs win{};
@@ -287,7 +288,11 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // Latency schedule for a handful of fits (k_tile_sk): the diagonal tile and
   // the panel tiles of a step in one launch, inner dimension split over up to SK_MAX workgroups.
   if (latency) {
-    SplitArgs q{c->dpart, c->dticket, c->sk_slots, 1, in_rows ? 1 : 0};
+    // default: k_trmm_sk as its own launch.  CGP_SK_TRMM=fused lets the tile finishers wait (bounded) for
+    // W_k inside k_tile_sk, one launch per step: measured 1.77 vs 1.80 ms per fit, not worth a wait loop.
+    static const bool split_trmm = [] { const char *e = getenv("CGP_SK_TRMM"); return !(e && std::string(e) == "fused"); }();
+    SplitArgs q{c->dpart, c->dticket, c->sk_slots, 1, in_rows ? 1 : 0, c->dwready, split_trmm ? 0 : 1};
+    if (in_rows) HIP_TRY(c, hipMemsetAsync(c->dwready, 0, sizeof(int) * LAT_FITS, s));
     for (int k = 0; k < a.NT; ++k) {
       const int tiles = (in_rows ? a.NT - k - 1 : 0) + a.ET;
       const int nslots = tiles + (in_rows ? 1 : 0);
@@ -298,9 +303,11 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       L[0].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, batch) + (in_rows ? diag_flops(a.N, a.d, k, batch) : 0.0));
       hipLaunchKernelGGL(k_tile_sk<T>, dim3(nslots, batch, sk), dim3(256), in_rows ? tile_lds : upd_lds, s, ga[0], q, k);
       L[0].end();
-      L[0].begin(2, trsm_flops(a.N, a.M, k, in_rows, batch));
-      hipLaunchKernelGGL(k_trmm_sk<T>, dim3(tiles, batch), dim3(256), upd_lds, s, ga[0], k);
-      L[0].end();
+      if (split_trmm) {
+        L[0].begin(2, trsm_flops(a.N, a.M, k, in_rows, batch));
+        hipLaunchKernelGGL(k_trmm_sk<T>, dim3(tiles, batch), dim3(256), upd_lds, s, ga[0], k);
+        L[0].end();
+      }
     }
     L[0].begin(3, batch * (4.0 * a.M * a.N + 2.0 * a.N));
     hipLaunchKernelGGL((k_finalize<T, 16>), dim3(cdiv(a.M, 16) + 1, batch), dim3(256), 0, s, ga[0], in_rows ? 1 : 0);
@@ -514,6 +521,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc(&c->dpart, (size_t)LAT_FITS * c->sk_slots * SK_MAX * TS * TS * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dticket, sizeof(int) * LAT_FITS * c->sk_slots) == hipSuccess;
   ok = ok && hipMemset(c->dticket, 0, sizeof(int) * LAT_FITS * c->sk_slots) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->dwready, sizeof(int) * LAT_FITS) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->ddbg, 64 * sizeof(long long)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dprep, B * PREP_N * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dlogml, B * sizeof(double)) == hipSuccess;
@@ -534,7 +542,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {

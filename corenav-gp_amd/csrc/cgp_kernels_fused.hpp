@@ -962,6 +962,8 @@ __global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
 //                  LDS (potf2_lds_body), the others are stored as -S into their slot of the panel.
 //                  The diagonal update and the panel updates of a step thus run side by side.
 //   k_trmm_sk(k) : L(i,k) = S(i,k) W_k^T in registers, as the tail of k_panel.
+//                  (CGP_SK_TRMM=fused: the other finishers of k_tile_sk wait -- bounded -- for W_k and
+//                  apply it themselves, one launch per step; 2 % faster, kept for A/B only.)
 // --------------------------------------------------------------------------------------------------
 struct SplitArgs {
   void *part;       // [fits][slots][SK_MAX][128*128] partial tiles
@@ -969,6 +971,8 @@ struct SplitArgs {
   int slots;        // tile slots per fit in `part` / `ticket`
   int sk;           // ranges the inner dimension is cut into (1..SK_MAX)
   int has_diag;     // fit: slot 0 is the diagonal tile; predict-only: extra tiles only
+  int *wready;      // [fits] number of block steps whose W_k is published (fit schedule); see k_tile_sk
+  int fuse_trmm;    // finishers of the non-diagonal tiles wait for W_k and apply it (one launch per step)
 };
 constexpr int SK_MAX = 8;
 
@@ -1023,7 +1027,26 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
   }
   __syncthreads();
 
+  if (!diag && !q.fuse_trmm) {
+    store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
+    return;
+  }
   if (!diag) {
+    // L(rt, k) = S W_k^T here as well: W_k comes from the diagonal tile's finishing workgroup of THIS
+    // launch.  Its workgroups have been dispatched by now or will be without this one's help (at
+    // most one waiting workgroup per tile, far fewer than CUs), so waiting cannot deadlock; the wait
+    // is bounded all the same and a timeout is reported through info[] instead of hanging the GPU.
+    if (q.has_diag) {
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(q.wready + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <= k && ++spins < (1 << 22))
+          __builtin_amdgcn_s_sleep(8);
+        if (spins >= (1 << 22)) atomicCAS(p.info + b, 0, -(k + 1));
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    trmm_in_registers<T>(p, acc, smem, b, k, tid);
     store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
     return;
   }
@@ -1044,6 +1067,9 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
   __syncthreads();
   potf2_lds_body<T>(At, Dv, Ts, flag, k, tid);
   potf2_store<T>(p, At, Dv, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
+  __threadfence();   // W_k (and L(k,k)) visible device-wide before the step is announced
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(q.wready + b, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <typename T>
