@@ -178,7 +178,7 @@ def main():
                          "launches": upd["launches"]},
             "kernel_ms_per_step": {k: v["ms"] / 2 for k, v in prof.items()},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # rank 0 at N = 1 only: other ranks would wait on the host work
             out["cpu_baseline"] = cpu_baseline(kid, X, y, Xs, th, args.cpu_sample, dmean, dvar, dlogml, f_fit)
         print(json.dumps(out))
     if world > 1:
