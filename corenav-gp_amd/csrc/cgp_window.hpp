@@ -11,9 +11,9 @@
 //   add x_new:  l = L^-1 k(X, x_new) (forward substitution), d = sqrt(k** + noise - |l|^2),
 //               z_new = (y_new - l'z)/d.  l'z and k** - |l|^2 are also the one-step-ahead
 //               predictive mean / variance of y_new BEFORE it is added, so they are the tick's output.
-// Both sweeps are fused into one pass over L in 32-column panels: wave 0 does the sequential part
-// of a panel (32x32 diagonal block in registers, v_readlane broadcasts), then every thread applies
-// the panel's 32 rotations and the substitution update to its own rows below.  L is read and
+// Both sweeps are fused into one pass over L in 16-column panels: wave 0 does the sequential part
+// of a panel (16x16 diagonal block in registers, DPP row_newbcast broadcasts), then every thread applies
+// the panel's 16 rotations and the substitution update to its own rows below.  L is read and
 // written exactly once per tick: ~ n^2/2 * 8 B * 2 of HBM/L2 traffic, the bound of this kernel.
 // Storage: column-major, capacity 2N x 2N; the window origin slides down the diagonal and is moved
 // back every N ticks.
@@ -22,7 +22,14 @@
 
 namespace cgp {
 
-constexpr int WPB = 32;  // panel width of the window sweep
+#ifndef WIN_WPB
+#define WIN_WPB 16
+#endif
+constexpr int WPB = WIN_WPB;  // panel width of the window sweep
+static_assert(WPB == 16, "phase A broadcasts with DPP row_newbcast: one 16-lane row = one diagonal block");
+#ifndef WIN_OCC
+#define WIN_OCC 2
+#endif
 
 struct WindowArgs {
   double *L;        // [nwin][CAP*CAP] column-major
@@ -58,12 +65,12 @@ __device__ __forceinline__ double win_cov(int kid, int d, const double *pr, cons
   return pr[9] * exp(-0.5 * rr * rr) * kb;
 }
 
-__global__ __launch_bounds__(256, 2) void k_window_ticks(WindowArgs p) {
+__global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *vv = reinterpret_cast<double *>(smem_raw);  // [N] rank-1 vector
   double *kk = vv + p.N;                               // [N] right-hand side of the append solve
   double *ll = kk + p.N;                               // [N] solution l
-  double *cs = ll + p.N;                               // [3][WPB] c, s, 1/c of the current panel
+  double *cs = ll + p.N;                               // [2][WPB] c, s of the current panel's rotations
   double *xn = cs + 3 * WPB;                           // [MAXD] the incoming point
   double *red = xn + MAXD;                             // [8] scalars handed from wave 0 to the block
   const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -109,44 +116,64 @@ __global__ __launch_bounds__(256, 2) void k_window_ticks(WindowArgs p) {
     for (int p0 = 0; p0 < n2; p0 += WPB) {
       const int nb = min(WPB, n2 - p0);
       double *Lp = L + (size_t)(o2 + p0) * CAP + o2;  // column p0 of the window, row 0 of the window
-      if (wave == 0) {
-        // ---- phase A: 32x32 diagonal block, lane = row (replicated in the upper half-wave)
-        const int i = lane & 31;
-        double a[WPB];
-#pragma unroll
-        for (int j = 0; j < WPB; ++j) a[j] = (j <= i && i < nb && j < nb) ? Lp[(size_t)j * CAP + p0 + i] : (i == j ? 1.0 : 0.0);
-        double vi = i < nb ? vv[p0 + i] : 0.0, ki = i < nb ? kk[p0 + i] : 0.0, zi = i < nb ? z[o2 + p0 + i] : 0.0;
+      // The rows below the panel do not depend on phase A: their panel columns are fetched now, so the
+      // HBM / L2 latency runs under the serial part instead of after the barrier.
+      const int i0 = p0 + WPB + tid;
+      double pre[WPB];
+      if (i0 < n2) {
+        const double *src = Lp + i0;
 #pragma unroll
         for (int j = 0; j < WPB; ++j) {
-          if (j < nb) {
-            // rotation (c, s) that folds v_j into the diagonal: one reciprocal and one rsqrt, both
-            // hardware-seeded + Newton (this chain is the serial critical path of the tick)
-            const double ljj = rdlane(a[j], j), vj = rdlane(vi, j);
-            double il = __builtin_amdgcn_rcp(ljj);
-            il = __builtin_fma(il, __builtin_fma(-ljj, il, 1.0), il);
-            il = __builtin_fma(il, __builtin_fma(-ljj, il, 1.0), il);
-            const double s = vj * il;
-            const double q2 = __builtin_fma(s, s, 1.0);
-            const double ci = Prec<double>::rsqrt_(q2);
-            const double c = q2 * ci;
-            const double tv = (a[j] + s * vi) * ci;
-            if (i > j) {
-              vi = c * vi - s * tv;
-              a[j] = tv;
-            } else if (i == j) a[j] = ljj * c;
-            const double zj = rdlane(zi, j);
-            const double zn = (zj + s * vz) * ci;
-            vz = c * vz - s * zn;
-            if (i == j) zi = zn;
+          pre[j] = *src;
+          src += CAP;
+          asm volatile("" : "+v"(src));
+        }
+      }
+      if (wave == 0) {
+        // ---- phase A: 32x32 diagonal block, lane = row (replicated in the upper half-wave)
+        const int i = lane & (WPB - 1);
+        double a[WPB];
+        {
+          // one running pointer (opaque to the optimiser): otherwise the unrolled loop keeps WPB 64-bit
+          // addresses live and the kernel spills
+          const double *src = Lp + p0 + i;
+#pragma unroll
+          for (int j = 0; j < WPB; ++j) {
+            a[j] = (j <= i && i < nb && j < nb) ? *src : (i == j ? 1.0 : 0.0);
+            src += CAP;
+            asm volatile("" : "+v"(src));
+          }
+        }
+        double vi = i < nb ? vv[p0 + i] : 0.0, ki = i < nb ? kk[p0 + i] : 0.0, zi = i < nb ? z[o2 + p0 + i] : 0.0;
+        // Givens rotation (c, s) = (l_jj, v_j) / sqrt(l_jj^2 + v_j^2) that folds v_j into the diagonal:
+        // one hardware-seeded rsqrt with a third-order step; this chain is the serial critical path
+        // of the tick.  Broadcasts of lane j's values are 64-bit DPP row_newbcast moves (the four
+        // 16-lane rows hold identical copies).
+        static_for<0, WPB>([&](auto jc) {
+          constexpr int J = decltype(jc)::value;
+          if (J < nb) {
+            const double ljj = mov_bcast<J>(a[J]), vj = mov_bcast<J>(vi), zj = mov_bcast<J>(zi);
+            const double r2 = __builtin_fma(vj, vj, ljj * ljj);
+            const double ri = rsqrt3(r2);
+            const double c = ljj * ri, sn = vj * ri;
+            const double aj = a[J];
+            const double tv = __builtin_fma(sn, vi, c * aj);
+            const double nv = __builtin_fma(c, vi, -(sn * aj));
+            if (i > J) {
+              a[J] = tv;
+              vi = nv;
+            } else if (i == J) a[J] = r2 * ri;
+            const double zn = __builtin_fma(sn, vz, c * zj);
+            vz = __builtin_fma(c, vz, -(sn * zj));
+            if (i == J) zi = zn;
             szz += zn * zn;
             if (lane == 0) {
-              cs[j] = c;
-              cs[WPB + j] = s;
-              cs[2 * WPB + j] = ci;
+              cs[J] = c;
+              cs[WPB + J] = sn;
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-        }
+        });
         // diagonal of the finished block: logs and reciprocals once per lane, in parallel
         double dg = 1.0;
 #pragma unroll
@@ -157,21 +184,25 @@ __global__ __launch_bounds__(256, 2) void k_window_ticks(WindowArgs p) {
         slog += lg;
         const double idg = 1.0 / dg;
         // forward substitution inside the block for the incoming point
-#pragma unroll
-        for (int q = 0; q < WPB; ++q) {
-          if (q < nb) {
-            const double lq = rdlane(ki, q) * rdlane(idg, q);
-            if (i > q) ki -= a[q] * lq;
-            sl2 += lq * lq;
-            slz += lq * rdlane(zi, q);
-            if (lane == 0) ll[p0 + q] = lq;
+        static_for<0, WPB>([&](auto qc) {
+          constexpr int Q = decltype(qc)::value;
+          if (Q < nb) {
+            const double lq = mov_bcast<Q>(ki * idg);
+            if (i > Q) ki = __builtin_fma(-a[Q], lq, ki);
+            sl2 = __builtin_fma(lq, lq, sl2);
+            fmac_bcast<Q, true>(slz, zi, lq);
+            if (lane == 0) ll[p0 + Q] = lq;
             __builtin_amdgcn_sched_barrier(0);
           }
-        }
+        });
         if (lane < nb) {
+          double *dst = Lp + p0 + i;
 #pragma unroll
-          for (int j = 0; j < WPB; ++j)
-            if (j <= i && j < nb) Lp[(size_t)j * CAP + p0 + i] = a[j];
+          for (int j = 0; j < WPB; ++j) {
+            if (j <= i && j < nb) *dst = a[j];
+            dst += CAP;
+            asm volatile("" : "+v"(dst));
+          }
           z[o2 + p0 + i] = zi;
         }
       }
@@ -180,18 +211,36 @@ __global__ __launch_bounds__(256, 2) void k_window_ticks(WindowArgs p) {
       for (int i = p0 + WPB + tid; i < n2; i += 256) {
         asm volatile("" ::: "memory");  // keep the panel's 128 LDS scalars from being hoisted into registers
         double a[WPB];
+        if (i == i0) {
 #pragma unroll
-        for (int j = 0; j < WPB; ++j) a[j] = Lp[(size_t)j * CAP + i];
+          for (int j = 0; j < WPB; ++j) a[j] = pre[j];
+        } else {
+          const double *src = Lp + i;
+#pragma unroll
+          for (int j = 0; j < WPB; ++j) {
+            a[j] = *src;
+            src += CAP;
+            asm volatile("" : "+v"(src));
+          }
+        }
         double vi = vv[i], ki = kk[i];
 #pragma unroll
         for (int j = 0; j < WPB; ++j) {
-          const double tv = (a[j] + cs[WPB + j] * vi) * cs[2 * WPB + j];
-          vi = cs[j] * vi - cs[WPB + j] * tv;
+          const double c = cs[j], sn = cs[WPB + j], aj = a[j];
+          const double tv = __builtin_fma(sn, vi, c * aj);
+          vi = __builtin_fma(c, vi, -(sn * aj));
           a[j] = tv;
-          ki -= tv * ll[p0 + j];
+          ki = __builtin_fma(-tv, ll[p0 + j], ki);
         }
+        {
+          double *dst = Lp + i;
 #pragma unroll
-        for (int j = 0; j < WPB; ++j) Lp[(size_t)j * CAP + i] = a[j];
+          for (int j = 0; j < WPB; ++j) {
+            *dst = a[j];
+            dst += CAP;
+            asm volatile("" : "+v"(dst));
+          }
+        }
         vv[i] = vi;
         kk[i] = ki;
       }
