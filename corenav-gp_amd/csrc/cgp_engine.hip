@@ -1074,7 +1074,7 @@ extern "C" int cgp_window_push_device(cgp_ctx *c, int T, const double *dxs, cons
   a.logml = dl;
   a.T = T;
   a.include_noise = include_noise;
-  const size_t lds = (size_t)(3 * a.N + 3 * WPB + MAXD + 8) * sizeof(double);
+  const size_t lds = (size_t)(3 * a.N + 4 * WPB + MAXD + 8) * sizeof(double);
   hipLaunchKernelGGL(k_window_ticks, dim3(c->nwin), dim3(256), lds, hip_stream ? (hipStream_t)hip_stream : c->stream, a);
   HIP_TRY(c, hipGetLastError());
   return CGP_OK;

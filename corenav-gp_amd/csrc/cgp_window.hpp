@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
   double *vv = reinterpret_cast<double *>(smem_raw);  // [N] rank-1 vector
   double *kk = vv + p.N;                               // [N] right-hand side of the append solve
   double *ll = kk + p.N;                               // [N] solution l
-  double *cs = ll + p.N;                               // [2][WPB] c, s of the current panel's rotations
-  double *xn = cs + 3 * WPB;                           // [MAXD] the incoming point
+  double *cs = ll + p.N;                               // [2][2][WPB] c, s of a panel's rotations, double-buffered
+  double *xn = cs + 4 * WPB;                           // [MAXD] the incoming point
   double *red = xn + MAXD;                             // [8] scalars handed from wave 0 to the block
   const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,139 +113,176 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
     double sl2 = 0, slz = 0, slog = 0, szz = 0;
     __syncthreads();
 
-    for (int p0 = 0; p0 < n2; p0 += WPB) {
-      const int nb = min(WPB, n2 - p0);
-      double *Lp = L + (size_t)(o2 + p0) * CAP + o2;  // column p0 of the window, row 0 of the window
-      // The rows below the panel do not depend on phase A: their panel columns are fetched now, so the
-      // HBM / L2 latency runs under the serial part instead of after the barrier.
-      const int i0 = p0 + WPB + tid;
-      double pre[WPB];
-      if (i0 < n2) {
-        const double *src = Lp + i0;
+    // Panel pipeline.  Per 16-column panel the work is  A(p): wave 0 rotates and solves the 16x16
+    // diagonal block (serial, in registers)  and  B(p): every row below takes the panel's 16
+    // rotations and the substitution update.  A(p+1) only needs B(p) on the 16 rows of the next
+    // diagonal block, so wave 0 applies B(p) to those rows itself and goes straight on to A(p+1) while
+    // waves 1-3 sweep the remaining rows: one barrier per panel, serial part and sweep side by side.
+    // (c, s) of a panel live in cs[panel & 1] (double buffer), l in ll[p0 ..].
+    const int i = lane & (WPB - 1);
+    const int npan = (n2 + WPB - 1) / WPB;
+    double vi = 0, ki = 0, zi = 0;  // wave 0: the diagonal block's rows of v, k, z (registers across panels)
+    // the 16x16 diagonal block of panel p0 (lane = row), identity-padded; issued early by the caller
+    auto load_diag = [&](int p0, int nb, double (&a)[WPB]) {
+      const double *src = L + (size_t)(o2 + p0) * CAP + o2 + p0 + i;
 #pragma unroll
-        for (int j = 0; j < WPB; ++j) {
-          pre[j] = *src;
-          src += CAP;
-          asm volatile("" : "+v"(src));
-        }
+      for (int j = 0; j < WPB; ++j) {
+        a[j] = (j <= i && i < nb && j < nb) ? *src : (i == j ? 1.0 : 0.0);
+        src += CAP;
+        asm volatile("" : "+v"(src));
       }
-      if (wave == 0) {
-        // ---- phase A: 32x32 diagonal block, lane = row (replicated in the upper half-wave)
-        const int i = lane & (WPB - 1);
-        double a[WPB];
-        {
-          // one running pointer (opaque to the optimiser): otherwise the unrolled loop keeps WPB 64-bit
-          // addresses live and the kernel spills
-          const double *src = Lp + p0 + i;
-#pragma unroll
-          for (int j = 0; j < WPB; ++j) {
-            a[j] = (j <= i && i < nb && j < nb) ? *src : (i == j ? 1.0 : 0.0);
-            src += CAP;
-            asm volatile("" : "+v"(src));
-          }
-        }
-        double vi = i < nb ? vv[p0 + i] : 0.0, ki = i < nb ? kk[p0 + i] : 0.0, zi = i < nb ? z[o2 + p0 + i] : 0.0;
-        // Givens rotation (c, s) = (l_jj, v_j) / sqrt(l_jj^2 + v_j^2) that folds v_j into the diagonal:
-        // one hardware-seeded rsqrt with a third-order step; this chain is the serial critical path
-        // of the tick.  Broadcasts of lane j's values are 64-bit DPP row_newbcast moves (the four
-        // 16-lane rows hold identical copies).
-        static_for<0, WPB>([&](auto jc) {
-          constexpr int J = decltype(jc)::value;
-          if (J < nb) {
-            const double ljj = mov_bcast<J>(a[J]), vj = mov_bcast<J>(vi), zj = mov_bcast<J>(zi);
-            const double r2 = __builtin_fma(vj, vj, ljj * ljj);
-            const double ri = rsqrt3(r2);
-            const double c = ljj * ri, sn = vj * ri;
-            const double aj = a[J];
-            const double tv = __builtin_fma(sn, vi, c * aj);
-            const double nv = __builtin_fma(c, vi, -(sn * aj));
-            if (i > J) {
-              a[J] = tv;
-              vi = nv;
-            } else if (i == J) a[J] = r2 * ri;
-            const double zn = __builtin_fma(sn, vz, c * zj);
-            vz = __builtin_fma(c, vz, -(sn * zj));
-            if (i == J) zi = zn;
-            szz += zn * zn;
-            if (lane == 0) {
-              cs[J] = c;
-              cs[WPB + J] = sn;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        });
-        // diagonal of the finished block: logs and reciprocals once per lane, in parallel
-        double dg = 1.0;
-#pragma unroll
-        for (int j = 0; j < WPB; ++j) dg = (i == j) ? a[j] : dg;
-        double lg = (lane < nb) ? log(dg) : 0.0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
-        slog += lg;
-        const double idg = 1.0 / dg;
-        // forward substitution inside the block for the incoming point
-        static_for<0, WPB>([&](auto qc) {
-          constexpr int Q = decltype(qc)::value;
-          if (Q < nb) {
-            const double lq = mov_bcast<Q>(ki * idg);
-            if (i > Q) ki = __builtin_fma(-a[Q], lq, ki);
-            sl2 = __builtin_fma(lq, lq, sl2);
-            fmac_bcast<Q, true>(slz, zi, lq);
-            if (lane == 0) ll[p0 + Q] = lq;
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        });
-        if (lane < nb) {
-          double *dst = Lp + p0 + i;
-#pragma unroll
-          for (int j = 0; j < WPB; ++j) {
-            if (j <= i && j < nb) *dst = a[j];
-            dst += CAP;
-            asm volatile("" : "+v"(dst));
-          }
-          z[o2 + p0 + i] = zi;
-        }
-      }
-      __syncthreads();
-      // ---- phase B: every row below the panel takes the panel's rotations and the solve update
-      for (int i = p0 + WPB + tid; i < n2; i += 256) {
-        asm volatile("" ::: "memory");  // keep the panel's 128 LDS scalars from being hoisted into registers
-        double a[WPB];
-        if (i == i0) {
-#pragma unroll
-          for (int j = 0; j < WPB; ++j) a[j] = pre[j];
-        } else {
-          const double *src = Lp + i;
-#pragma unroll
-          for (int j = 0; j < WPB; ++j) {
-            a[j] = *src;
-            src += CAP;
-            asm volatile("" : "+v"(src));
-          }
-        }
-        double vi = vv[i], ki = kk[i];
-#pragma unroll
-        for (int j = 0; j < WPB; ++j) {
-          const double c = cs[j], sn = cs[WPB + j], aj = a[j];
+      zi = i < nb ? z[o2 + p0 + i] : 0.0;
+    };
+    auto phase_a = [&](int p0, int nb, double *csb, double (&a)[WPB]) {
+      double *Lp = L + (size_t)(o2 + p0) * CAP + o2;
+      // Givens rotation (c, s) = (l_jj, v_j) / sqrt(l_jj^2 + v_j^2) that folds v_j into the diagonal:
+      // one hardware-seeded rsqrt with a third-order step; this chain is the serial critical path
+      // of the tick.  Broadcasts of lane j's values are 64-bit DPP row_newbcast moves (the four
+      // 16-lane rows hold identical copies).
+      static_for<0, WPB>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        if (J < nb) {
+          const double ljj = mov_bcast<J>(a[J]), vj = mov_bcast<J>(vi), zj = mov_bcast<J>(zi);
+          const double r2 = __builtin_fma(vj, vj, ljj * ljj);
+          const double ri = rsqrt3(r2);
+          const double c = ljj * ri, sn = vj * ri;
+          const double aj = a[J];
           const double tv = __builtin_fma(sn, vi, c * aj);
-          vi = __builtin_fma(c, vi, -(sn * aj));
-          a[j] = tv;
-          ki = __builtin_fma(-tv, ll[p0 + j], ki);
-        }
-        {
-          double *dst = Lp + i;
-#pragma unroll
-          for (int j = 0; j < WPB; ++j) {
-            *dst = a[j];
-            dst += CAP;
-            asm volatile("" : "+v"(dst));
+          const double nv = __builtin_fma(c, vi, -(sn * aj));
+          if (i > J) {
+            a[J] = tv;
+            vi = nv;
+          } else if (i == J) a[J] = r2 * ri;
+          const double zn = __builtin_fma(sn, vz, c * zj);
+          vz = __builtin_fma(c, vz, -(sn * zj));
+          if (i == J) zi = zn;
+          szz += zn * zn;
+          if (lane == 0) {
+            csb[J] = c;
+            csb[WPB + J] = sn;
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        vv[i] = vi;
-        kk[i] = ki;
+      });
+      // diagonal of the finished block: logs and reciprocals once per lane, in parallel
+      double dg = 1.0;
+#pragma unroll
+      for (int j = 0; j < WPB; ++j) dg = (i == j) ? a[j] : dg;
+      double lg = (lane < nb) ? log(dg) : 0.0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
+      slog += lg;
+      const double idg = 1.0 / dg;
+      // forward substitution inside the block for the incoming point
+      static_for<0, WPB>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        if (Q < nb) {
+          const double lq = mov_bcast<Q>(ki * idg);
+          if (i > Q) ki = __builtin_fma(-a[Q], lq, ki);
+          sl2 = __builtin_fma(lq, lq, sl2);
+          fmac_bcast<Q, true>(slz, zi, lq);
+          if (lane == 0) ll[p0 + Q] = lq;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      if (lane < nb) {
+        double *dst = Lp + p0 + i;
+#pragma unroll
+        for (int j = 0; j < WPB; ++j) {
+          if (j <= i && j < nb) *dst = a[j];
+          dst += CAP;
+          asm volatile("" : "+v"(dst));
+        }
+        z[o2 + p0 + i] = zi;
       }
-      __syncthreads();
+    };
+    // one row of the sweep: a[] = the row's 16 panel columns; returns the row's updated v and k
+    auto sweep_row = [&](double (&a)[WPB], double &v, double &k, const double *csb, int p0) {
+#pragma unroll
+      for (int j = 0; j < WPB; ++j) {
+        const double c = csb[j], sn = csb[WPB + j], aj = a[j];
+        const double tv = __builtin_fma(sn, v, c * aj);
+        v = __builtin_fma(c, v, -(sn * aj));
+        a[j] = tv;
+        k = __builtin_fma(-tv, ll[p0 + j], k);
+      }
+    };
+
+    if (wave == 0 && npan > 0) {
+      const int nb = min(WPB, n2);
+      vi = i < nb ? vv[i] : 0.0;
+      ki = i < nb ? kk[i] : 0.0;
+      double ad[WPB];
+      load_diag(0, nb, ad);
+      phase_a(0, nb, cs, ad);
     }
+    for (int pi = 0; pi < npan; ++pi) {
+      __syncthreads();  // A(pi) and B(pi-1) are complete
+      const int p0 = pi * WPB;
+      double *Lp = L + (size_t)(o2 + p0) * CAP + o2;  // column p0 of the window, row 0 of the window
+      const double *csb = cs + (pi & 1) * 2 * WPB;
+      if (wave == 0) {
+        if (pi + 1 < npan) {
+          // B(pi) on the rows of the next diagonal block, then A(pi + 1) with v, k still in registers
+          const int nb1 = min(WPB, n2 - (p0 + WPB));
+          const int r = p0 + WPB + i;
+          double ad[WPB];
+          load_diag(p0 + WPB, nb1, ad);  // in flight while the 16 rows below take B(pi)
+          double a[WPB];
+          {
+            const double *src = Lp + r;
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) {
+              a[j] = i < nb1 ? *src : 0.0;
+              src += CAP;
+              asm volatile("" : "+v"(src));
+            }
+          }
+          vi = i < nb1 ? vv[r] : 0.0;
+          ki = i < nb1 ? kk[r] : 0.0;
+          sweep_row(a, vi, ki, csb, p0);
+          if (lane < nb1) {
+            double *dst = Lp + r;
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) {
+              *dst = a[j];
+              dst += CAP;
+              asm volatile("" : "+v"(dst));
+            }
+          }
+          phase_a(p0 + WPB, nb1, cs + ((pi + 1) & 1) * 2 * WPB, ad);
+        }
+      } else {
+        // ---- B(pi): rows below the next diagonal block, three waves
+        for (int r = p0 + 2 * WPB + (tid - 64); r < n2; r += 192) {
+          asm volatile("" ::: "memory");  // keep the panel's LDS scalars from being hoisted across rows
+          double a[WPB];
+          {
+            const double *src = Lp + r;
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) {
+              a[j] = *src;
+              src += CAP;
+              asm volatile("" : "+v"(src));
+            }
+          }
+          double v = vv[r], k = kk[r];
+          sweep_row(a, v, k, csb, p0);
+          {
+            double *dst = Lp + r;
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) {
+              *dst = a[j];
+              dst += CAP;
+              asm volatile("" : "+v"(dst));
+            }
+          }
+          vv[r] = v;
+          kk[r] = k;
+        }
+      }
+    }
+    __syncthreads();
 
     // ---- append the new sample as the last row of the factor
     if (tid == 0) {
