@@ -103,6 +103,30 @@ def test_ragged_shapes_fp64(engine, N, d, M, kid):
     check_fit_predict(engine, kid, theta, X, y, Xs, engine.F64, TOL64)
 
 
+@pytest.mark.parametrize("B,N,d,M,kid", [(7, 300, 6, 64, 1), (16, 513, 8, 257, 1), (9, 640, 2, 1, 0), (5, 385, 1, 40, 2)])
+def test_ragged_batches_throughput_schedule(engine, B, N, d, M, kid):
+    """Ragged shapes through the batched ABI on the throughput schedule (batch > 4): batch sizes that are
+    and are not multiples of 8 (XCD-steered vs identity tile map), N just above a tile boundary, max d,
+    a single test point, the reference kernel."""
+    rng = np.random.default_rng(7 * N + B)
+    if kid == 2:
+        X = np.stack([(5 + b + np.arange(N, dtype=float))[:, None] for b in range(B)])
+        Xs = np.stack([(5 + b + N + np.arange(M, dtype=float))[:, None] for b in range(B)])
+        th = np.tile(np.array([0.5, 30.0, 0.01, 0.002]), (B, 1))
+    else:
+        X, Xs = rng.normal(size=(B, N, d)), rng.normal(size=(B, M, d))
+        th = np.stack([np.concatenate([[0.8], rng.uniform(0.6, 2.0, 1 if kid == 0 else d), [0.02]]) for _ in range(B)])
+    y = 0.1 * np.sin(np.arange(N) / 7.0)[None, :] + 0.03 * rng.normal(size=(B, N))
+    ctx = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=B)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not info.any()
+    for b in range(B):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        assert relmax(mean[b], omu) < TOL64 and releach(var[b], ovar) < TOL64
+        assert abs(logml[b] - f.logml) <= TOL64 * abs(f.logml)
+
+
 def test_factor_and_alpha_properties(engine):
     kid, X, y, Xs, th, _ = synth.config(1)       # N=256 d=3 SE-iso (configs[0])
     ctx, f = check_fit_predict(engine, kid, th[0], X[0], y[0], Xs[0], engine.F64, TOL64)
