@@ -817,10 +817,14 @@ int cgp_slip_node_callback(cgp_ctx *c, const double *time_array, const double *s
   if (M == 0) return CGP_OK;
   std::vector<double> xs(M), var(M);
   for (int m = 0; m < M; ++m) xs[m] = xmin + (double)(n + m);
-  int rc = cgp_fit(c, time_array, slip_array, ntr, 1, kid, theta, nullptr);
+  // GPRegression(...) and the m.predict loop (gp_slip_node.py:35,45-49) in ONE factorisation pass: the
+  // prediction points ride as extra rows (one schedule, one host round trip instead of two)
+  double logml = 0.0;
+  int info = 0;
+  int rc = cgp_fit_predict_batch(c, 1, ntr, 1, M, kid, time_array, slip_array, xs.data(), theta, ntheta(kid, 1), 1, mean,
+                                 var.data(), &logml, &info);
   if (rc != CGP_OK) return rc;
-  rc = cgp_predict(c, xs.data(), M, 1, mean, var.data());
-  if (rc != CGP_OK) return rc;
+  if (info != 0) return info;  // not positive definite even with GPy's jitter ladder (LinAlgError there)
   for (int m = 0; m < M; ++m) sigma[m] = 2.0 * std::sqrt(var[m]);  // gp_slip_node.py:61
   return CGP_OK;
 }
