@@ -604,7 +604,8 @@ __device__ __forceinline__ void factor_block16(T (&a)[DB], T (&w)[DB], int &bad,
 // Phases (a)-(d) on an LDS-resident tile: factor it in place (lower triangle), leave W = L^-1
 // transposed in the strict upper triangle and the inverted 16x16 diagonal blocks in Dv.
 template <typename T>
-__device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, int k, int tid, long long *dbgbuf = nullptr) {
+__device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, int k, int tid, long long *dbgbuf = nullptr,
+                                               int live = TS) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
   const int lane = tid & 63;
@@ -617,10 +618,15 @@ __device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, i
     if (wave == 0) {
       // (a) lane holds row (lane & 15) of the diagonal block (replicated over the four 16-lane groups)
       T a[DB], w[DB];
-#pragma unroll
-      for (int c = 0; c < DB; ++c) a[c] = At[(j0 + c) * LDP + j0 + l15];
       int bad = 0;
-      factor_block16<T>(a, w, bad, k * TS + j0, l15);
+      if (j0 < live) {
+#pragma unroll
+        for (int c = 0; c < DB; ++c) a[c] = At[(j0 + c) * LDP + j0 + l15];
+        factor_block16<T>(a, w, bad, k * TS + j0, l15);
+      } else {  // identity padding beyond the window (N not a multiple of 128): nothing to factor
+#pragma unroll
+        for (int c = 0; c < DB; ++c) a[c] = w[c] = (c == l15) ? T(1) : T(0);
+      }
       if (bad != 0 && lane == 0 && *flag == 0) *flag = bad;
       if (lane < DB) {
 #pragma unroll
@@ -760,7 +766,7 @@ __global__ __launch_bounds__(256) void k_potf2(FitArgs p, int k) {
   }
   if (tid == 0) *flag = 0;
   __syncthreads();
-  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid);
+  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, nullptr, p.N - k * TS);
   potf2_store<T>(p, At, Dv, flag, tile, ld, b, k, tid);
 }
 

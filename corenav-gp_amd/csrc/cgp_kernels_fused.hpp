@@ -537,6 +537,7 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
+  const int live = p.N - k * TS;  // rows / columns of this tile that belong to the window
   T *Dv = Bk + 36 * DB * DB;  // Dv[q][x]  = Dinv_jb[x][q]
   T *DvT = Dv + DB * DB;      // DvT[jb & 1][q][c] = Dinv_jb[q][c]
   int bad = 0;
@@ -545,9 +546,14 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
     if (wave == 0) {
       T *Djj = Bk + tri_blk(jb, jb);
       T a[DB], w[DB];
+      if (j0 < live) {
 #pragma unroll
-      for (int c = 0; c < DB; ++c) a[c] = Djj[c * DB + l15];
-      factor_block16<T>(a, w, bad, k * TS + j0, l15);
+        for (int c = 0; c < DB; ++c) a[c] = Djj[c * DB + l15];
+        factor_block16<T>(a, w, bad, k * TS + j0, l15);
+      } else {  // identity padding beyond the window (N not a multiple of 128): nothing to factor
+#pragma unroll
+        for (int c = 0; c < DB; ++c) a[c] = w[c] = (c == l15) ? T(1) : T(0);
+      }
       if (lane < DB) {
         T *dvt = DvT + (jb & 1) * DB * DB;
 #pragma unroll
@@ -945,7 +951,7 @@ __global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
   if (tid == 0) *flag = 0;
   __syncthreads();
   const long long tq = __builtin_amdgcn_s_memtime();
-  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, (p.dbg & 512) ? p.dbgbuf : nullptr);
+  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, (p.dbg & 512) ? p.dbgbuf : nullptr, p.N - k * TS);
   potf2_store<T>(p, At, Dv, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
   if ((p.dbg & 512) && tid == 0 && b == 0) { p.dbgbuf[5] = __builtin_amdgcn_s_memtime() - tq; p.dbgbuf[6] = tq - tstart; }
 }
@@ -1065,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
     }
   if (tid == 0) *flag = 0;
   __syncthreads();
-  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid);
+  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, nullptr, p.N - k * TS);
   potf2_store<T>(p, At, Dv, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
   __threadfence();   // W_k (and L(k,k)) visible device-wide before the step is announced
   __syncthreads();
