@@ -1168,7 +1168,7 @@ extern "C" int cgp_predict_stop_batch(cgp_ctx *c, int ntraj, int M, const double
     return CGP_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t T = ntraj;
-  const size_t nd = T * (2 * (size_t)M + 3 * 225 + 60 + 3 + 2 + 2);  // doubles in, incl. 2 double outputs
+  const size_t nd = T * (2 * (size_t)M + 3 * 225 + 60 + 3 + 4 + 2 + 2);  // doubles in (incl. 4 trig values), 2 double outputs
   double *buf = nullptr;
   int *ibuf = nullptr;
   HIP_TRY(c, hipMalloc((void **)&buf, nd * sizeof(double)));
@@ -1192,6 +1192,20 @@ extern "C" int cgp_predict_stop_batch(cgp_ctx *c, int ntraj, int M, const double
   a.STM = put(STM, T * 225);
   a.Hvec = put(Hvec, T * 60);
   a.pos = put(pos, T * 3);
+  // sines / cosines of the base positions and of the ENU origin on the host: libm's large-argument
+  // paths would otherwise set the kernel's register and scratch footprint
+  std::vector<double> trig(T * 4);
+  for (size_t t = 0; t < T; ++t) {
+    trig[4 * t + 0] = std::sin(pos[3 * t]);
+    trig[4 * t + 1] = std::cos(pos[3 * t]);
+    trig[4 * t + 2] = std::sin(pos[3 * t + 1]);
+    trig[4 * t + 3] = std::cos(pos[3 * t + 1]);
+  }
+  a.trig = put(trig.data(), T * 4);
+  a.origin_trig[0] = std::sin(init_llh[0]);
+  a.origin_trig[1] = std::cos(init_llh[0]);
+  a.origin_trig[2] = std::sin(init_llh[1]);
+  a.origin_trig[3] = std::cos(init_llh[1]);
   a.arrival = put(arrival, T);
   a.now = put(now, T);
   a.stop_cmd = d;
