@@ -56,6 +56,9 @@ struct cgp_ctx {
   void *dpart = nullptr;   // latency schedule: partial tiles [LAT_FITS][slots][SK_MAX][128*128]
   int *dticket = nullptr;  //                   arrival tickets [LAT_FITS][slots]
   int *dwready = nullptr;  //                   published block steps [LAT_FITS]
+  double *la_buf = nullptr;  // cgp_predict_stop_batch staging, grown on demand
+  int *la_ibuf = nullptr;
+  size_t la_nd = 0, la_ni = 0;
   int sk_slots = 0;
   // sliding windows (cgp_window_*)
   WindowArgs win{};
@@ -542,7 +545,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->la_buf, c->la_ibuf};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {
@@ -1169,13 +1172,23 @@ extern "C" int cgp_predict_stop_batch(cgp_ctx *c, int ntraj, int M, const double
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t T = ntraj;
   const size_t nd = T * (2 * (size_t)M + 3 * 225 + 60 + 3 + 4 + 2 + 2);  // doubles in (incl. 4 trig values), 2 double outputs
-  double *buf = nullptr;
-  int *ibuf = nullptr;
-  HIP_TRY(c, hipMalloc((void **)&buf, nd * sizeof(double)));
-  if (hipMalloc((void **)&ibuf, T * 2 * sizeof(int)) != hipSuccess) {
-    (void)hipFree(buf);
-    return CGP_ENOMEM;
+  // staging buffers live in the context and only grow (the replay loop calls this once per tick group)
+  if (nd > c->la_nd) {
+    if (c->la_buf) (void)hipFree(c->la_buf);
+    c->la_buf = nullptr;
+    c->la_nd = 0;
+    if (hipMalloc((void **)&c->la_buf, nd * sizeof(double)) != hipSuccess) return CGP_ENOMEM;
+    c->la_nd = nd;
   }
+  if (T * 2 > c->la_ni) {
+    if (c->la_ibuf) (void)hipFree(c->la_ibuf);
+    c->la_ibuf = nullptr;
+    c->la_ni = 0;
+    if (hipMalloc((void **)&c->la_ibuf, T * 2 * sizeof(int)) != hipSuccess) return CGP_ENOMEM;
+    c->la_ni = T * 2;
+  }
+  double *buf = c->la_buf;
+  int *ibuf = c->la_ibuf;
   hipStream_t s = c->stream;
   double *d = buf;
   LookaheadArgs a{};
@@ -1229,8 +1242,6 @@ extern "C" int cgp_predict_stop_batch(cgp_ctx *c, int ntraj, int M, const double
   if (rc == CGP_OK && !hip_ok(c, hipMemcpyAsync(xy_err, a.xy_err, T * 8, hipMemcpyDeviceToHost, s), "D2H")) rc = CGP_EHIP;
   if (rc == CGP_OK && !hip_ok(c, hipMemcpyAsync(hi.data(), ibuf, T * 2 * sizeof(int), hipMemcpyDeviceToHost, s), "D2H")) rc = CGP_EHIP;
   if (!hip_ok(c, hipStreamSynchronize(s), "sync")) rc = CGP_EHIP;
-  (void)hipFree(buf);
-  (void)hipFree(ibuf);
   if (rc != CGP_OK) return rc;
   for (size_t i = 0; i < T; ++i) {
     fired[i] = hi[i];
