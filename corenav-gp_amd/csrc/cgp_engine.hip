@@ -56,6 +56,7 @@ struct cgp_ctx {
   void *dpart = nullptr;   // latency schedule: partial tiles [LAT_FITS][slots][SK_MAX][128*128]
   int *dticket = nullptr;  //                   arrival tickets [LAT_FITS][slots]
   int *dwready = nullptr;  //                   published block steps [LAT_FITS]
+  double *dmacc = nullptr;  // [max_batch][2][max_m] running predictive sums (throughput schedule, fp64)
   double *la_buf = nullptr;  // cgp_predict_stop_batch staging, grown on demand
   int *la_ibuf = nullptr;
   size_t la_nd = 0, la_ni = 0;
@@ -127,7 +128,8 @@ struct Launcher {
 constexpr int LAT_FITS = 4;  // batches up to this size take the latency schedule
 
 template <typename T> constexpr int upd_lds_bytes() { return 4 * KT * LDST * (int)sizeof(T); }
-template <typename T> constexpr int paneldiag_lds_bytes() { return std::max(upd_lds_bytes<T>(), diag_lds_elems<T>() * (int)sizeof(T)); }
+template <typename T> constexpr int panel_lds_bytes() { return upd_lds_bytes<T>() + TS * (int)sizeof(T); }  // + z of one block column
+template <typename T> constexpr int paneldiag_lds_bytes() { return std::max(panel_lds_bytes<T>(), diag_lds_elems<T>() * (int)sizeof(T)); }
 template <typename T> constexpr int potf2_lds_bytes() {
   return (TS * LDP + 8 * DB * DB + 4 * DB * DB) * (int)sizeof(T) + 16;
 }
@@ -139,7 +141,7 @@ template <typename T> int set_lds_attrs() {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trmm<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, panel_lds_bytes<T>()) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, paneldiag_lds_bytes<T>()) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
@@ -241,6 +243,21 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // default: k_diag_lean (two diagonal workgroups per CU: with >= 2 fits per CU one's factorisation
   // latency runs under the other's MFMA loop; 3.8 vs 5.1 ms per 512 fits).  CGP_DIAG=fat: k_diag.
   const bool lean_diag = diag_env != 2;
+  // fp64 throughput schedule: the predictive sums V z and |V|^2 accumulate inside k_panel (block column
+  // k - 1 while it streams through the row fragments of step k); k_finalize then only adds the last
+  // block column instead of reading all of V.  CGP_ACC=off: k_finalize reads V (A/B).
+  static const bool acc_off = [] { const char *e = getenv("CGP_ACC"); return e && std::string(e) == "off"; }();
+  const bool use_acc = sizeof(T) == 8 && !classic && !latency && !acc_off && a.M > 0 && !a.xid;
+  if (use_acc) {
+    const size_t half = (size_t)batch * a.M;
+    for (int g = 0, g0 = 0; g < G; g0 += gb[g], ++g) {
+      HIP_TRY(c, hipMemsetAsync(c->dmacc + (size_t)g0 * a.M, 0, sizeof(double) * gb[g] * a.M, gs[g]));
+      HIP_TRY(c, hipMemsetAsync(c->dmacc + half + (size_t)g0 * a.M, 0, sizeof(double) * gb[g] * a.M, gs[g]));
+      ga[g].macc = c->dmacc + (size_t)g0 * a.M;
+      ga[g].vacc = c->dmacc + half + (size_t)g0 * a.M;
+    }
+  }
+  const int panel_lds = panel_lds_bytes<T>();
   static const bool overlap = [] { const char *e = getenv("CGP_SCHED"); return e && std::string(e) == "overlap"; }();
   if (overlap && in_rows && G == 1 && !c->prof && a.NT >= 2) {
     // Look-ahead schedule on two streams: the panel launch of step k is cut into P1 = the tile right
@@ -265,13 +282,13 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       const int n2 = (has_p1 ? nin - 1 : 0) + a.ET;                // P2: everything but the first tile
       if (has_p1) {
         if (k > 0) HIP_TRY(c, hipStreamWaitEvent(sA, ev(3 * (k - 1) + 2), 0));  // P2(k-1)
-        hipLaunchKernelGGL((k_panel<T, false>), dim3(1, B), dim3(256), upd_lds, sA, a1, k);
+        hipLaunchKernelGGL((k_panel<T, false>), dim3(1, B), dim3(256), panel_lds, sA, a1, k);
         HIP_TRY(c, hipEventRecord(ev(3 * k + 1), sA));             // evP1[k]
       }
       HIP_TRY(c, hipStreamWaitEvent(sB, ev(3 * k), 0));            // diag(k)
       if (k > 0 && NT - k >= 1) HIP_TRY(c, hipStreamWaitEvent(sB, ev(3 * (k - 1) + 1), 0));  // P1(k-1)
       FitArgs ap = has_p1 ? a2 : a1;
-      hipLaunchKernelGGL((k_panel<T, false>), dim3(n2, B), dim3(256), upd_lds, sB, ap, k);
+      hipLaunchKernelGGL((k_panel<T, false>), dim3(n2, B), dim3(256), panel_lds, sB, ap, k);
       HIP_TRY(c, hipEventRecord(ev(3 * k + 2), sB));               // evP2[k]
       if (k + 1 < NT) {
         if (!has_p1 && k > 0) HIP_TRY(c, hipStreamWaitEvent(sA, ev(3 * (k - 1) + 2), 0));
@@ -353,7 +370,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
         if (fuse_next)
           hipLaunchKernelGGL((k_panel<T, true>), dim3(gx_t, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ga[g], k);
         else
-          hipLaunchKernelGGL((k_panel<T, false>), dim3(gx_t, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
+          hipLaunchKernelGGL((k_panel<T, false>), dim3(gx_t, gb[g]), dim3(256), panel_lds, gs[g], ga[g], k);
         L[g].end();
       }
     }
@@ -525,6 +542,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc((void **)&c->dticket, sizeof(int) * LAT_FITS * c->sk_slots) == hipSuccess;
   ok = ok && hipMemset(c->dticket, 0, sizeof(int) * LAT_FITS * c->sk_slots) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dwready, sizeof(int) * LAT_FITS) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->dmacc, sizeof(double) * 2 * B * std::max(c->max_m, 1)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->ddbg, 64 * sizeof(long long)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dprep, B * PREP_N * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dlogml, B * sizeof(double)) == hipSuccess;
@@ -545,7 +563,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->la_buf, c->la_ibuf};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->la_buf, c->la_ibuf, c->dmacc};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {

@@ -57,6 +57,9 @@ struct FitArgs {
   size_t alpha_stride;
   int N, d, M, NT, ET, kernel_id, include_noise;
   int rows_from_extra;   // 1: only the extra (test/y) row tiles are processed (predict after fit)
+  double *macc, *vacc;   // [batch][M] running sums V_m . z and |V_m|^2 over the block columns already
+                         // final (fp64 throughput schedule: accumulated inside k_panel); null = k_finalize
+                         // reads the whole of V
   int tile_off;          // first block-tile index of this launch (split panel launches)
   int xid;               // 1: the M (= N) "test rows" are the identity, so the extra block becomes (L^-1)^T (gradient mode)
   double *gpart;         // [batch][pairs][GRAD_N] per-tile-pair partial sums of k_grad
@@ -794,7 +797,13 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs p, int do_logml) {
     const int m = blockIdx.x * RB + ml;
     double smu = 0, sq = 0;
     if (m < M) {
-      for (int c = g; c < NP; c += NG) {
+      // with accumulators only the last block column is still to be added
+      const int c0 = p.macc ? (p.NT - 1) * TS : 0;
+      if (p.macc && g == 0) {
+        smu = p.macc[(size_t)b * M + m];
+        sq = p.vacc[(size_t)b * M + m];
+      }
+      for (int c = c0 + g; c < NP; c += NG) {
         const double v = (double)Lw[(size_t)c * ld + rb + m];
         const double z = (double)Lw[(size_t)c * ld + rb + M];
         smu += v * z;

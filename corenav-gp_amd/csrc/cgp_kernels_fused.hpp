@@ -191,9 +191,14 @@ __device__ __forceinline__ void rdirect_prologue(RowFrag<T> &f, const T *gR, siz
 // ISSUE / LAST are compile-time so that no data-dependent branch sits between a load and its use:
 // the compiler's own s_waitcnt insertion then counts the loads in flight exactly (with a branch it
 // falls back to vmcnt(0) at the first use of the row fragments, which serialises the pipeline).
-template <typename T, int S, bool ISSUE, bool LAST>
+// ACC: the chunk belongs to the newest block column; besides feeding the MFMAs its row fragments are
+// folded into the running sums  ms[j] += V z,  ms[2 + j] += V^2  (rows 2 l15 + j; zs = z of that block
+// column, 16 values per chunk) -- the predictive mean / variance accumulate here instead of in a
+// separate pass over V.
+template <typename T, int S, bool ISSUE, bool LAST, bool ACC = false>
 __device__ __forceinline__ void rdirect_step(typename Prec<T>::acc_t (&acc)[NCB][2], RowFrag<T> &f, const T *gRl, size_t ldR,
-                                             const T *gC, size_t ldC, int c, T *smem, int lane, int wave) {
+                                             const T *gC, size_t ldC, int c, T *smem, int lane, int wave,
+                                             const T *zs = nullptr, T *ms = nullptr) {
   using P = Prec<T>;
   constexpr int CH = KT * LDST;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -202,6 +207,11 @@ __device__ __forceinline__ void rdirect_step(typename Prec<T>::acc_t (&acc)[NCB]
   else if constexpr (sizeof(T) == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
   static_assert(cpanel_loads<double>() + KT / 4 == 8 && cpanel_loads<float>() + KT / 4 == 12, "vmcnt constants");
+  // The row fragments were loaded by raw instructions two steps ago; to the compiler they were ready
+  // at once.  Pin every use of this step's fragments behind the wait above (volatile asm statements
+  // keep their order), or a use that depends on nothing else -- the V^2 sums -- is hoisted over it.
+#pragma unroll
+  for (int ks = 0; ks < KT / 4; ++ks) asm volatile("" : "+v"(f.r[S][ks]));
   if constexpr (ISSUE) {
     cpanel_stage<T>(gC, ldC, c + 2, smem + ((S + 2) & 3) * CH, lane, wave);
     rfrag_load<T, (S + 2) & 3>(f, gRl, ldR, c + 2, lq);
@@ -218,6 +228,13 @@ __device__ __forceinline__ void rdirect_step(typename Prec<T>::acc_t (&acc)[NCB]
       for (int cb = 0; cb < NCB; ++cb) fa[(ks + 1) & 1][cb] = cur[(ks + 1) * 4 * LDST + cb * DB];
     }
     const typename RowFrag<T>::vec2 fb = f.r[S][ks];
+    if constexpr (ACC) {
+      const T zv = zs[ks * 4 + lq];
+      ms[0] = __builtin_fma(fb[0], zv, ms[0]);
+      ms[1] = __builtin_fma(fb[1], zv, ms[1]);
+      ms[2] = __builtin_fma(fb[0], fb[0], ms[2]);
+      ms[3] = __builtin_fma(fb[1], fb[1], ms[3]);
+    }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
       acc[cb][0] = P::mfma(fa[ks & 1][cb], fb[0], acc[cb][0]);
@@ -228,22 +245,28 @@ __device__ __forceinline__ void rdirect_step(typename Prec<T>::acc_t (&acc)[NCB]
 
 template <typename T>
 __device__ __forceinline__ void mfma_rowpanel_loop_rdirect(typename Prec<T>::acc_t (&acc)[NCB][2], RowFrag<T> &f, const T *gR,
-                                                           size_t ldR, const T *gC, size_t ldC, int nchunk, T *smem, int tid) {
+                                                           size_t ldR, const T *gC, size_t ldC, int nchunk, T *smem, int tid,
+                                                           const T *zs, T (&ms)[4]) {
   if (nchunk <= 0) return;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const T *gRl = gR + wave * 32 + 2 * (lane & 15);
   int c = 0;
-  for (; c + 4 < nchunk; c += 4) {
+  for (; c + 8 < nchunk; c += 4) {
     rdirect_step<T, 0, true, false>(acc, f, gRl, ldR, gC, ldC, c, smem, lane, wave);
     rdirect_step<T, 1, true, false>(acc, f, gRl, ldR, gC, ldC, c + 1, smem, lane, wave);
     rdirect_step<T, 2, true, false>(acc, f, gRl, ldR, gC, ldC, c + 2, smem, lane, wave);
     rdirect_step<T, 3, true, false>(acc, f, gRl, ldR, gC, ldC, c + 3, smem, lane, wave);
   }
-  rdirect_step<T, 0, true, false>(acc, f, gRl, ldR, gC, ldC, c, smem, lane, wave);
-  rdirect_step<T, 1, true, false>(acc, f, gRl, ldR, gC, ldC, c + 1, smem, lane, wave);
-  rdirect_step<T, 2, false, false>(acc, f, gRl, ldR, gC, ldC, c + 2, smem, lane, wave);
-  rdirect_step<T, 3, false, true>(acc, f, gRl, ldR, gC, ldC, c + 3, smem, lane, wave);
+  // the last 8 chunks are the newest block column (nchunk is a multiple of 8): sums ride along
+  rdirect_step<T, 0, true, false, true>(acc, f, gRl, ldR, gC, ldC, c, smem, lane, wave, zs, ms);
+  rdirect_step<T, 1, true, false, true>(acc, f, gRl, ldR, gC, ldC, c + 1, smem, lane, wave, zs + KT, ms);
+  rdirect_step<T, 2, true, false, true>(acc, f, gRl, ldR, gC, ldC, c + 2, smem, lane, wave, zs + 2 * KT, ms);
+  rdirect_step<T, 3, true, false, true>(acc, f, gRl, ldR, gC, ldC, c + 3, smem, lane, wave, zs + 3 * KT, ms);
+  rdirect_step<T, 0, true, false, true>(acc, f, gRl, ldR, gC, ldC, c + 4, smem, lane, wave, zs + 4 * KT, ms);
+  rdirect_step<T, 1, true, false, true>(acc, f, gRl, ldR, gC, ldC, c + 5, smem, lane, wave, zs + 5 * KT, ms);
+  rdirect_step<T, 2, false, false, true>(acc, f, gRl, ldR, gC, ldC, c + 6, smem, lane, wave, zs + 6 * KT, ms);
+  rdirect_step<T, 3, false, true, true>(acc, f, gRl, ldR, gC, ldC, c + 7, smem, lane, wave, zs + 7 * KT, ms);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -864,13 +887,40 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
   const int nchunk = (k * TS) / KT;
   if constexpr (RDIRECT && sizeof(T) == 8) {
     RowFrag<T> rf;
+    // running predictive sums (extra tiles, throughput schedule): z of the newest block column
+    // (k - 1) goes to LDS behind the chunk ring; zeros when nothing is to be accumulated
+    const bool accm = p.macc != nullptr && rt >= p.NT && k > 0;
+    T *zs = smem + 4 * KT * LDST;
+    if (tid < TS) zs[tid] = accm ? Lw[(size_t)((k - 1) * TS + tid) * ld + (size_t)p.NT * TS + p.M] : T(0);
+    T ms[4] = {T(0), T(0), T(0), T(0)};
     {
       GramPre<T> gp;
       gram_prefetch<T>(p, b, k, rt, tid, gp);
       rdirect_prologue<T>(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
       gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
     }
-    mfma_rowpanel_loop_rdirect<T>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+    mfma_rowpanel_loop_rdirect<T>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
+    if (accm) {
+      // a row's 128 columns are spread over the four 16-lane groups: fold them, then the lanes of
+      // group 0 add to the fit's accumulators (this workgroup is the only writer of its rows)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ms[q] += __shfl_xor(ms[q], 16);
+        ms[q] += __shfl_xor(ms[q], 32);
+      }
+      const int lane = tid & 63;
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int m = (rt - p.NT) * TS + wave * 32 + 2 * lane + j;
+          if (m < p.M) {
+            p.macc[(size_t)b * p.M + m] += (double)ms[j];
+            p.vacc[(size_t)b * p.M + m] += (double)ms[2 + j];
+          }
+        }
+      }
+    }
   } else {
     {
       GramPre<T> gp;

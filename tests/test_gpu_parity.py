@@ -269,7 +269,7 @@ def test_latency_schedule_is_deterministic(engine):
 
 @pytest.mark.parametrize("env", [{"CGP_SCHED": "classic"}, {"CGP_SCHED": "overlap"}, {"CGP_SCHED": "fuseddiag"},
                                  {"CGP_SCHED": "throughput"}, {"CGP_SCHED": "throughput", "CGP_DIAG": "fat"},
-                                 {"CGP_SK_TRMM": "fused"}],
+                                 {"CGP_SK_TRMM": "fused"}, {"CGP_SCHED": "throughput", "CGP_ACC": "off"}],
                          ids=lambda e: "-".join(e.values()))
 def test_alternate_schedules_match_oracle(env):
     """The schedules kept behind CGP_SCHED / CGP_DIAG for A/B measurements (read once per process, hence
