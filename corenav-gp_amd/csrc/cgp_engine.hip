@@ -243,11 +243,11 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // default: k_diag_lean (two diagonal workgroups per CU: with >= 2 fits per CU one's factorisation
   // latency runs under the other's MFMA loop; 3.8 vs 5.1 ms per 512 fits).  CGP_DIAG=fat: k_diag.
   const bool lean_diag = diag_env != 2;
-  // fp64 throughput schedule: the predictive sums V z and |V|^2 accumulate inside k_panel (block column
+  // throughput schedule: the predictive sums V z and |V|^2 accumulate inside k_panel (block column
   // k - 1 while it streams through the row fragments of step k); k_finalize then only adds the last
   // block column instead of reading all of V.  CGP_ACC=off: k_finalize reads V (A/B).
   static const bool acc_off = [] { const char *e = getenv("CGP_ACC"); return e && std::string(e) == "off"; }();
-  const bool use_acc = sizeof(T) == 8 && !classic && !latency && !acc_off && a.M > 0 && !a.xid;
+  const bool use_acc = !classic && !latency && !acc_off && a.M > 0 && !a.xid;
   if (use_acc) {
     const size_t half = (size_t)batch * a.M;
     for (int g = 0, g0 = 0; g < G; g0 += gb[g], ++g) {

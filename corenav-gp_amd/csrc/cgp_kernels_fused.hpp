@@ -48,9 +48,12 @@ __device__ __forceinline__ void stage_first_chunk(const T *gR, size_t ldR, const
   }
 }
 
+// zs / ms (optional): z of the newest block column (the last 8 chunks) and the running sums
+// ms[j] += V z, ms[2 + j] += V^2 for rows 2 l15 + j, as in rdirect_step.
 template <typename T, bool PRESTAGED = false>
 __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc)[NCB][2], const T *gR, size_t ldR,
-                                                   const T *gC, size_t ldC, int nchunk, T *smem, int tid) {
+                                                   const T *gC, size_t ldC, int nchunk, T *smem, int tid,
+                                                   const T *zs = nullptr, T *ms = nullptr) {
   using P = Prec<T>;
   using vec8 = T __attribute__((ext_vector_type(8)));
   using vec2 = T __attribute__((ext_vector_type(2)));
@@ -59,7 +62,8 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
 
-  auto compute = [&](const T *cur) {
+  auto compute = [&](const T *cur, int c) {
+    const T *zc = (zs && c >= nchunk - TS / KT) ? zs + (c - (nchunk - TS / KT)) * KT : nullptr;  // block-uniform
 #pragma unroll
     for (int ks = 0; ks < KT / 4; ++ks) {
       T fa[NCB];
@@ -67,6 +71,13 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) fa[cb] = ra[cb * DB];
       const vec2 fb = *reinterpret_cast<const vec2 *>(cur + (ks * 4 + lq) * LDST + wave * 32 + 2 * l15);
+      if (zc) {
+        const T zv = zc[ks * 4 + lq];
+        ms[0] = __builtin_fma(fb[0], zv, ms[0]);
+        ms[1] = __builtin_fma(fb[1], zv, ms[1]);
+        ms[2] = __builtin_fma(fb[0], fb[0], ms[2]);
+        ms[3] = __builtin_fma(fb[1], fb[1], ms[3]);
+      }
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         acc[cb][0] = P::mfma(fa[cb], fb[0], acc[cb][0]);
@@ -92,7 +103,7 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
     __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
       if (c + 1 < nchunk) stage(smem + ((c + 1) & 1) * 2 * CH, c + 1);
-      compute(smem + (c & 1) * 2 * CH);
+      compute(smem + (c & 1) * 2 * CH, c);
       __syncthreads();
     }
   } else {
@@ -112,7 +123,7 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
         pr = *reinterpret_cast<const vec8 *>(gR + (size_t)((c + 1) * KT + sc) * ldR);
         pc = *reinterpret_cast<const vec8 *>(gC + (size_t)((c + 1) * KT + sc) * ldC);
       }
-      compute(smem + (c & 1) * 2 * CH);
+      compute(smem + (c & 1) * 2 * CH, c);
       if (c + 1 < nchunk) {
         T *nxt = smem + ((c + 1) & 1) * 2 * CH;
         *reinterpret_cast<vec8 *>(nxt + sc * LDST + sr) = pr;
@@ -885,14 +896,14 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
   acc_t acc[NCB][2];
   const T *gR = Lw + (size_t)rt * TS, *gC = Lw + (size_t)k * TS;
   const int nchunk = (k * TS) / KT;
+  // running predictive sums (extra tiles, throughput schedule): z of the newest block column
+  // (k - 1) goes to LDS behind the chunk ring; zeros when nothing is to be accumulated
+  const bool accm = p.macc != nullptr && rt >= p.NT && k > 0;
+  T *zs = smem + 4 * KT * LDST;
+  if (tid < TS) zs[tid] = accm ? Lw[(size_t)((k - 1) * TS + tid) * ld + (size_t)p.NT * TS + p.M] : T(0);
+  T ms[4] = {T(0), T(0), T(0), T(0)};
   if constexpr (RDIRECT && sizeof(T) == 8) {
     RowFrag<T> rf;
-    // running predictive sums (extra tiles, throughput schedule): z of the newest block column
-    // (k - 1) goes to LDS behind the chunk ring; zeros when nothing is to be accumulated
-    const bool accm = p.macc != nullptr && rt >= p.NT && k > 0;
-    T *zs = smem + 4 * KT * LDST;
-    if (tid < TS) zs[tid] = accm ? Lw[(size_t)((k - 1) * TS + tid) * ld + (size_t)p.NT * TS + p.M] : T(0);
-    T ms[4] = {T(0), T(0), T(0), T(0)};
     {
       GramPre<T> gp;
       gram_prefetch<T>(p, b, k, rt, tid, gp);
@@ -900,27 +911,6 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
       gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
     }
     mfma_rowpanel_loop_rdirect<T>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
-    if (accm) {
-      // a row's 128 columns are spread over the four 16-lane groups: fold them, then the lanes of
-      // group 0 add to the fit's accumulators (this workgroup is the only writer of its rows)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        ms[q] += __shfl_xor(ms[q], 16);
-        ms[q] += __shfl_xor(ms[q], 32);
-      }
-      const int lane = tid & 63;
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-      if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int m = (rt - p.NT) * TS + wave * 32 + 2 * lane + j;
-          if (m < p.M) {
-            p.macc[(size_t)b * p.M + m] += (double)ms[j];
-            p.vacc[(size_t)b * p.M + m] += (double)ms[2 + j];
-          }
-        }
-      }
-    }
   } else {
     {
       GramPre<T> gp;
@@ -928,7 +918,28 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
       if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
       gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
     }
-    mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+    mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, accm ? zs : nullptr, ms);
+  }
+  if (accm) {
+    // a row's 128 columns are spread over the four 16-lane groups: fold them, then the lanes of
+    // group 0 add to the fit's accumulators (this workgroup is the only writer of its rows)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ms[q] += __shfl_xor(ms[q], 16);
+      ms[q] += __shfl_xor(ms[q], 32);
+    }
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = (rt - p.NT) * TS + wave * 32 + 2 * lane + j;
+        if (m < p.M) {
+          p.macc[(size_t)b * p.M + m] += (double)ms[j];
+          p.vacc[(size_t)b * p.M + m] += (double)ms[2 + j];
+        }
+      }
+    }
   }
   __syncthreads();  // every wave is done with the staged inputs before W_k overwrites them
   if (!(p.dbg & 64)) trmm_in_registers<T>(p, acc, smem, b, k, tid);
