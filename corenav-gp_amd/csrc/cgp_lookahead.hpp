@@ -177,9 +177,12 @@ __global__ __launch_bounds__(64 * LA_WAVES) void k_lookahead(LookaheadArgs p) {
       const double cov = ((o0 - est) * (o0 - est) + (o1 - est) * (o1 - est) + (o2 - est) * (o2 - est)) / 3.0;
       double R2[4] = {fmax(0.03 * 0.03, cov * cov), fmax(0.03 * 0.03, cov * cov), fmax(0.05 * 0.05, cov * cov), 0.05 * 0.05};
       double R[16];  // R = 25 R1 R2 R1'  (every lane computes it: 4x4)
+#pragma unroll
       for (int r = 0; r < 4; ++r)
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
           double s = 0.0;
+#pragma unroll
           for (int q = 0; q < 4; ++q) s += R1[r * 4 + q] * R2[q] * R1[c * 4 + q];
           R[r * 4 + c] = 25.0 * s;
         }
@@ -187,33 +190,61 @@ __global__ __launch_bounds__(64 * LA_WAVES) void k_lookahead(LookaheadArgs p) {
       la_mm<false>(H, PHt, sc, LA_NM, LA_NS, LA_NM, lane);      // H P H' (4 x 4) -> sc[0..15]
       // S^-1 by Gauss-Jordan with partial pivoting, redundantly in every lane's registers
       double a[4][8];
+#pragma unroll
       for (int r = 0; r < 4; ++r)
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
           a[r][c] = sc[r * 4 + c] + R[r * 4 + c];
           a[r][4 + c] = (r == c) ? 1.0 : 0.0;
         }
+      // fully unrolled with compile-time indices (the pivot row is swapped in by selects), so the
+      // 4 x 8 tableau stays in registers instead of scratch memory
+#pragma unroll
       for (int c = 0; c < 4; ++c) {
         int piv = c;
-        for (int r = c + 1; r < 4; ++r)
-          if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
-        if (piv != c)
-          for (int j = 0; j < 8; ++j) {
-            const double t = a[c][j];
-            a[c][j] = a[piv][j];
-            a[piv][j] = t;
+        double best = fabs(a[c][c]);
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {
+          const double v = fabs(a[r][c]);
+          if (v > best) {   // same rule as the host path: first strictly larger magnitude wins
+            best = v;
+            piv = r;
           }
+        }
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {
+          const bool sw = piv == r;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const double t = a[c][j], u = a[r][j];
+            a[c][j] = sw ? u : t;
+            a[r][j] = sw ? t : u;
+          }
+        }
         const double d = 1.0 / a[c][c];
+#pragma unroll
         for (int j = 0; j < 8; ++j) a[c][j] *= d;
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (r == c) continue;
           const double f = a[r][c];
-          if (f != 0.0)
-            for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[r][j] = (f != 0.0) ? a[r][j] - f * a[c][j] : a[r][j];
         }
       }
       __builtin_amdgcn_wave_barrier();
-      if (lane < 16) sc[16 + lane] = a[lane >> 2][4 + (lane & 3)];  // Si
-      if (lane < 16) sc[32 + lane] = R[lane];
+      {
+        double siv = 0.0, rv = 0.0;   // lane e < 16 picks Si[e / 4][e % 4] and R[e] with static indices
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          siv = (lane == e) ? a[e >> 2][4 + (e & 3)] : siv;
+          rv = (lane == e) ? R[e] : rv;
+        }
+        if (lane < 16) {
+          sc[16 + lane] = siv;  // Si
+          sc[32 + lane] = rv;
+        }
+      }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       la_mm<false>(PHt, sc + 16, K, LA_NS, LA_NM, LA_NM, lane);   // K = P H' S^-1  (15 x 4)   :90
