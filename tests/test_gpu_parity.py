@@ -153,6 +153,25 @@ def test_config2_full_size_fp64(engine):
     assert relmax(mean2[::-1], mean) < 1e-12 and releach(var2[::-1], var) < 1e-12
 
 
+def test_config2_full_size_throughput_schedule(engine):
+    """BASELINE configs[1] shape (N=2048 d=6 ARD fp64, M=599) through the throughput schedule (5 fits):
+    two of them against the numpy oracle, all of them through the variance floor and a permutation
+    property (a fit's outputs do not depend on its slot in the batch)."""
+    kid, X, y, Xs, th, _ = synth.config(2, batch=5)
+    ctx = engine.Context(max_n=2048, max_m=599, max_d=6, max_batch=5)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not info.any()
+    for b in (0, 4):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        assert relmax(mean[b], omu) < TOL64 and releach(var[b], ovar) < TOL64
+        assert abs(logml[b] - f.logml) <= TOL64 * abs(f.logml)
+    assert np.all(var >= th[:, -1:])
+    perm = np.array([3, 0, 4, 1, 2])
+    rc, m2, v2, l2, _ = ctx.fit_predict_batch(X[perm], y[perm], Xs[perm], th[perm], kid)
+    assert np.array_equal(m2, mean[perm]) and np.array_equal(v2, var[perm]) and np.array_equal(l2, logml[perm])
+
+
 def test_batch_matches_single_and_oracle(engine):
     kid, X, y, Xs, th, _ = synth.config(2, batch=3, N=384)
     ctx = engine.Context(max_n=384, max_m=599, max_d=6, max_batch=3)
