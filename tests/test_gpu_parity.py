@@ -46,6 +46,7 @@ def check_fit_predict(engine, kid, theta, X, y, Xs, dtype, tol, include_noise=Tr
 
 
 SK = ["sk_se_iso_n256_d3", "sk_se_ard_n2_d1", "sk_se_ard_n15_d3", "sk_se_ard_n134_d6", "sk_se_ard_n256_d6",
+      "sk_se_ard_n2048_d6",
       "closed_n1_se", "closed_n2_rbfbrownian"]
 
 

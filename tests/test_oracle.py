@@ -9,7 +9,8 @@ import pytest
 from conftest import load_golden
 from oracle import gp_oracle as go
 
-SK = ["sk_se_iso_n256_d3", "sk_se_ard_n2_d1", "sk_se_ard_n15_d3", "sk_se_ard_n134_d6", "sk_se_ard_n256_d6"]
+SK = ["sk_se_iso_n256_d3", "sk_se_ard_n2_d1", "sk_se_ard_n15_d3", "sk_se_ard_n134_d6", "sk_se_ard_n256_d6",
+      "sk_se_ard_n2048_d6"]
 CLOSED = ["closed_n1_se", "closed_n2_rbfbrownian"]
 
 

@@ -139,6 +139,10 @@ def main():
         Xn, yn, Xsn = synth.window(n, d, m, seed=synth.SEED_BASE + 10 * n + d)
         theta = synth.theta_for(go.KERNEL_SE_ARD, d, yn if n > 2 else np.array([0.3, -0.2]))
         sklearn_case(f"sk_se_ard_{tag}", go.KERNEL_SE_ARD, Xn, yn, Xsn, theta)
+    # BASELINE configs[1] at full size (N=2048, d=6 ARD, M=599): the headline workload pinned by an
+    # independent implementation
+    kid, X, y, Xs, th, _ = synth.config(2)
+    sklearn_case("sk_se_ard_n2048_d6", kid, X[0], y[0], Xs[0], th[0])
     slipval_window()
     restated_cases()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
