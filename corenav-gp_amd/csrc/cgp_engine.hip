@@ -22,6 +22,7 @@
 using namespace cgp;
 
 static_assert(CGP_MAX_D == MAXD, "header / kernel MAXD mismatch");
+static_assert(CGP_DEBUG_SLOTS == DBG_SLOTS, "header / kernel debug slot mismatch");
 static_assert(CGP_MAX_THETA == MAX_THETA, "header / kernel MAX_THETA mismatch");
 
 namespace {
@@ -57,6 +58,10 @@ struct cgp_ctx {
   int *dticket = nullptr;  //                   arrival tickets [LAT_FITS][slots]
   int *dwready = nullptr;  //                   published block steps [LAT_FITS]
   double *dmacc = nullptr;  // [max_batch][2][max_m] running predictive sums (throughput schedule, fp64)
+  // cgp_fit_predict_batch staging, grown on demand and kept: pinned host buffers (hipHostMalloc) so the
+  // H2D / D2H copies are real asynchronous DMA, and a raw fp64 device buffer the pack kernels read
+  void *pin_in = nullptr, *pin_out = nullptr, *draw = nullptr;
+  size_t pin_in_cap = 0, pin_out_cap = 0, draw_cap = 0;
   double *la_buf = nullptr;  // cgp_predict_stop_batch staging, grown on demand
   int *la_ibuf = nullptr;
   size_t la_nd = 0, la_ni = 0;
@@ -127,6 +132,7 @@ struct Launcher {
 
 constexpr int LAT_FITS = 4;  // batches up to this size take the latency schedule
 
+inline size_t alpha_lds_bytes(int NT) { return (size_t)(NT * TS + TS) * sizeof(double); }
 template <typename T> constexpr int upd_lds_bytes() { return 4 * KT * LDST * (int)sizeof(T); }
 template <typename T> constexpr int panel_lds_bytes() { return upd_lds_bytes<T>() + TS * (int)sizeof(T); }  // + z of one block column
 template <typename T> constexpr int paneldiag_lds_bytes() { return std::max(panel_lds_bytes<T>(), diag_lds_elems<T>() * (int)sizeof(T)); }
@@ -134,32 +140,41 @@ template <typename T> constexpr int potf2_lds_bytes() {
   return (TS * LDP + 8 * DB * DB + 4 * DB * DB) * (int)sizeof(T) + 16;
 }
 
-template <typename T> int set_lds_attrs() {
-  static bool done = false;
-  if (done) return 0;
+// hipFuncSetAttribute applies to the CURRENT device's function object: called from cgp_create after
+// hipSetDevice, once per (device, dtype).
+template <typename T> int set_lds_attrs(int device) {
+  static bool done[64] = {false};
+  if (device >= 0 && device < 64 && done[device]) return 0;
   const int upd = upd_lds_bytes<T>(), tile = potf2_lds_bytes<T>();
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_update<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trmm<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, panel_lds_bytes<T>()) != hipSuccess) return -1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, paneldiag_lds_bytes<T>()) != hipSuccess) return -1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sk<T>), hipFuncAttributeMaxDynamicSharedMemorySize, tile) != hipSuccess) return -1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trmm_sk<T>), hipFuncAttributeMaxDynamicSharedMemorySize, upd) != hipSuccess) return -1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag_lean<T>), hipFuncAttributeMaxDynamicSharedMemorySize, paneldiag_lds_bytes<T>()) != hipSuccess) return -1;
-  done = true;
+  auto set = [](const void *fn, int bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; };
+  bool ok = true;
+  ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, false>), panel_lds_bytes<T>());
+  ok = ok && set(reinterpret_cast<const void *>(&k_grad<T>), upd);
+  ok = ok && set(reinterpret_cast<const void *>(&k_tile_sk<T>), tile);
+  ok = ok && set(reinterpret_cast<const void *>(&k_trmm_sk<T>), upd);
+  ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T>), paneldiag_lds_bytes<T>());
+#ifdef CGP_AB
+  ok = ok && set(reinterpret_cast<const void *>(&k_update<T>), upd);
+  ok = ok && set(reinterpret_cast<const void *>(&k_potf2<T>), tile);
+  ok = ok && set(reinterpret_cast<const void *>(&k_trmm<T>), upd);
+  ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true>), paneldiag_lds_bytes<T>());
+  ok = ok && set(reinterpret_cast<const void *>(&k_diag<T>), tile);
+#endif
+  if (!ok) return -1;
+  if (device >= 0 && device < 64) done[device] = true;
   return 0;
 }
 
 // Algorithmic flops of the update launches of block step k (DESIGN.md "Kernels"): lower-trapezoid
 // entries of block column k times a 2*(k*128)-flop inner product, plus (3d+2) per Gram entry.
+#ifdef CGP_AB
 double update_flops(int N, int M, int d, int k, bool in_rows, int batch) {
   const double w = std::min(TS, N - k * TS);
   const double rows_in = in_rows ? ((double)(N - k * TS) * w - w * (w - 1) / 2.0) : 0.0;
   const double rows_ex = (double)(M + 1) * w;
   return batch * ((rows_in + rows_ex) * 2.0 * (double)(k * TS) + (3.0 * d + 2.0) * (rows_in + (double)M * w));
 }
+#endif
 double trsm_flops(int N, int M, int k, bool in_rows, int batch) {
   const double w = std::min(TS, N - k * TS);
   const double rows = (in_rows ? std::max(0, N - (k + 1) * TS) : 0) + (M + 1);
@@ -201,23 +216,64 @@ template <typename T> FitArgs group_view(const FitArgs &a, int g0) {
   return v;
 }
 
+// A/B switches of the schedule.  The shipped library has ONE schedule pair (throughput: k_diag_lean +
+// k_panel with running predictive sums; latency: k_tile_sk + k_trmm_sk for <= LAT_FITS fits); the
+// alternatives measured in DESIGN.md (classic three-launch, two-stream overlap, fused next diagonal,
+// fat diagonal, finalize without accumulators, fused trmm) exist only in a -DCGP_AB build, where the
+// environment selects them once per process.
+struct SchedSwitches {
+  bool no_latency = false, classic = false, fuse_next_diag = false, overlap = false, fat_diag = false, acc_off = false,
+       sk_fused_trmm = false;
+};
+const SchedSwitches &sched_switches() {
+  static const SchedSwitches sw = [] {
+    SchedSwitches w;
+    // CGP_SCHED=throughput is honoured by every build: the tests use it to run the throughput schedule
+    // on a handful of fits.
+    const char *e = getenv("CGP_SCHED");
+    const std::string sch = e ? e : "";
+    w.no_latency = sch == "throughput";
+#ifdef CGP_AB
+    w.no_latency = w.no_latency || sch == "classic" || sch == "overlap" || sch == "fuseddiag";
+    w.classic = sch == "classic";
+    w.fuse_next_diag = sch == "fuseddiag";
+    w.overlap = sch == "overlap";
+    const char *dg = getenv("CGP_DIAG");
+    w.fat_diag = dg && std::string(dg) == "fat";
+    const char *ac = getenv("CGP_ACC");
+    w.acc_off = ac && std::string(ac) == "off";
+    const char *tk = getenv("CGP_SK_TRMM");
+    w.sk_fused_trmm = tk && std::string(tk) == "fused";
+#endif
+    return w;
+  }();
+  return sw;
+}
+
+template <typename T> void launch_diag(const FitArgs &a, int nfits, int k, bool fat, hipStream_t s) {
+#ifdef CGP_AB
+  if (fat) {
+    hipLaunchKernelGGL(k_diag<T>, dim3(nfits), dim3(256), potf2_lds_bytes<T>(), s, a, k);
+    return;
+  }
+#endif
+  (void)fat;
+  hipLaunchKernelGGL(k_diag_lean<T>, dim3(nfits), dim3(256), paneldiag_lds_bytes<T>(), s, a, k);
+}
+
 // Enqueue the whole schedule for `batch` fits.  The batch is cut into up to c->nstreams contiguous
 // groups, one worker stream each, forked from / joined to the caller's stream `s` with events; the
 // launches are issued step-interleaved so every stream always has work queued.
 // in_rows = false: predict after fit (only the extra row tiles).
 template <typename T>
 int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha, hipStream_t s) {
-  if (set_lds_attrs<T>() != 0) {
-    c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
-    return CGP_EHIP;
-  }
+  const SchedSwitches &sw = sched_switches();
   a.rows_from_extra = in_rows ? 0 : 1;
   const int upd_lds = upd_lds_bytes<T>();
   const int tile_lds = potf2_lds_bytes<T>();
   int G = std::max(1, std::min(std::min(c->nstreams, (int)cgp_ctx::kMaxStreams), batch));
   if (c->prof || !in_rows) G = 1;  // per-kernel timing wants isolated launches
-  static const bool no_latency = [] { const char *e = getenv("CGP_SCHED"); return e && (std::string(e) == "throughput" || std::string(e) == "classic" || std::string(e) == "overlap" || std::string(e) == "fuseddiag"); }();
-  const bool latency = !no_latency && batch <= LAT_FITS && a.NT >= 3;
+  const bool latency = !sw.no_latency && batch <= LAT_FITS && a.NT >= 3;
   if (latency) G = 1;
   std::vector<FitArgs> ga(G);
   std::vector<int> gb(G);
@@ -237,17 +293,10 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   for (int g = 0; g < G; ++g) L.push_back(Launcher{c, gs[g]});
   if (in_rows)
     for (int g = 0; g < G; ++g) HIP_TRY(c, hipMemsetAsync(ga[g].info, 0, sizeof(int) * gb[g], gs[g]));
-  static const bool classic = [] { const char *e = getenv("CGP_SCHED"); return e && std::string(e) == "classic"; }();
-  static const bool split = [] { const char *e = getenv("CGP_SCHED"); return !(e && std::string(e) == "fuseddiag"); }();
-  static const int diag_env = [] { const char *e = getenv("CGP_DIAG"); return !e ? 0 : (std::string(e) == "lean" ? 1 : 2); }();
-  // default: k_diag_lean (two diagonal workgroups per CU: with >= 2 fits per CU one's factorisation
-  // latency runs under the other's MFMA loop; 3.8 vs 5.1 ms per 512 fits).  CGP_DIAG=fat: k_diag.
-  const bool lean_diag = diag_env != 2;
   // throughput schedule: the predictive sums V z and |V|^2 accumulate inside k_panel (block column
   // k - 1 while it streams through the row fragments of step k); k_finalize then only adds the last
-  // block column instead of reading all of V.  CGP_ACC=off: k_finalize reads V (A/B).
-  static const bool acc_off = [] { const char *e = getenv("CGP_ACC"); return e && std::string(e) == "off"; }();
-  const bool use_acc = !classic && !latency && !acc_off && a.M > 0 && !a.xid;
+  // block column instead of reading all of V.
+  const bool use_acc = !sw.classic && !latency && !sw.acc_off && a.M > 0 && !a.xid;
   if (use_acc) {
     const size_t half = (size_t)batch * a.M;
     for (int g = 0, g0 = 0; g < G; g0 += gb[g], ++g) {
@@ -258,12 +307,12 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     }
   }
   const int panel_lds = panel_lds_bytes<T>();
-  static const bool overlap = [] { const char *e = getenv("CGP_SCHED"); return e && std::string(e) == "overlap"; }();
-  if (overlap && in_rows && G == 1 && !c->prof && a.NT >= 2) {
+#ifdef CGP_AB
+  if (sw.overlap && in_rows && G == 1 && !c->prof && a.NT >= 2) {
     // Look-ahead schedule on two streams: the panel launch of step k is cut into P1 = the tile right
     // below the diagonal (the only one the next diagonal tile needs) and P2 = all the others, and
     //     sA:  P1(k) -> diag(k+1)            sB:  P2(k)
-    // run concurrently; events carry the cross dependencies.
+    // run concurrently; events carry the cross dependencies.  Measured: no gain.
     hipStream_t sA = c->wstream[0], sB = c->wstream[1];
     auto ev = [&](int i) { return c->ev_look[i]; };
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
@@ -273,8 +322,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     a1.tile_off = 0;
     a2.tile_off = 1;
     const int B = gb[0], NT = a.NT;
-    if (lean_diag) hipLaunchKernelGGL(k_diag_lean<T>, dim3(B), dim3(256), paneldiag_lds_bytes<T>(), sA, ga[0], 0);
-    else hipLaunchKernelGGL(k_diag<T>, dim3(B), dim3(256), tile_lds, sA, ga[0], 0);
+    launch_diag<T>(ga[0], B, 0, sw.fat_diag, sA);
     HIP_TRY(c, hipEventRecord(ev(0), sA));                         // evD[0]
     for (int k = 0; k < NT; ++k) {
       const int nin = NT - k - 1;                                  // in-matrix tiles below the diagonal
@@ -292,8 +340,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       HIP_TRY(c, hipEventRecord(ev(3 * k + 2), sB));               // evP2[k]
       if (k + 1 < NT) {
         if (!has_p1 && k > 0) HIP_TRY(c, hipStreamWaitEvent(sA, ev(3 * (k - 1) + 2), 0));
-        if (lean_diag) hipLaunchKernelGGL(k_diag_lean<T>, dim3(B), dim3(256), paneldiag_lds_bytes<T>(), sA, ga[0], k + 1);
-        else hipLaunchKernelGGL(k_diag<T>, dim3(B), dim3(256), tile_lds, sA, ga[0], k + 1);
+        launch_diag<T>(ga[0], B, k + 1, sw.fat_diag, sA);
         HIP_TRY(c, hipEventRecord(ev(3 * (k + 1)), sA));           // evD[k+1]
       }
     }
@@ -305,12 +352,11 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[0], 0));
     return CGP_OK;
   }
+#endif
   // Latency schedule for a handful of fits (k_tile_sk): the diagonal tile and
   // the panel tiles of a step in one launch, inner dimension split over up to SK_MAX workgroups.
   if (latency) {
-    // default: k_trmm_sk as its own launch.  CGP_SK_TRMM=fused lets the tile finishers wait (bounded) for
-    // W_k inside k_tile_sk, one launch per step: measured 1.77 vs 1.80 ms per fit, not worth a wait loop.
-    static const bool split_trmm = [] { const char *e = getenv("CGP_SK_TRMM"); return !(e && std::string(e) == "fused"); }();
+    const bool split_trmm = !sw.sk_fused_trmm;
     SplitArgs q{c->dpart, c->dticket, c->sk_slots, 1, in_rows ? 1 : 0, c->dwready, split_trmm ? 0 : 1};
     if (in_rows) HIP_TRY(c, hipMemsetAsync(c->dwready, 0, sizeof(int) * LAT_FITS, s));
     for (int k = 0; k < a.NT; ++k) {
@@ -334,17 +380,18 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     L[0].end();
     if (want_alpha) {
       L[0].begin(4, batch * (double)a.N * a.N);
-      hipLaunchKernelGGL(k_alpha<T>, dim3(batch), dim3(256), (a.NT * TS + TS) * sizeof(double), s, ga[0]);
+      hipLaunchKernelGGL(k_alpha<T>, dim3(batch), dim3(256), alpha_lds_bytes(a.NT), s, ga[0]);
       L[0].end();
     }
     HIP_TRY(c, hipGetLastError());
     return CGP_OK;
   }
   for (int k = 0; k < a.NT; ++k) {
-    const int gx_u = (in_rows ? a.NT - k : 0) + a.ET;
     const int gx_t = (in_rows ? a.NT - k - 1 : 0) + a.ET;
     for (int g = 0; g < G; ++g) {
-      if (classic) {  // three launches per step, S tile through HBM (kept for A/B measurements)
+#ifdef CGP_AB
+      if (sw.classic) {  // three launches per step, S tile through HBM (kept for A/B measurements)
+        const int gx_u = (in_rows ? a.NT - k : 0) + a.ET;
         L[g].begin(0, update_flops(a.N, a.M, a.d, k, in_rows, gb[g]));
         hipLaunchKernelGGL(k_update<T>, dim3(gx_u, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
         L[g].end();
@@ -356,23 +403,29 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
         L[g].begin(2, trsm_flops(a.N, a.M, k, in_rows, gb[g]));
         hipLaunchKernelGGL(k_trmm<T>, dim3(gx_t, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
         L[g].end();
-      } else {
-        // default: one k_diag launch per step.  CGP_SCHED=fuseddiag: diagonal tile k+1 rides in the
-        // panel launch of step k (measured: +0.6 % fp64 N=2048, -5 % fp32 N=1024 -- DESIGN.md).
-        const bool fuse_next = !split && in_rows && k + 1 < a.NT;
-        if (in_rows && (split || k == 0)) {
-          L[g].begin(1, diag_flops(a.N, a.d, k, gb[g]));
-          if (lean_diag) hipLaunchKernelGGL(k_diag_lean<T>, dim3(gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ga[g], k);
-          else hipLaunchKernelGGL(k_diag<T>, dim3(gb[g]), dim3(256), tile_lds, gs[g], ga[g], k);
-          L[g].end();
-        }
-        L[g].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, gb[g]) + (fuse_next ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0));
-        if (fuse_next)
-          hipLaunchKernelGGL((k_panel<T, true>), dim3(gx_t, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ga[g], k);
-        else
-          hipLaunchKernelGGL((k_panel<T, false>), dim3(gx_t, gb[g]), dim3(256), panel_lds, gs[g], ga[g], k);
+        continue;
+      }
+      // CGP_SCHED=fuseddiag: diagonal tile k+1 rides in the panel launch of step k (measured: +0.6 %
+      // fp64 N=2048, -5 % fp32 N=1024 -- DESIGN.md)
+      const bool fuse_next = sw.fuse_next_diag && in_rows && k + 1 < a.NT;
+      const bool own_diag = in_rows && (!sw.fuse_next_diag || k == 0);
+#else
+      const bool fuse_next = false;
+      const bool own_diag = in_rows;
+#endif
+      if (own_diag) {
+        L[g].begin(1, diag_flops(a.N, a.d, k, gb[g]));
+        launch_diag<T>(ga[g], gb[g], k, sw.fat_diag, gs[g]);
         L[g].end();
       }
+      L[g].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, gb[g]) + (fuse_next ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0));
+#ifdef CGP_AB
+      if (fuse_next)
+        hipLaunchKernelGGL((k_panel<T, true>), dim3(gx_t, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ga[g], k);
+      else
+#endif
+        hipLaunchKernelGGL((k_panel<T, false>), dim3(gx_t, gb[g]), dim3(256), panel_lds, gs[g], ga[g], k);
+      L[g].end();
     }
   }
   for (int g = 0; g < G; ++g) {
@@ -381,7 +434,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     L[g].end();
     if (want_alpha) {
       L[g].begin(4, gb[g] * (double)a.N * a.N);
-      hipLaunchKernelGGL(k_alpha<T>, dim3(gb[g]), dim3(256), (a.NT * TS + TS) * sizeof(double), gs[g], ga[g]);
+      hipLaunchKernelGGL(k_alpha<T>, dim3(gb[g]), dim3(256), alpha_lds_bytes(a.NT), gs[g], ga[g]);
       L[g].end();
     }
   }
@@ -418,7 +471,10 @@ FitArgs base_args(cgp_ctx *c, int N, int d, int M, int kid, int include_noise) {
   a.ET = cdiv(M + 1, TS);
   a.kernel_id = kid;
   a.include_noise = include_noise;
-  if (const char *e = getenv("CGP_DBG")) a.dbg = atoi(e);  // timing ablations only
+#ifdef CGP_ABLATION
+  static const int dbg_env = [] { const char *e = getenv("CGP_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg_env;  // timing ablations: results are wrong on purpose, cgp_build_flags() reports the build
+#endif
   return a;
 }
 
@@ -429,6 +485,38 @@ int check_shape(const cgp_ctx *c, int batch, int N, int d, int M, int kid) {
   if (kid == CGP_KERNEL_RBF_BROWNIAN && d != 1) return CGP_EINVAL;
   if (batch > c->max_batch || N > c->max_n || M > c->max_m || d > c->max_d) return CGP_ECAPACITY;
   return CGP_OK;
+}
+
+// hip_stream argument of the device entry points: NULL is the legacy default stream itself (what
+// torch.cuda.current_stream().cuda_stream is for the default stream), so the work is ordered with the
+// caller's other default-stream work; CGP_STREAM_CTX selects the context's private stream.
+inline hipStream_t pick_stream(cgp_ctx *c, void *hip_stream) {
+  return hip_stream == CGP_STREAM_CTX ? c->stream : (hipStream_t)hip_stream;
+}
+
+bool grow_pinned(void *&p, size_t &cap, size_t bytes) {
+  if (bytes <= cap) return true;
+  if (p) (void)hipHostFree(p);
+  p = nullptr;
+  cap = 0;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    p = nullptr;
+    return false;
+  }
+  cap = bytes;
+  return true;
+}
+bool grow_device(void *&p, size_t &cap, size_t bytes) {
+  if (bytes <= cap) return true;
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    p = nullptr;
+    return false;
+  }
+  cap = bytes;
+  return true;
 }
 
 // (n, d) row-major fp64  ->  SoA [d][n] in the device dtype, staged in `tmp`
@@ -504,6 +592,10 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nullptr;
   if (hipSetDevice(device) != hipSuccess) return nullptr;
+  // the code object holds gfx950 kernels only (MFMA f64 16x16x4, 64-bit DPP row_newbcast, 16-byte LDS-DMA)
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) return nullptr;
+  if ((dtype == CGP_F64 ? set_lds_attrs<double>(device) : set_lds_attrs<float>(device)) != 0) return nullptr;
   cgp_ctx *c = new cgp_ctx();
   c->device = device;
   c->dtype = dtype;
@@ -543,7 +635,8 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMemset(c->dticket, 0, sizeof(int) * LAT_FITS * c->sk_slots) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dwready, sizeof(int) * LAT_FITS) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dmacc, sizeof(double) * 2 * B * std::max(c->max_m, 1)) == hipSuccess;
-  ok = ok && hipMalloc((void **)&c->ddbg, 64 * sizeof(long long)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->ddbg, DBG_SLOTS * sizeof(long long)) == hipSuccess;
+  ok = ok && hipMemset(c->ddbg, 0, DBG_SLOTS * sizeof(long long)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dprep, B * PREP_N * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dlogml, B * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dinfo, B * sizeof(int)) == hipSuccess;
@@ -578,15 +671,37 @@ void cgp_destroy(cgp_ctx *c) {
     if (e) (void)hipEventDestroy(e);
   for (void *wb : c->winbuf)
     if (wb) (void)hipFree(wb);
+  if (c->pin_in) (void)hipHostFree(c->pin_in);
+  if (c->pin_out) (void)hipHostFree(c->pin_out);
+  if (c->draw) (void)hipFree(c->draw);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
-int cgp_debug_read(cgp_ctx *c, long long out[64]) {
+int cgp_debug_read(cgp_ctx *c, long long out[CGP_DEBUG_SLOTS]) {
   if (!c || !out) return CGP_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipDeviceSynchronize());
-  HIP_TRY(c, hipMemcpy(out, c->ddbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(out, c->ddbg, DBG_SLOTS * sizeof(long long), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemset(c->ddbg, 0, DBG_SLOTS * sizeof(long long)));  // the sums restart
+  return CGP_OK;
+}
+
+int cgp_build_flags(void) {
+  int f = 0;
+#ifdef CGP_ABLATION
+  f |= CGP_BUILD_ABLATION;
+#endif
+#ifdef CGP_AB
+  f |= CGP_BUILD_AB;
+#endif
+  return f;
+}
+
+int cgp_synchronize(cgp_ctx *c) {
+  if (!c) return CGP_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return CGP_OK;
 }
 
@@ -648,7 +763,7 @@ int cgp_fit_predict_batch_device(cgp_ctx *c, int batch, int N, int d, int M, int
   a.logml = dlogml;
   a.info = dinfo;
   c->have_fit = false;
-  return run(c, a, batch, true, false, hip_stream ? (hipStream_t)hip_stream : c->stream);
+  return run(c, a, batch, true, false, pick_stream(c, hip_stream));
 }
 
 int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, const double *X, const double *y,
@@ -661,30 +776,47 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
   if (theta_stride < nth) return CGP_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
-  const int dt = c->dtype;
   const size_t esz = c->esz;
-  std::vector<char> hx((size_t)batch * d * N * esz), hy((size_t)batch * N * esz),
-      hxs((size_t)batch * d * std::max(M, 1) * esz);
-  for (int b = 0; b < batch; ++b) {
-    pack_soa(X + (size_t)b * N * d, N, d, dt, hx, (size_t)b * d * N);
-    pack_vec(y + (size_t)b * N, N, dt, hy, (size_t)b * N);
-    if (M > 0) pack_soa(Xs + (size_t)b * M * d, M, d, dt, hxs, (size_t)b * d * M);
-  }
-  std::vector<double> hth, hjit(batch, 0.0);
-  HIP_TRY(c, hipMemcpyAsync(c->dX, hx.data(), hx.size(), hipMemcpyHostToDevice, s));
-  HIP_TRY(c, hipMemcpyAsync(c->dy, hy.data(), hy.size(), hipMemcpyHostToDevice, s));
-  if (M > 0) HIP_TRY(c, hipMemcpyAsync(c->dXs, hxs.data(), hxs.size(), hipMemcpyHostToDevice, s));
-  rc = upload_theta(c, theta, theta_stride, nth, batch, s, hth);
-  if (rc != CGP_OK) return rc;
+  // Host side of the boundary (gp_slip_node.py:19-25 "list -> (n, 1) fp64"): the caller's row-major fp64
+  // arrays go through ONE pinned staging block and ONE H2D DMA; the (n, d) -> SoA [d][n] transposition
+  // and the fp64 -> device dtype conversion run on the device (k_pack_soa), not on a host core.
+  const size_t B = batch, nX = B * N * d, ny = B * N, nXs = B * (size_t)M * d, nTh = B * CGP_MAX_THETA;
+  const size_t in_bytes = (nX + ny + nXs + nTh) * sizeof(double);
+  const size_t out_elems = 2 * B * (size_t)M;                    // mean, var in the device dtype
+  const size_t out_bytes = out_elems * esz + B * sizeof(double) + B * sizeof(int);
+  if (!grow_pinned(c->pin_in, c->pin_in_cap, in_bytes) || !grow_pinned(c->pin_out, c->pin_out_cap, out_bytes) ||
+      !grow_device(c->draw, c->draw_cap, in_bytes))
+    return CGP_ENOMEM;
+  double *hin = static_cast<double *>(c->pin_in);
+  memcpy(hin, X, nX * sizeof(double));
+  memcpy(hin + nX, y, ny * sizeof(double));
+  if (nXs) memcpy(hin + nX + ny, Xs, nXs * sizeof(double));
+  double *hth = hin + nX + ny + nXs;
+  for (size_t b = 0; b < B; ++b)
+    for (int q = 0; q < CGP_MAX_THETA; ++q) hth[b * CGP_MAX_THETA + q] = q < nth ? theta[b * theta_stride + q] : 0.0;
+  const double *draw = static_cast<const double *>(c->draw);
+  HIP_TRY(c, hipMemcpyAsync(c->draw, hin, in_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemcpyAsync(c->dtheta, draw + nX + ny + nXs, nTh * sizeof(double), hipMemcpyDeviceToDevice, s));
+  auto pack = [&](const double *src, void *dst, int n, int dd) {
+    const dim3 grid(std::min(64, cdiv(n * dd, 256)), batch);
+    if (c->dtype == CGP_F64) hipLaunchKernelGGL(k_pack_soa<double>, grid, dim3(256), 0, s, src, static_cast<double *>(dst), n, dd);
+    else hipLaunchKernelGGL(k_pack_soa<float>, grid, dim3(256), 0, s, src, static_cast<float *>(dst), n, dd);
+  };
+  pack(draw, c->dX, N, d);
+  pack(draw + nX, c->dy, N, 1);
+  if (M > 0) pack(draw + nX + ny, c->dXs, M, d);
   HIP_TRY(c, hipMemsetAsync(c->djitter, 0, sizeof(double) * batch, s));
   rc = cgp_fit_predict_batch_device(c, batch, N, d, M, kid, c->dX, c->dy, c->dXs, c->dtheta, c->djitter,
-                                    include_noise, c->dmean, c->dvar, c->dlogml, c->dinfo, s);
+                                    include_noise, c->dmean, c->dvar, c->dlogml, c->dinfo, CGP_STREAM_CTX);
   if (rc != CGP_OK) return rc;
-  std::vector<int> hinfo(batch, 0);
-  HIP_TRY(c, hipMemcpyAsync(hinfo.data(), c->dinfo, sizeof(int) * batch, hipMemcpyDeviceToHost, s));
+  char *hout = static_cast<char *>(c->pin_out);
+  double *hl = reinterpret_cast<double *>(hout + out_elems * esz);
+  int *hinfo = reinterpret_cast<int *>(hl + B);
+  HIP_TRY(c, hipMemcpyAsync(hinfo, c->dinfo, sizeof(int) * batch, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   // GPy jitchol policy for the fits that failed: jitter = mean(diag) * 1e-6 * 10^k, k = 0..4,
   // re-submitted one fit at a time (rare path) into the same device slots.
+  std::vector<double> hjit(batch, 0.0);
   for (int b = 0; b < batch; ++b) {
     if (hinfo[b] == 0) continue;
     double jit = mean_diag(kid, theta + (size_t)b * theta_stride, d, X + (size_t)b * N * d, N) * 1e-6;
@@ -694,7 +826,7 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
           c, 1, N, d, M, kid, (char *)c->dX + (size_t)b * d * N * esz, (char *)c->dy + (size_t)b * N * esz,
           (char *)c->dXs + (size_t)b * d * M * esz, c->dtheta + (size_t)b * CGP_MAX_THETA, c->djitter + b,
           include_noise, (char *)c->dmean + (size_t)b * M * esz, (char *)c->dvar + (size_t)b * M * esz,
-          c->dlogml + b, c->dinfo + b, s);
+          c->dlogml + b, c->dinfo + b, CGP_STREAM_CTX);
       if (rc != CGP_OK) return rc;
       HIP_TRY(c, hipMemcpyAsync(&hinfo[b], c->dinfo + b, sizeof(int), hipMemcpyDeviceToHost, s));
       HIP_TRY(c, hipStreamSynchronize(s));
@@ -702,17 +834,23 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
     }
   }
   c->fjitter = hjit[0];
-  std::vector<char> hm((size_t)batch * std::max(M, 1) * esz), hv((size_t)batch * std::max(M, 1) * esz);
   if (M > 0) {
-    HIP_TRY(c, hipMemcpyAsync(hm.data(), c->dmean, (size_t)batch * M * esz, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(hv.data(), c->dvar, (size_t)batch * M * esz, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hout, c->dmean, B * M * esz, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hout + B * M * esz, c->dvar, B * M * esz, hipMemcpyDeviceToHost, s));
   }
-  std::vector<double> hl(batch);
-  HIP_TRY(c, hipMemcpyAsync(hl.data(), c->dlogml, sizeof(double) * batch, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(hl, c->dlogml, sizeof(double) * batch, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   if (M > 0) {
-    unpack_vec(hm, 0, (size_t)batch * M, dt, mean);
-    unpack_vec(hv, 0, (size_t)batch * M, dt, var);
+    if (c->dtype == CGP_F64) {
+      memcpy(mean, hout, B * M * sizeof(double));
+      memcpy(var, hout + B * M * esz, B * M * sizeof(double));
+    } else {
+      const float *fm = reinterpret_cast<const float *>(hout), *fv = fm + B * M;
+      for (size_t i = 0; i < B * M; ++i) {
+        mean[i] = (double)fm[i];
+        var[i] = (double)fv[i];
+      }
+    }
   }
   int first = 0;
   for (int b = 0; b < batch; ++b) {
@@ -1047,18 +1185,28 @@ extern "C" int cgp_window_init(cgp_ctx *c, int nwin, int N, int d, int kid, cons
   const int nth = ntheta(kid, d);
   if (theta_stride < nth) return CGP_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
-  for (void *&wb : c->winbuf) {
-    if (wb) (void)hipFree(wb);
-    wb = nullptr;
-  }
+  // the old windows are gone from here on: a failure below must leave the context without windows,
+  // not with stale pointers (cgp_window_push checks nwin)
+  c->nwin = 0;
+  c->win = WindowArgs{};
+  auto drop = [c]() {
+    for (void *&wb : c->winbuf) {
+      if (wb) (void)hipFree(wb);
+      wb = nullptr;
+    }
+  };
+  drop();
   const int CAP = 2 * N;
   const size_t W = nwin;
   size_t sizes[6] = {W * CAP * CAP * 8, W * CAP * 8, W * d * CAP * 8, W * CAP * 8, W * 4 * sizeof(int),
                      W * (PREP_N + MAX_THETA) * 8};
   for (int i = 0; i < 6; ++i)
-    if (hipMalloc(&c->winbuf[i], sizes[i]) != hipSuccess) return CGP_ENOMEM;
-  WindowArgs &wa = c->win;
-  wa = WindowArgs{};
+    if (hipMalloc(&c->winbuf[i], sizes[i]) != hipSuccess) {
+      c->winbuf[i] = nullptr;
+      drop();
+      return CGP_ENOMEM;
+    }
+  WindowArgs wa{};
   wa.L = (double *)c->winbuf[0];
   wa.z = (double *)c->winbuf[1];
   wa.xw = (double *)c->winbuf[2];
@@ -1080,8 +1228,12 @@ extern "C" int cgp_window_init(cgp_ctx *c, int nwin, int N, int d, int kid, cons
     o[10] = (kid == CGP_KERNEL_RBF_BROWNIAN) ? th[2] : 0.0;
     for (int q = 0; q < nth; ++q) h[W * PREP_N + w * MAX_THETA + q] = th[q];
   }
-  HIP_TRY(c, hipMemcpy(pt, h.data(), h.size() * 8, hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemset(wa.state, 0, W * 4 * sizeof(int)));
+  if (!hip_ok(c, hipMemcpy(pt, h.data(), h.size() * 8, hipMemcpyHostToDevice), "window theta H2D") ||
+      !hip_ok(c, hipMemset(wa.state, 0, W * 4 * sizeof(int)), "window state memset")) {
+    drop();
+    return CGP_EHIP;
+  }
+  c->win = wa;  // published only when every allocation and copy has succeeded
   c->nwin = nwin;
   return CGP_OK;
 }
@@ -1100,7 +1252,7 @@ extern "C" int cgp_window_push_device(cgp_ctx *c, int T, const double *dxs, cons
   a.T = T;
   a.include_noise = include_noise;
   const size_t lds = (size_t)(3 * a.N + 4 * WPB + MAXD + 8) * sizeof(double);
-  hipLaunchKernelGGL(k_window_ticks, dim3(c->nwin), dim3(256), lds, hip_stream ? (hipStream_t)hip_stream : c->stream, a);
+  hipLaunchKernelGGL(k_window_ticks, dim3(c->nwin), dim3(256), lds, pick_stream(c, hip_stream), a);
   HIP_TRY(c, hipGetLastError());
   return CGP_OK;
 }
@@ -1163,6 +1315,7 @@ extern "C" int cgp_recorder_update(cgp_recorder *rec, const double wv[4], double
       if (time_out) time_out[i] = rec->r.time_array[i];
       if (slipwin_out) slipwin_out[i] = rec->r.slip_array[i];
     }
+    if (n > cap && (time_out || slipwin_out)) return CGP_ECAPACITY;  // *n_out = the size the window needs
   }
   return pub ? 1 : 0;
 }
@@ -1300,7 +1453,7 @@ int grad_eval_batch(cgp_ctx *c, int batch, int N, int d, int kid, std::vector<do
   a.Xs = c->dX;
   a.y = c->dy;
   a.theta = c->dtheta;
-  a.jitter = nullptr;
+  a.jitter = c->djitter;  // per window; zero unless the jitter ladder of cgp_optimize_batch is climbing
   a.mean = c->dmean;
   a.var = c->dvar;
   a.logml = c->dlogml;
@@ -1375,9 +1528,13 @@ extern "C" int cgp_optimize_batch(cgp_ctx *c, int batch, int N, int d, int kid, 
     }
     st.emplace_back(x0, max_evals > 0 ? max_evals : 1000, 1e-5, 1e7);
   }
-  std::vector<double> th((size_t)batch * nth), hth, lml, sums, g(nth), gx(nth);
-  std::vector<int> info;
+  std::vector<double> th((size_t)batch * nth), hth, lml, sums, g(nth), gx(nth), jit(batch, 0.0), lml2, sums2;
+  std::vector<int> info, info2;
   c->have_fit = false;
+  auto eval = [&](std::vector<double> &l, std::vector<double> &sm, std::vector<int> &inf) {
+    return c->dtype == CGP_F64 ? grad_eval_batch<double>(c, batch, N, d, kid, l, sm, inf)
+                               : grad_eval_batch<float>(c, batch, N, d, kid, l, sm, inf);
+  };
   for (int round = 0; round < (max_evals > 0 ? max_evals : 1000) + 40; ++round) {
     bool any = false;
     for (int b = 0; b < batch; ++b) {
@@ -1388,9 +1545,31 @@ extern "C" int cgp_optimize_batch(cgp_ctx *c, int batch, int N, int d, int kid, 
     if (!any) break;
     rc = upload_theta(c, th.data(), nth, nth, batch, s, hth);
     if (rc != CGP_OK) return rc;
-    rc = c->dtype == CGP_F64 ? grad_eval_batch<double>(c, batch, N, d, kid, lml, sums, info)
-                             : grad_eval_batch<float>(c, batch, N, d, kid, lml, sums, info);
+    HIP_TRY(c, hipMemsetAsync(c->djitter, 0, sizeof(double) * batch, s));
+    rc = eval(lml, sums, info);
     if (rc != CGP_OK) return rc;
+    // GPy jitchol inside m.optimize(): a trial point whose matrix is not positive definite is retried
+    // with jitter mean(diag) 1e-6 10^k, k = 0..4.  Only the windows that failed climb the ladder (the
+    // others keep jitter 0 and their first results); the re-evaluation is one more batched schedule.
+    for (int attempt = 0; attempt < 5; ++attempt) {
+      bool any_bad = false;
+      for (int b = 0; b < batch; ++b) {
+        if (st[b].done() || info[b] == 0) continue;
+        any_bad = true;
+        jit[b] = attempt == 0 ? mean_diag(kid, th.data() + (size_t)b * nth, d, X + (size_t)b * N * d, N) * 1e-6 : jit[b] * 10.0;
+      }
+      if (!any_bad) break;
+      HIP_TRY(c, hipMemcpyAsync(c->djitter, jit.data(), sizeof(double) * batch, hipMemcpyHostToDevice, s));
+      rc = eval(lml2, sums2, info2);
+      if (rc != CGP_OK) return rc;
+      for (int b = 0; b < batch; ++b) {
+        if (st[b].done() || info[b] == 0) continue;
+        info[b] = info2[b];
+        lml[b] = lml2[b];
+        std::copy(sums2.begin() + (size_t)b * GRAD_N, sums2.begin() + (size_t)(b + 1) * GRAD_N, sums.begin() + (size_t)b * GRAD_N);
+      }
+    }
+    std::fill(jit.begin(), jit.end(), 0.0);
     for (int b = 0; b < batch; ++b) {
       if (st[b].done()) continue;
       const double *tb = th.data() + (size_t)b * nth;

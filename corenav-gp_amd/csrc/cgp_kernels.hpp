@@ -63,8 +63,43 @@ struct FitArgs {
   int tile_off;          // first block-tile index of this launch (split panel launches)
   int xid;               // 1: the M (= N) "test rows" are the identity, so the extra block becomes (L^-1)^T (gradient mode)
   double *gpart;         // [batch][pairs][GRAD_N] per-tile-pair partial sums of k_grad
-  long long *dbgbuf;     // 64 slots of s_memtime stamps (block 0, CGP_DBG & 512)
-  int dbg;               // timing ablations only (env CGP_DBG, results are WRONG when non-zero)
+  long long *dbgbuf;     // 64 slots of s_memtime stamps / per-phase cycle sums (-DCGP_ABLATION builds)
+  int dbg;               // timing ablations (env CGP_DBG); only a -DCGP_ABLATION build reads it
+};
+
+// Timing ablations skip parts of the arithmetic (results are WRONG by design), so the shipped library
+// does not contain them: CGP_DBG_ON(p, bit) is a compile-time 0 unless built with -DCGP_ABLATION.
+#ifdef CGP_ABLATION
+#define CGP_DBG_ON(p, bit) (((p).dbg & (bit)) != 0)
+#else
+#define CGP_DBG_ON(p, bit) false
+#endif
+constexpr int DBG_SLOTS = 512;  // cgp_debug_read: [0, 8) potf2 phases, [64 + 8 k, 64 + 8 k + 8) k_panel phases of step k
+
+// Per-phase cycle sums of a kernel (CGP_DBG & 1024 in a -DCGP_ABLATION build): thread 0 of every
+// workgroup adds the s_memtime ticks since the previous lap to dbgbuf[slot]; slot + 7 of a step counts
+// the workgroups.  Compiles to nothing in the shipped library.
+struct PhaseClock {
+#ifdef CGP_ABLATION
+  long long t;
+  bool on;
+  __device__ __forceinline__ void start(const FitArgs &p, int tid) {
+    on = CGP_DBG_ON(p, 1024) && tid == 0;
+    t = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void lap(const FitArgs &p, int slot) {
+    const long long n = __builtin_amdgcn_s_memtime();
+    if (on) atomicAdd(reinterpret_cast<unsigned long long *>(p.dbgbuf) + slot, (unsigned long long)(n - t));
+    t = n;
+  }
+  __device__ __forceinline__ void count(const FitArgs &p, int slot) {
+    if (on) atomicAdd(reinterpret_cast<unsigned long long *>(p.dbgbuf) + slot, 1ull);
+  }
+#else
+  __device__ __forceinline__ void start(const FitArgs &, int) {}
+  __device__ __forceinline__ void lap(const FitArgs &, int) {}
+  __device__ __forceinline__ void count(const FitArgs &, int) {}
+#endif
 };
 
 template <typename T> struct Prec;
@@ -160,6 +195,7 @@ __device__ __forceinline__ double rdlane(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
+#ifdef CGP_AB  // first-generation three-launch schedule (k_update -> k_potf2 -> k_trmm), A/B builds only
 // --------------------------------------------------------------------------------------------------
 // The MFMA inner loop shared by k_update and k_trmm:
 //   acc[i][j] (+)= sum_q  Cop[cl][q] * Rop[rl][q]      over nchunk chunks of KT columns
@@ -257,6 +293,8 @@ __device__ __forceinline__ void mfma_panel_loop(typename Prec<T>::acc_t (&acc)[4
   }
 }
 
+#endif  // CGP_AB
+
 // exp(x) for x <= 0 (every covariance exponent is -0.5 r^2): n = rint(x log2 e), r = x - n ln2 in
 // two pieces, degree-13 Horner polynomial on |r| <= ln2/2, v_ldexp for 2^n (denormal-exact).  The
 // argument is clamped at -800 (result 0) instead of being special-cased.  Coefficients live in
@@ -289,6 +327,7 @@ __device__ __forceinline__ double exp_nonpos(double x, const ExpC &e) {
 }
 __device__ __forceinline__ float exp_nonpos(float x, const ExpC &) { return __expf(fmaxf(x, -104.f)); }
 
+#ifdef CGP_AB
 // Gram tile G(rt, k) evaluated from the inputs, then S = G - acc, stored to the factor panel.
 // Column points (16 per lane) are the outer static loops, the 4 row points the inner one.
 // FAST: interior tile -- every row and column is a real point and no diagonal / y-row entry is in
@@ -330,7 +369,7 @@ __device__ __forceinline__ void gram_tile(const FitArgs &p, typename Prec<T>::ac
             const T df = xrow[j][q] - xcol[q];
             d2 = __builtin_fma(df, df, d2);
           }
-          g = (p.dbg & 32) ? d2 : amp * exp_nonpos(T(-0.5) * d2, ec);
+          g = CGP_DBG_ON(p, 32) ? d2 : amp * exp_nonpos(T(-0.5) * d2, ec);
         } else {
           const T x = xrow[j][0], xp = xcol[0];
           const bool same = !FAST && !extra && grow == gcol;  // GPy forces r^2 = 0 on the auto-covariance diagonal
@@ -352,7 +391,7 @@ __device__ __forceinline__ void gram_tile(const FitArgs &p, typename Prec<T>::ac
             g = (!colok || grow > M) ? T(0) : g;
           }
         }
-        if (!(p.dbg & 16) || g == T(12345)) ocol[j * 16] = g - acc[i][j][r];
+        if (!CGP_DBG_ON(p, 16) || g == T(12345)) ocol[j * 16] = g - acc[i][j][r];
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the 16 column points from being software-pipelined into spills
     }
@@ -440,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void k_update(FitArgs p, int k) {
 
   mfma_panel_loop<T, false>(acc, Lw + (size_t)rt * TS, (size_t)ld, Lw + (size_t)k * TS, (size_t)ld,
                             (k * TS) / KT, smem, tid, p.dbg);
-  if (p.dbg & 8) return;
+  if (CGP_DBG_ON(p, 8)) return;
 
   // ---- epilogue: Gram tile from the inputs, S = G - acc ----
   if (p.kernel_id == K_RBF_BROWNIAN) gram_epilogue<T, true>(p, acc, Lw, smem, b, k, rt, tid);
@@ -487,6 +526,8 @@ __global__ __launch_bounds__(256, 2) void k_trmm(FitArgs p, int k) {
       }
   }
 }
+
+#endif  // CGP_AB
 
 // One 16x16 diagonal block in the registers of a wavefront: lane holds row (lane & 15) of the block
 // in a[] (replicated over the four 16-lane groups).  On return a[] holds the row of the Cholesky
@@ -752,6 +793,7 @@ __device__ __forceinline__ void potf2_store(const FitArgs &p, const T *At, const
   }
 }
 
+#ifdef CGP_AB
 template <typename T>
 __global__ __launch_bounds__(256) void k_potf2(FitArgs p, int k) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -772,6 +814,8 @@ __global__ __launch_bounds__(256) void k_potf2(FitArgs p, int k) {
   potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, nullptr, p.N - k * TS);
   potf2_store<T>(p, At, Dv, flag, tile, ld, b, k, tid);
 }
+
+#endif  // CGP_AB
 
 // --------------------------------------------------------------------------------------------------
 // k_finalize: mean_m = V_m . z ; var_m = k** - |V_m|^2 (clip 1e-15, + sigma_n^2) ;
@@ -862,8 +906,12 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs p, int do_logml) {
 
 // --------------------------------------------------------------------------------------------------
 // k_alpha: alpha = L^-T z (a5 "potrs" back substitution).  One workgroup per fit; z is the y row
-// of the factor panel.  Per 128-tile (last to first): rhs = z - L(below,tile)^T alpha(below) by one
-// wave per column with a shuffle reduction, then a 128-step in-tile back substitution.
+// of the factor panel.  Per 128-tile (last to first):
+//   rhs      = z_tile - L(below, tile)^T alpha(below)      one wave per column, shuffle reduction
+//   alpha_t  = L(t,t)^-T rhs = W_t^T rhs                    W_t = L(t,t)^-1 is already in Winv (the panel
+// kernels multiply by it), so the in-tile back substitution is a triangular matrix-vector product with
+// no sequential dependency: two barriers per tile instead of one per column.  Only entries r >= c of a
+// W_t column are read (at 16-row block granularity: the strictly upper 16x16 blocks are never written).
 // --------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_alpha(FitArgs p) {
@@ -872,6 +920,7 @@ __global__ __launch_bounds__(256) void k_alpha(FitArgs p) {
   double *rhs = al + p.NT * TS;                        // [128]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T *Lw = reinterpret_cast<const T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const T *Winv = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride;
   const int ld = p.ld, NP = p.NT * TS, M = p.M;
   const size_t rb = (size_t)p.NT * TS;
   for (int tb = p.NT - 1; tb >= 0; --tb) {
@@ -885,16 +934,32 @@ __global__ __launch_bounds__(256) void k_alpha(FitArgs p) {
       if (lane == 0) rhs[cl] = (double)col[rb + M] - s;
     }
     __syncthreads();
-    for (int c = TS - 1; c >= 0; --c) {
-      // alpha_c = rhs_c / L_cc ; then rhs_q -= L[c][q] alpha_c for q < c   (L[c][q] at col q, row c0+c)
-      const double ac = rhs[c] / (double)Lw[(size_t)(c0 + c) * ld + c0 + c];
-      if (tid == 0) al[c0 + c] = ac;
-      if (tid < c) rhs[tid] -= (double)Lw[(size_t)(c0 + tid) * ld + c0 + c] * ac;
-      __syncthreads();
+    const T *Wt = Winv + (size_t)tb * TS * TS;  // column-major: W[r][c] at Wt[c * 128 + r], zero for r < c
+    for (int cl = wave; cl < TS; cl += 4) {
+      const T *wc = Wt + (size_t)cl * TS;
+      double s = 0;
+      for (int r = (cl & ~(DB - 1)) + lane; r < TS; r += 64) s += (double)wc[r] * rhs[r];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (lane == 0) al[c0 + cl] = s;
     }
+    __syncthreads();
   }
   T *out = reinterpret_cast<T *>(p.alpha) + (size_t)b * p.alpha_stride;
   for (int i = tid; i < NP; i += 256) out[i] = (T)al[i];
+}
+
+// (n, d) row-major fp64 -> SoA [d][n] in the device dtype, one fit per blockIdx.y (the host-buffer entry
+// points stage the caller's arrays untouched; transposition and conversion happen here).
+template <typename T>
+__global__ void k_pack_soa(const double *__restrict__ src, T *__restrict__ dst, int n, int d) {
+  const size_t b = blockIdx.y;
+  const double *s = src + b * (size_t)n * d;
+  T *o = dst + b * (size_t)n * d;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * d; i += gridDim.x * blockDim.x) {
+    const int r = i / d, q = i - r * d;
+    o[(size_t)q * n + r] = (T)s[i];
+  }
 }
 
 }  // namespace cgp

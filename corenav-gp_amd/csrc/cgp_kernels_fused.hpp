@@ -414,7 +414,7 @@ __device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<
         const int gcol = colbase + cl;
         T g;
         if (!BROWN) {
-          g = (p.dbg & 128) ? e[r] : exp_gen(e[r], ec);
+          g = CGP_DBG_ON(p, 128) ? e[r] : exp_gen(e[r], ec);
         } else {
           const T x = xrw[j], xp = craw[cl];
           const bool same = !FAST && !extra && grow == gcol;  // GPy forces r^2 = 0 on the auto-covariance diagonal
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256, 2) void k_diag_lean(FitArgs p, int k) {
 // Every wave must be done with `smem` before the call.
 template <typename T>
 __device__ __forceinline__ void trmm_in_registers(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
-                                                  int b, int k, int tid) {
+                                                  int b, int k, int tid, PhaseClock *pc = nullptr, int wslot = 0) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
   const int lane = tid & 63, l15 = lane & 15;
@@ -814,6 +814,7 @@ __device__ __forceinline__ void trmm_in_registers(const FitArgs &p, typename Pre
     }
   }
   __syncthreads();
+  if (pc) pc->lap(p, wslot);  // W_k staged
 
   // in-register triangular product, descending column blocks so L(:, cb) may overwrite S(:, cb)
 #pragma unroll
@@ -889,6 +890,9 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
   T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
   const int ld = p.ld;
   const int tid = threadIdx.x;
+  PhaseClock pc;
+  pc.start(p, tid);
+  const int ps = 64 + 8 * (k & 31);  // debug slots of this step
 
   // Gram first: acc = -G(rt, k) while nothing else is live in the register file, with chunk 0 of the
   // panels already in flight into LDS buffer 0 (the Gram inputs are staged in buffer 1's space).
@@ -910,6 +914,7 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
       rdirect_prologue<T>(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
       gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
     }
+    pc.lap(p, ps + 0);
     mfma_rowpanel_loop_rdirect<T>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
   } else {
     {
@@ -918,8 +923,10 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
       if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
       gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
     }
+    pc.lap(p, ps + 0);
     mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, accm ? zs : nullptr, ms);
   }
+  pc.lap(p, ps + 1);
   if (accm) {
     // a row's 128 columns are spread over the four 16-lane groups: fold them, then the lanes of
     // group 0 add to the fit's accumulators (this workgroup is the only writer of its rows)
@@ -942,13 +949,20 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
     }
   }
   __syncthreads();  // every wave is done with the staged inputs before W_k overwrites them
-  if (!(p.dbg & 64)) trmm_in_registers<T>(p, acc, smem, b, k, tid);
+  pc.lap(p, ps + 2);
+  if (!CGP_DBG_ON(p, 64)) trmm_in_registers<T>(p, acc, smem, b, k, tid, &pc, ps + 3);
+  pc.lap(p, ps + 4);
   store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
+  pc.lap(p, ps + 5);
+  pc.count(p, ps + 7);
+#ifdef CGP_AB
   if constexpr (DIAGNEXT) {
     if (rt == k + 1) diag_next<T, true, false>(p, acc, smem, Lw, b, k + 1, tid);
   }
+#endif
 }
 
+#ifdef CGP_AB
 // --------------------------------------------------------------------------------------------------
 // k_diag: the diagonal tile of block step k, updated, factored and inverted by one workgroup.
 // --------------------------------------------------------------------------------------------------
@@ -1018,10 +1032,12 @@ __global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
   if (tid == 0) *flag = 0;
   __syncthreads();
   const long long tq = __builtin_amdgcn_s_memtime();
-  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, (p.dbg & 512) ? p.dbgbuf : nullptr, p.N - k * TS);
+  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, CGP_DBG_ON(p, 512) ? p.dbgbuf : nullptr, p.N - k * TS);
   potf2_store<T>(p, At, Dv, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
-  if ((p.dbg & 512) && tid == 0 && b == 0) { p.dbgbuf[5] = __builtin_amdgcn_s_memtime() - tq; p.dbgbuf[6] = tq - tstart; }
+  if (CGP_DBG_ON(p, 512) && tid == 0 && b == 0) { p.dbgbuf[5] = __builtin_amdgcn_s_memtime() - tq; p.dbgbuf[6] = tq - tstart; }
 }
+
+#endif  // CGP_AB
 
 // --------------------------------------------------------------------------------------------------
 // Latency schedule (a handful of fits: the throughput schedule would leave most CUs idle and walk

@@ -16,7 +16,12 @@ PROF_KERNELS = 5
 PROF_NAMES = ("update", "potf2", "trmm", "finalize", "alpha")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcorenav_gp.so")
+# CGP_LIB selects another build of the same ABI for measurements (the -DCGP_AB -DCGP_ABLATION library
+# `make ab` writes next to the shipped one); there is still no CPU fallback.
+LIB_PATH = os.environ.get("CGP_LIB") or os.path.join(_HERE, "libcorenav_gp.so")
+DEBUG_SLOTS = 512
+BUILD_ABLATION, BUILD_AB = 1, 2
+STREAM_CTX = ctypes.c_void_p(-1).value   # CGP_STREAM_CTX: the context's private stream
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -28,6 +33,14 @@ _SIGS = {
     "cgp_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "cgp_last_error": (ctypes.c_char_p, [_vp]),
     "cgp_abi_version": (ctypes.c_int, []),
+    "cgp_build_flags": (ctypes.c_int, []),
+    "cgp_synchronize": (ctypes.c_int, [_vp]),
+    "cgp_sweep_create": (_vp, [_ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "cgp_sweep_destroy": (None, [_vp]),
+    "cgp_sweep_ndev": (ctypes.c_int, [_vp]),
+    "cgp_sweep_shard": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _ip, _ip]),
+    "cgp_sweep_fit_predict": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5 + [_dp, _dp, _dp, _dp, ctypes.c_int,
+                                                                          ctypes.c_int, _dp, _dp, _dp, _ip, _dp]),
     "cgp_fit": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp]),
     "cgp_predict": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
     "cgp_get_alpha": (ctypes.c_int, [_vp, _dp]),
@@ -243,9 +256,15 @@ class Context:
     # -- batch, device pointers (ints) on a caller stream ------------------------------------------
     def fit_predict_batch_device(self, B, N, d, M, kernel_id, dX, dy, dXs, dtheta, djitter, include_noise, dmean,
                                  dvar, dlogml, dinfo, stream=0):
+        """stream: a hipStream_t handle as an int.  0 is the legacy default stream itself (what
+        torch.cuda.current_stream().cuda_stream returns for the default stream), so the work is ordered
+        with the caller's default-stream kernels; engine.STREAM_CTX = the context's private stream."""
         return self._chk(self.lib.cgp_fit_predict_batch_device(self.h, B, N, d, M, kernel_id, dX, dy, dXs, dtheta,
                                                                djitter or None, int(include_noise), dmean, dvar,
-                                                               dlogml, dinfo, stream or None))
+                                                               dlogml, dinfo, ctypes.c_void_p(stream)))
+
+    def synchronize(self):
+        self._chk(self.lib.cgp_synchronize(self.h))
 
     # -- sliding windows (BASELINE configs[3]) ----------------------------------------------------
     def window_init(self, nwin, N, d, kernel_id, theta):
@@ -268,7 +287,7 @@ class Context:
 
     def window_push_device(self, T, dxs, dys, include_noise, dpm, dpv, dlm, stream=0):
         return self._chk(self.lib.cgp_window_push_device(self.h, T, dxs, dys, int(include_noise), dpm, dpv, dlm,
-                                                         stream or None))
+                                                         ctypes.c_void_p(stream)))
 
     def window_state(self, w=0):
         n, info = ctypes.c_int(0), ctypes.c_int(0)
@@ -292,7 +311,7 @@ class Context:
         return fired.astype(bool), cmd, iout, xy
 
     def debug_read(self):
-        out = np.zeros(64, dtype=np.int64)
+        out = np.zeros(DEBUG_SLOTS, dtype=np.int64)
         self._chk(self.lib.cgp_debug_read(self.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
         return out
 
@@ -308,6 +327,46 @@ class Context:
         self._chk(self.lib.cgp_profile_read(self.h, _p(ms), _p(fl), n.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
         return {PROF_NAMES[i]: {"ms": float(ms[i]), "flops": float(fl[i]), "launches": int(n[i])}
                 for i in range(PROF_KERNELS)}
+
+
+class Sweep:
+    """Multi-device sweep of independent fits through the C ABI (cgp_sweep_*): one context and one host
+    thread per listed device, contiguous block partition, summaries gathered on the host."""
+
+    def __init__(self, devices, max_n, max_m, max_d, max_batch_total, dtype=F64):
+        self.lib = load()
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        self.h = self.lib.cgp_sweep_create(dv.ctypes.data_as(_ip), len(dv), max_n, max_m, max_d, max_batch_total, dtype)
+        if not self.h:
+            raise RuntimeError("cgp_sweep_create failed: a listed device is not a usable gfx950 GPU or out of memory")
+        self.ndev = self.lib.cgp_sweep_ndev(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cgp_sweep_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def shard(self, batch, i):
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        rc = self.lib.cgp_sweep_shard(self.h, batch, i, ctypes.byref(a), ctypes.byref(b))
+        if rc:
+            raise CgpError(rc)
+        return a.value, b.value
+
+    def fit_predict(self, X, y, Xs, theta, kernel_id, include_noise=True):
+        X, y, Xs, theta = _d(X), _d(y), _d(Xs), _d(theta)
+        B, N, d = X.shape
+        M = Xs.shape[1]
+        mean, var = np.empty((B, M)), np.empty((B, M))
+        logml, info, summ = np.empty(B), np.zeros(B, dtype=np.int32), np.empty((B, 3))
+        rc = self.lib.cgp_sweep_fit_predict(self.h, B, N, d, M, kernel_id, _p(X), _p(y), _p(Xs), _p(theta), theta.shape[1],
+                                            int(include_noise), _p(mean), _p(var), _p(logml), info.ctypes.data_as(_ip),
+                                            _p(summ))
+        if rc < 0:
+            raise CgpError(rc)
+        return rc, mean, var, logml, info, summ
 
 
 INIT_LLH = (0.693457963620326, -1.39498384275845, 334.993517334743)   # init_params.yaml:13-16

@@ -37,18 +37,33 @@ enum {
 };
 #define CGP_MAX_D 8
 #define CGP_MAX_THETA (CGP_MAX_D + 2)
+/* `hip_stream` arguments take a hipStream_t.  NULL is the legacy default stream itself (the value
+ * torch.cuda.current_stream().cuda_stream has for the default stream): the enqueued work is ordered
+ * after the caller's earlier default-stream work (e.g. the kernels that produced dX) and before its
+ * later work.  CGP_STREAM_CTX selects the context's private non-blocking stream; the caller then
+ * orders it against its own streams with events or cgp_synchronize. */
+#define CGP_STREAM_CTX ((void *)(size_t)-1)
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
 /* Allocates every device buffer for up to `max_batch` simultaneous fits of at most max_n training
  * points, max_m test points, max_d input dimensions.  dtype = CGP_F64 | CGP_F32 is the arithmetic
  * type of the device path; host buffers are always fp64 (the messages are float64[]).
- * Returns NULL on failure (no usable gfx950 device, out of memory): there is no CPU fallback. */
+ * Returns NULL on failure (device index out of range, device is not gfx950 -- the architecture name
+ * is checked: the code object holds gfx950 kernels only -- or out of memory): no CPU fallback. */
 cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, int dtype);
 void cgp_destroy(cgp_ctx *ctx);
 const char *cgp_strerror(int code);
 /* Text of the last HIP error seen by this context ("" if none). */
 const char *cgp_last_error(const cgp_ctx *ctx);
 int cgp_abi_version(void);
+/* How the library was built: 0 for the shipped library.  CGP_BUILD_ABLATION (-DCGP_ABLATION): env
+ * CGP_DBG is read and can skip parts of the arithmetic for timing ablations -- outputs are WRONG by
+ * design, bench.py refuses to report such a build as a measurement.  CGP_BUILD_AB (-DCGP_AB): the
+ * alternative schedules of DESIGN.md section 13 are compiled in and selectable by environment. */
+enum { CGP_BUILD_ABLATION = 1, CGP_BUILD_AB = 2 };
+int cgp_build_flags(void);
+/* Blocks until everything enqueued on the context's private stream has finished. */
+int cgp_synchronize(cgp_ctx *ctx);
 
 /* ---- single window, host buffers -------------------------------------------------------------
  * cgp_fit replaces `GPy.models.GPRegression(x_train, y_train, kernel)` + the exact-inference pass
@@ -87,7 +102,9 @@ int cgp_optimize(cgp_ctx *ctx, const double *X, const double *y, int N, int d, i
 /* cgp_optimize_batch: the same optimisation for `batch` windows of identical shape at once.  Every
  * L-BFGS round evaluates value + gradient of ALL windows in one batched device schedule (each window
  * keeps its own line-search / history state on the host); a window whose matrix is not positive
- * definite at a trial point treats it as infeasible (no jitter retry in the batched path).
+ * definite at a trial point is re-evaluated with GPy's jitter ladder (mean(diag) 1e-6 10^k, k = 0..4,
+ * the windows that failed only), exactly as jitchol does inside m.optimize(); a point that still
+ * fails is infeasible (+inf) for the line search.
  * X (batch, N, d), y (batch, N), theta_inout (batch, theta_stride); logml / n_evals (batch) may be
  * NULL.  Needs max_batch >= batch and max_m >= N.  Follow with cgp_fit_predict_batch at the optima. */
 int cgp_optimize_batch(cgp_ctx *ctx, int batch, int N, int d, int kernel_id, const double *X, const double *y,
@@ -125,13 +142,36 @@ int cgp_fit_predict_batch(cgp_ctx *ctx, int batch, int N, int d, int M, int kern
  * All pointers are DEVICE pointers in the context's dtype (fp64 or fp32), SoA per fit:
  *   dX (batch, d, N), dy (batch, N), dXs (batch, d, M), dtheta (batch, CGP_MAX_THETA) fp64,
  *   djitter (batch) fp64 or NULL, dmean/dvar (batch, M), dlogml (batch) fp64, dinfo (batch) int32.
- * Work is enqueued on `hip_stream` (a hipStream_t; NULL = the context's own stream) and the call
- * returns without synchronising.  No jitter retry happens here: read dinfo and re-submit the failed
+ * Work is enqueued on `hip_stream` (see CGP_STREAM_CTX above: NULL = the legacy default stream,
+ * CGP_STREAM_CTX = the context's own stream) and the call returns without synchronising.  No jitter retry happens here: read dinfo and re-submit the failed
  * fits with djitter set (cgp_fit_predict_batch does exactly that). */
 int cgp_fit_predict_batch_device(cgp_ctx *ctx, int batch, int N, int d, int M, int kernel_id,
                                  const void *dX, const void *dy, const void *dXs, const double *dtheta,
                                  const double *djitter, int include_noise, void *dmean, void *dvar,
                                  double *dlogml, int *dinfo, void *hip_stream);
+
+/* ---- multi-device sweep (SURVEY.md 8b "cgp_fit_predict_batch(ctx[], ...)", 8e) --------------------
+ * One engine context and one host thread per listed device; a batch of independent windows is cut into
+ * contiguous per-device blocks (device i gets fits [start_i, stop_i), the first batch % ndev devices
+ * one fit more -- cgp_sweep_shard returns the range), every block runs cgp_fit_predict_batch on its own
+ * device concurrently, and the per-fit summaries {logml, max sigma = 2 sqrt(max var), info} are gathered
+ * on the host in global fit order (`summary` is (batch, 3), may be NULL).  No data-path collective:
+ * the path shards across fits only, a single fit is never split.  This is the entry point that lets
+ * the reference's C++ ROS host (gp_predictor) shard a Monte-Carlo ensemble without Python; the
+ * one-process-per-GPU form over RCCL is corenav-gp_amd/sharding.py + bench.py --gpus N.  `devices` may
+ * name a device more than once (several contexts on one GPU: the self-test of a one-GPU box).
+ * Argument meaning, outputs and return value as cgp_fit_predict_batch; max_batch_total = the largest
+ * batch a call will carry.  Returns NULL / CGP_ECAPACITY like cgp_create / cgp_fit_predict_batch. */
+typedef struct cgp_sweep cgp_sweep;
+cgp_sweep *cgp_sweep_create(const int *devices, int ndev, int max_n, int max_m, int max_d, int max_batch_total,
+                            int dtype);
+void cgp_sweep_destroy(cgp_sweep *sweep);
+int cgp_sweep_ndev(const cgp_sweep *sweep);
+int cgp_sweep_shard(const cgp_sweep *sweep, int batch, int i, int *start, int *stop);
+int cgp_sweep_fit_predict(cgp_sweep *sweep, int batch, int N, int d, int M, int kernel_id, const double *X,
+                          const double *y, const double *Xs, const double *theta, int theta_stride,
+                          int include_noise, double *mean, double *var, double *logml, int *info,
+                          double *summary);
 
 /* Number of worker streams a batch is spread over (1..8, default 4): the batch is cut into that
  * many groups whose launch schedules run concurrently (HIP streams + events, forked from and
@@ -139,8 +179,11 @@ int cgp_fit_predict_batch_device(cgp_ctx *ctx, int batch, int N, int d, int M, i
  * launches of another. */
 int cgp_set_streams(cgp_ctx *ctx, int n);
 
-/* Development aid: 64 in-kernel s_memtime stamps (100 MHz ticks) written when env CGP_DBG & 512. */
-int cgp_debug_read(cgp_ctx *ctx, long long out[64]);
+/* Development aid (-DCGP_ABLATION builds; all zero otherwise): in-kernel s_memtime sums.  [0, 8) potf2
+ * phases of block 0 (CGP_DBG & 512); [64 + 8k, 64 + 8k + 8) per-phase sums of k_panel at block step k
+ * over all workgroups, slot 7 of each group = workgroup count (CGP_DBG & 1024).  Reading resets them. */
+#define CGP_DEBUG_SLOTS 512
+int cgp_debug_read(cgp_ctx *ctx, long long out[CGP_DEBUG_SLOTS]);
 
 /* ---- online sliding-window GP (BASELINE configs[3]; not reference behaviour) -------------------
  * `nwin` independent windows of at most N samples each live on the device.  cgp_window_push feeds
@@ -154,7 +197,7 @@ int cgp_window_init(cgp_ctx *ctx, int nwin, int N, int d, int kernel_id, const d
 int cgp_window_push(cgp_ctx *ctx, int T, const double *xs, const double *ys, int include_noise,
                     double *pred_mean, double *pred_var, double *logml);
 /* Device-resident variant for streaming benchmarks: dxs/dys/outputs are device pointers, enqueued on
- * hip_stream without synchronising. */
+ * hip_stream (NULL = legacy default stream, CGP_STREAM_CTX = the context's own) without synchronising. */
 int cgp_window_push_device(cgp_ctx *ctx, int T, const double *dxs, const double *dys, int include_noise,
                            double *dpred_mean, double *dpred_var, double *dlogml, void *hip_stream);
 /* Current size of window `w` and the first failing tick (0 = none). */
@@ -206,8 +249,9 @@ int cgp_gppredictor_callback(const double *mean, const double *sigma, int M, con
  * (core_navigation/src/CoreNav.cpp:176,244-330; stopCallback :755-759; getCmdData :794-816).
  * cgp_recorder_update = one 10 Hz odometry update: wheel ground speeds {FL, FR, BL, BR}, INS forward
  * speed, commanded speed.  Returns 1 when a GP_Input window is published this tick; it is then
- * copied to time_out / slipwin_out (at most cap entries, *n_out = its length).  *slip_out = the
- * tick's slip value (may be NULL). */
+ * copied to time_out / slipwin_out and *n_out = its length.  If the window is longer than `cap` the
+ * first cap entries are copied, *n_out still holds the full length and CGP_ECAPACITY is returned
+ * (never a silent truncation).  *slip_out = the tick's slip value (may be NULL). */
 typedef struct cgp_recorder cgp_recorder;
 cgp_recorder *cgp_recorder_create(void);
 void cgp_recorder_destroy(cgp_recorder *rec);

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--steps", "2", "--warmup", "1",
-                        "--cpu-sample", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--cpu-sample", "1", "--no-extra"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -25,7 +25,40 @@ def test_bench_line_contract():
     assert "workload" in j["config"] and "model" not in j["config"]
     rf = j["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf and "from" in rf
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["gpu_vs_oracle_max_rel_err"] < 1e-6
+    assert cb["host"]["cpu_model"] and "governor" in cb["host"] and cb["port_threads_over_batch"]["value"] > 0
+    assert "ablation_build" not in j and "dry_run" not in j
     assert j["value"] > 0 and j["config"]["single_fit_latency_ms"] > 0
+
+
+def test_bench_extra_lines():
+    """config.extra of the same driver command: the PCIe-inclusive rate, BASELINE configs[2] (512 x N=1024
+    fp32) on its own schedule, configs[3] (sliding window) and the batched look-ahead."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--steps", "1", "--warmup", "1",
+                        "--no-cpu"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    ex = j["config"]["extra"]
+    assert not [k for k in ex if k.endswith("_error")], ex
+    assert ex["end_to_end_fits_per_s"] > 0 and ex["end_to_end_matches_resident"] is True
+    assert ex["cfg3_fits_per_s"] > 0 and 0 < ex["cfg3_roofline_frac"] < 1 and ex["cfg3_max_rel_err_vs_oracle_fit0"] < 1e-3
+    assert ex["window_ticks_per_s"] > 0 and 0 < ex["window_hbm_frac"] < 1 and ex["lookahead_traj_per_s"] > 0
+
+
+def test_bench_gpus2_on_one_gpu():
+    """`bench.py --gpus 2` starts two ranks by itself; on a one-GPU box both use device 0
+    (CGP_BENCH_SAME_DEVICE) and the summaries travel over gloo (RCCL refuses two ranks on one GPU)."""
+    env = dict(os.environ, CGP_BENCH_SAME_DEVICE="1", CGP_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "16", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["ranks"] == 2 and len(j["config"]["per_rank_fits_per_s"]) == 2
+    assert j["config"]["ensemble"]["n"] == 32 and j["config"]["ensemble"]["n_failed"] == 0
+    assert "cpu_baseline" not in j and j["roofline"]["frac"] > 0

@@ -104,3 +104,27 @@ def test_optimize_batch_matches_single(engine):
         np.testing.assert_allclose(th[b], th1, rtol=1e-6)
         olml = go.optimize(2, X[b], y[b])[1]
         assert lml[b] >= olml - 1e-5 * abs(olml)
+
+
+def test_optimize_batch_climbs_the_jitter_ladder(engine):
+    """GPy's jitchol inside m.optimize(): a trial point whose matrix is not positive definite gets
+    mean(diag) 1e-6 10^k.  Window 1 has duplicated inputs and starts at amplitude 1e9 with (almost) no
+    noise, so its first factorisations fail without jitter; the batched optimiser must follow the same
+    trajectory as the single-window one (which always had the ladder) instead of treating the point as
+    infeasible, and the healthy window next to it must be unaffected."""
+    N = 96
+    rng = np.random.default_rng(77)
+    xa = np.sort(rng.normal(size=N))
+    xb = np.repeat(np.sort(rng.normal(size=N // 2)), 2)
+    X = np.stack([xa, xb])[:, :, None]
+    y = np.sin(2.0 * X[:, :, 0]) + 0.01 * rng.normal(size=(2, N))
+    y[1] = np.repeat(y[1][::2], 2)
+    th0 = np.array([[1.0, 1.0, 1.0], [1e9, 1.0, 1e-10]])
+    ctx = engine.Context(max_n=N, max_m=N, max_d=1, max_batch=2)
+    th, lml, nev = ctx.optimize_batch(X, y, 0, th0.copy(), max_evals=60)
+    ctx1 = engine.Context(max_n=N, max_m=N, max_d=1)
+    assert ctx1.nll_grad(X[1], y[1], 0, th0[1])[0] is not None and ctx1.last_jitter() > 0   # the ladder is needed
+    for b in range(2):
+        th1, lml1, nev1 = ctx1.optimize(X[b], y[b], 0, th0[b].copy(), max_evals=60)
+        assert np.isfinite(lml[b]) and lml[b] == pytest.approx(lml1, rel=1e-6)
+        np.testing.assert_allclose(th[b], th1, rtol=1e-4)

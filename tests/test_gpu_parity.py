@@ -202,6 +202,44 @@ def test_config3_fp32_batch(engine):
         assert abs(logml[b] - f.logml) <= TOL32 * abs(f.logml)
 
 
+def test_config3_fp32_full_size_throughput_schedule(engine):
+    """BASELINE configs[2] at its own size AND on the schedule the 512-fit sweep takes: N=1024 d=6 fp32,
+    M=599, 8 fits (> 4 -> k_diag_lean + k_panel<float>), every fit against the oracle at north_star's
+    fp32 bar (1e-3), per-fit random length-scales as SURVEY.md 8d prescribes for cfg3."""
+    kid, X, y, Xs, th, _ = synth.config(3, batch=8)
+    ctx = engine.Context(max_n=1024, max_m=599, max_d=6, max_batch=8, dtype=engine.F32)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not info.any()
+    for b in range(8):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        assert relmax(mean[b], omu) < TOL32 and releach(var[b], ovar) < TOL32
+        assert abs(logml[b] - f.logml) <= TOL32 * abs(f.logml)
+
+
+def test_config3_fp32_batch512_properties(engine):
+    """The full configs[2] workload (512 x N=1024 d=6 fp32, what bench.py's cfg3 line times) through
+    size-independent properties: every fit factors (info == 0), the predictive variance never drops
+    below the noise floor, a sample of fits meets the oracle, and a fit's outputs do not depend on its
+    slot in the batch (bitwise under a permutation of the 512 slots)."""
+    B = 512
+    kid, X, y, Xs, th, _ = synth.config(3, batch=B)
+    ctx = engine.Context(max_n=1024, max_m=599, max_d=6, max_batch=B, dtype=engine.F32)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not info.any()
+    assert np.all(np.isfinite(mean)) and np.all(np.isfinite(logml))
+    assert np.all(var >= th[:, -1:] * (1 - 1e-6))
+    for b in (0, 257, 511):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        assert relmax(mean[b], omu) < TOL32 and releach(var[b], ovar) < TOL32
+        assert abs(logml[b] - f.logml) <= TOL32 * abs(f.logml)
+    perm = np.random.default_rng(5).permutation(B)
+    rc, m2, v2, l2, i2 = ctx.fit_predict_batch(X[perm], y[perm], Xs[perm], th[perm], kid)
+    assert rc == 0 and not i2.any()
+    assert np.array_equal(m2, mean[perm]) and np.array_equal(v2, var[perm]) and np.array_equal(l2, logml[perm])
+
+
 def test_jitter_policy_and_failure(engine):
     """GPy jitchol: a matrix that is not PD gets mean(diag)*1e-6*10^k; hopeless input returns info."""
     X = np.zeros((40, 1))
@@ -298,11 +336,17 @@ def test_alternate_schedules_match_oracle(env):
     multi-tile fp64 and fp32 problems."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # the alternatives are not in the shipped library: `make ab` builds them into libcorenav_gp_ab.so
+    ab = os.path.join(root, "corenav-gp_amd", "libcorenav_gp_ab.so")
+    if not os.path.exists(ab):
+        pytest.skip("libcorenav_gp_ab.so not built (make -C corenav-gp_amd/csrc ab)")
+    env = dict(env, CGP_LIB=ab)
     code = (
         "import sys; sys.path.insert(0, %r)\n"
         "import numpy as np\n"
         "from corenav_gp_amd import engine, synth\n"
         "from oracle import gp_oracle as go\n"
+        "assert engine.load().cgp_build_flags() & engine.BUILD_AB\n"
         "for dtype, tol, N in ((engine.F64, 1e-6, 700), (engine.F32, 1e-3, 300)):\n"
         "    kid, X, y, Xs, th, _ = synth.config(2, N=N)\n"
         "    ctx = engine.Context(max_n=N, max_m=Xs.shape[1], max_d=X.shape[2], max_batch=2, dtype=dtype)\n"
@@ -374,3 +418,65 @@ def test_stream_groups_do_not_change_results(engine):
             ref = (mean, var, logml)
         else:
             assert np.array_equal(mean, ref[0]) and np.array_equal(var, ref[1]) and np.array_equal(logml, ref[2])
+
+
+def test_shipped_library_has_no_ablation_switches(engine):
+    """The product library is built without -DCGP_ABLATION / -DCGP_AB: a stray CGP_DBG cannot skip
+    arithmetic and the A/B schedules are not in it."""
+    import os
+    if os.environ.get("CGP_LIB"):
+        pytest.skip("CGP_LIB selects a measurement build")
+    assert engine.load().cgp_build_flags() == 0
+
+
+def test_default_stream_ordering(engine):
+    """hip_stream = NULL is the legacy default stream itself: inputs produced by default-stream kernels
+    right before the call and outputs consumed right after it need no host synchronisation."""
+    import torch
+    kid, X, y, Xs, th, _ = synth.config(2, batch=6, N=300)
+    B, N, d = X.shape
+    M = Xs.shape[1]
+    dev = torch.device("cuda", 0)
+    ctx = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=B)
+    thp = np.zeros((B, engine.MAX_THETA))
+    thp[:, :th.shape[1]] = th
+    hX = torch.from_numpy(np.ascontiguousarray(X.transpose(0, 2, 1)))
+    dXs = torch.from_numpy(np.ascontiguousarray(Xs.transpose(0, 2, 1))).to(dev)
+    dy, dth = torch.from_numpy(y).to(dev), torch.from_numpy(thp).to(dev)
+    big = torch.randn(64 << 20, device=dev)
+    out = []
+    for rep in range(3):
+        dmean, dvar = torch.empty((B, M), device=dev, dtype=torch.float64), torch.empty((B, M), device=dev, dtype=torch.float64)
+        dlogml, dinfo = torch.empty(B, device=dev, dtype=torch.float64), torch.zeros(B, device=dev, dtype=torch.int32)
+        big = big * 1.0001 + 1.0                        # keeps the default stream busy ahead of the producer
+        dX = (hX.to(dev, non_blocking=True) * 2.0) * 0.5  # produced by default-stream kernels, no sync
+        ctx.fit_predict_batch_device(B, N, d, M, kid, dX.data_ptr(), dy.data_ptr(), dXs.data_ptr(), dth.data_ptr(), 0,
+                                     True, dmean.data_ptr(), dvar.data_ptr(), dlogml.data_ptr(), dinfo.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+        out.append((dmean.sum() + dlogml.sum()).item())   # consumer on the default stream
+        assert int(dinfo.abs().sum().item()) == 0
+    f = go.fit(kid, th[0], X[0], y[0])
+    assert abs(dlogml[0].item() - f.logml) <= TOL64 * abs(f.logml)
+    assert out[0] == out[1] == out[2]
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_sweep_matches_single_context(engine, devices):
+    """cgp_sweep_* (the C-ABI multi-device entry of SURVEY.md 8b / 8e): block partition over per-device
+    contexts on their own host threads; results bitwise equal to one context running the whole batch,
+    summaries in global fit order.  A one-GPU box names device 0 several times (one context each)."""
+    kid, X, y, Xs, th, _ = synth.config(2, batch=16, N=300)   # every shard > 4 fits: throughput schedule
+    B = X.shape[0]
+    ctx = engine.Context(max_n=300, max_m=599, max_d=6, max_batch=B)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0
+    sw = engine.Sweep(devices, 300, 599, 6, B)
+    assert sw.ndev == len(devices)
+    cover = [sw.shard(B, i) for i in range(sw.ndev)]
+    assert cover[0][0] == 0 and cover[-1][1] == B and all(cover[i][1] == cover[i + 1][0] for i in range(sw.ndev - 1))
+    from corenav_gp_amd import sharding
+    assert cover == [sharding.shard_range(B, i, sw.ndev) for i in range(sw.ndev)]
+    rc, m2, v2, l2, i2, summ = sw.fit_predict(X, y, Xs, th, kid)
+    assert rc == 0 and not i2.any()
+    assert np.array_equal(m2, mean) and np.array_equal(v2, var) and np.array_equal(l2, logml)
+    assert np.array_equal(summ[:, 0], logml) and np.allclose(summ[:, 1], 2 * np.sqrt(var.max(1))) and not summ[:, 2].any()

@@ -75,3 +75,19 @@ def test_short_window_is_skipped_and_slip_clamps():
     # INS much faster than the wheels: raw slip < -1 clamps to -1 and is excluded from windows
     assert rec.update(0.5, 0.5, 0.5, 0.5, 2.0, 1.0) is None and rec.slip == -1.0
     assert rec.state()["first_driving_flag"] == 1.0
+
+
+def test_window_longer_than_the_callers_buffer_is_an_error():
+    """cgp_recorder_update never truncates silently: a 149-sample window into a 100-entry buffer returns
+    CGP_ECAPACITY with *n_out = 149."""
+    rec = engine.SlipRecorder()
+    seen = False
+    for wheels, vlin, cmd in drive_stream(9, T=200, stops=False):
+        try:
+            got = rec.update(*wheels, vlin, cmd, cap=100)
+            assert got is None
+        except engine.CgpError as e:
+            assert e.code == -6
+            seen = True
+            break
+    assert seen
