@@ -154,9 +154,6 @@ template <typename T> int set_lds_attrs(int device) {
   ok = ok && set(reinterpret_cast<const void *>(&k_trmm_sk<T>), upd);
   ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T>), paneldiag_lds_bytes<T>());
 #ifdef CGP_AB
-  ok = ok && set(reinterpret_cast<const void *>(&k_update<T>), upd);
-  ok = ok && set(reinterpret_cast<const void *>(&k_potf2<T>), tile);
-  ok = ok && set(reinterpret_cast<const void *>(&k_trmm<T>), upd);
   ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true>), paneldiag_lds_bytes<T>());
   ok = ok && set(reinterpret_cast<const void *>(&k_diag<T>), tile);
 #endif
@@ -167,14 +164,6 @@ template <typename T> int set_lds_attrs(int device) {
 
 // Algorithmic flops of the update launches of block step k (DESIGN.md "Kernels"): lower-trapezoid
 // entries of block column k times a 2*(k*128)-flop inner product, plus (3d+2) per Gram entry.
-#ifdef CGP_AB
-double update_flops(int N, int M, int d, int k, bool in_rows, int batch) {
-  const double w = std::min(TS, N - k * TS);
-  const double rows_in = in_rows ? ((double)(N - k * TS) * w - w * (w - 1) / 2.0) : 0.0;
-  const double rows_ex = (double)(M + 1) * w;
-  return batch * ((rows_in + rows_ex) * 2.0 * (double)(k * TS) + (3.0 * d + 2.0) * (rows_in + (double)M * w));
-}
-#endif
 double trsm_flops(int N, int M, int k, bool in_rows, int batch) {
   const double w = std::min(TS, N - k * TS);
   const double rows = (in_rows ? std::max(0, N - (k + 1) * TS) : 0) + (M + 1);
@@ -218,11 +207,11 @@ template <typename T> FitArgs group_view(const FitArgs &a, int g0) {
 
 // A/B switches of the schedule.  The shipped library has ONE schedule pair (throughput: k_diag_lean +
 // k_panel with running predictive sums; latency: k_tile_sk + k_trmm_sk for <= LAT_FITS fits); the
-// alternatives measured in DESIGN.md (classic three-launch, two-stream overlap, fused next diagonal,
+// alternatives measured in DESIGN.md (two-stream overlap, fused next diagonal,
 // fat diagonal, finalize without accumulators, fused trmm) exist only in a -DCGP_AB build, where the
 // environment selects them once per process.
 struct SchedSwitches {
-  bool no_latency = false, classic = false, fuse_next_diag = false, overlap = false, fat_diag = false, acc_off = false,
+  bool no_latency = false, fuse_next_diag = false, overlap = false, fat_diag = false, acc_off = false,
        sk_fused_trmm = false;
 };
 const SchedSwitches &sched_switches() {
@@ -234,8 +223,7 @@ const SchedSwitches &sched_switches() {
     const std::string sch = e ? e : "";
     w.no_latency = sch == "throughput";
 #ifdef CGP_AB
-    w.no_latency = w.no_latency || sch == "classic" || sch == "overlap" || sch == "fuseddiag";
-    w.classic = sch == "classic";
+    w.no_latency = w.no_latency || sch == "overlap" || sch == "fuseddiag";
     w.fuse_next_diag = sch == "fuseddiag";
     w.overlap = sch == "overlap";
     const char *dg = getenv("CGP_DIAG");
@@ -296,7 +284,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // throughput schedule: the predictive sums V z and |V|^2 accumulate inside k_panel (block column
   // k - 1 while it streams through the row fragments of step k); k_finalize then only adds the last
   // block column instead of reading all of V.
-  const bool use_acc = !sw.classic && !latency && !sw.acc_off && a.M > 0 && !a.xid;
+  const bool use_acc = !latency && !sw.acc_off && a.M > 0 && !a.xid;
   if (use_acc) {
     const size_t half = (size_t)batch * a.M;
     for (int g = 0, g0 = 0; g < G; g0 += gb[g], ++g) {
@@ -390,21 +378,6 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     const int gx_t = (in_rows ? a.NT - k - 1 : 0) + a.ET;
     for (int g = 0; g < G; ++g) {
 #ifdef CGP_AB
-      if (sw.classic) {  // three launches per step, S tile through HBM (kept for A/B measurements)
-        const int gx_u = (in_rows ? a.NT - k : 0) + a.ET;
-        L[g].begin(0, update_flops(a.N, a.M, a.d, k, in_rows, gb[g]));
-        hipLaunchKernelGGL(k_update<T>, dim3(gx_u, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
-        L[g].end();
-        if (in_rows) {
-          L[g].begin(1, gb[g] * (double)TS * TS * TS / 3.0);
-          hipLaunchKernelGGL(k_potf2<T>, dim3(gb[g]), dim3(256), tile_lds, gs[g], ga[g], k);
-          L[g].end();
-        }
-        L[g].begin(2, trsm_flops(a.N, a.M, k, in_rows, gb[g]));
-        hipLaunchKernelGGL(k_trmm<T>, dim3(gx_t, gb[g]), dim3(256), upd_lds, gs[g], ga[g], k);
-        L[g].end();
-        continue;
-      }
       // CGP_SCHED=fuseddiag: diagonal tile k+1 rides in the panel launch of step k (measured: +0.6 %
       // fp64 N=2048, -5 % fp32 N=1024 -- DESIGN.md)
       const bool fuse_next = sw.fuse_next_diag && in_rows && k + 1 < a.NT;
@@ -608,7 +581,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   c->ETmax = cdiv(max_m + 1, TS);
   c->ld = (c->NTmax + c->ETmax) * TS;
   c->lw_stride = (size_t)c->ld * c->NTmax * TS;
-  c->winv_stride = (size_t)c->NTmax * TS * TS;
+  c->winv_stride = (size_t)c->NTmax * WIMG;
   c->alpha_stride = (size_t)c->NTmax * TS;
   const size_t B = max_batch;
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;

@@ -35,6 +35,13 @@ constexpr int MAX_THETA = MAXD + 2;
 constexpr int PREP_N = 16;  // prep[0..7] 1/ell_q, [8] log amp (SE) or 0, [9] amp, [10] amp_b, [11] diag add
 constexpr int GRAD_N = 12;  // k_grad sums: [0] amplitude, [1..8] length-scales, [9] noise
 constexpr int LDP = TS + 2;   // LDS leading dimension of the potf2 tile (2-way conflicts at most)
+constexpr int NCB = TS / DB;  // 8 column blocks of 16
+// W_k = L(k,k)^-1 is kept in HBM as the exact LDS image the in-register trmm reads: its 36 lower 16x16
+// blocks, NEGATED (the panel accumulators hold -S),
+//   Wimg[blk(cb, qb)][q][c] = -W[cb*16 + c][qb*16 + q],   blk(cb, qb) = cb (cb + 1) / 2 + qb,  qb <= cb,
+// so staging it is a straight 16-byte-per-lane LDS-DMA copy of 36 (fp32) / 72 (fp64) KiB.
+constexpr int WIMG = NCB * (NCB + 1) / 2 * DB * DB;
+__host__ __device__ __forceinline__ constexpr int wimg_blk(int cb, int qb) { return (cb * (cb + 1) / 2 + qb) * DB * DB; }
 
 enum { K_SE_ISO = 0, K_SE_ARD = 1, K_RBF_BROWNIAN = 2 };
 
@@ -48,7 +55,7 @@ struct FitArgs {
   const double *theta;   // [batch][MAX_THETA]
   const double *jitter;  // [batch] or nullptr
   const double *prep;    // [batch][PREP_N] per-fit derived constants written by k_prep
-  void *Winv;            // [batch][NTmax][128*128]  W_k = L(k,k)^-1, column-major, lower triangular
+  void *Winv;            // [batch][NTmax][WIMG]  negated block image of W_k = L(k,k)^-1 (see WIMG)
   size_t winv_stride;    // elements per fit
   int *info;             // [batch]
   void *mean, *var;      // [batch][M]
@@ -195,106 +202,6 @@ __device__ __forceinline__ double rdlane(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-#ifdef CGP_AB  // first-generation three-launch schedule (k_update -> k_potf2 -> k_trmm), A/B builds only
-// --------------------------------------------------------------------------------------------------
-// The MFMA inner loop shared by k_update and k_trmm:
-//   acc[i][j] (+)= sum_q  Cop[cl][q] * Rop[rl][q]      over nchunk chunks of KT columns
-// Rop = "row panel" (128 rows x K), Cop = "column panel" (128 rows x K), both column-major in global
-// memory (K runs along columns, leading dimensions ldR / ldC).  256 threads = 4 waves as 2x2, each
-// wave owns a 64x64 block of the 128x128 result as 4x4 MFMA 16x16x4 accumulators:
-//   acc[i][j][reg] = C[row = wr*64 + j*16 + (lane&15)][col = wc*64 + i*16 + drow(lane,reg)]
-// (MFMA "A" operand = Cop, "B" operand = Rop, so lane&15 runs along result rows, which are
-// contiguous in the column-major destination).  Chunks are staged global -> registers -> LDS with
-// one chunk of prefetch; LDS rows are padded to LDST so the four k-groups of an operand read fall in
-// disjoint bank halves.  TRI: Cop is lower-triangular in (cl, q) (a 128x128 inverse factor), so
-// 16-column fragments whose every entry has q > cl are skipped (half the MFMAs).
-// --------------------------------------------------------------------------------------------------
-template <typename T, bool TRI>
-__device__ __forceinline__ void mfma_panel_loop(typename Prec<T>::acc_t (&acc)[4][4], const T *gR, size_t ldR,
-                                                const T *gC, size_t ldC, int nchunk, T *smem, int tid, int dbg = 0) {
-  using P = Prec<T>;
-  using vec8 = T __attribute__((ext_vector_type(8)));
-  constexpr int CH = KT * LDST;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int l15 = lane & 15, lq = lane >> 4;
-
-  auto compute = [&](const T *cur, int c) {
-#pragma unroll
-    for (int ks = 0; ks < KT / 4; ++ks) {
-      T fa[4], fb[4];
-      const T *ra = cur + CH + (ks * 4 + lq) * LDST + wc * 64 + l15;  // column panel -> result columns
-      const T *rb = cur + (ks * 4 + lq) * LDST + wr * 64 + l15;       // row panel    -> result rows
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = ra[i * 16];
-        fb[i] = rb[i * 16];
-      }
-      const int q0 = c * KT + ks * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (TRI && q0 > wc * 64 + i * 16 + 15) continue;  // wave-uniform: whole fragment is zero
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = P::mfma(fa[i], fb[j], acc[i][j]);
-      }
-    }
-  };
-
-  if constexpr (sizeof(T) == 8) {
-    // fp64: global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write).  One
-    // wave-instruction moves one 1 KiB column (128 rows): lane -> rows 2*lane, 2*lane+1; the LDS
-    // destination is wave-uniform base + lane*16 B, which the column-padded image satisfies.
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void gbl_void;
-    auto stage = [&](T *buf, int chunk) {
-#pragma unroll
-      for (int i = 0; i < KT / 4; ++i) {
-        const int col = wave * (KT / 4) + i;
-        __builtin_amdgcn_global_load_lds((gbl_void *)(gR + (size_t)(chunk * KT + col) * ldR + lane * 2),
-                                         (lds_void *)(buf + col * LDST), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void *)(gC + (size_t)(chunk * KT + col) * ldC + lane * 2),
-                                         (lds_void *)(buf + CH + col * LDST), 16, 0, 0);
-      }
-    };
-    if (nchunk > 0) stage(smem, 0);
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-      if (c + 1 < nchunk && !(dbg & 1)) stage(smem + ((c + 1) & 1) * 2 * CH, c + 1);
-      compute(smem + (c & 1) * 2 * CH, c);
-      if (!(dbg & 4)) __syncthreads();
-    }
-  } else {
-    // fp32: register-staged (a 512-byte column does not fill a 1 KiB LDS-DMA wave-instruction)
-    const int sc = tid >> 4, sr = (tid & 15) * 8;  // staging: column sc of the chunk, rows sr..sr+7
-    gR += sr;
-    gC += sr;
-    vec8 pr, pc;
-    if (nchunk > 0) {
-      pr = *reinterpret_cast<const vec8 *>(gR + (size_t)sc * ldR);
-      pc = *reinterpret_cast<const vec8 *>(gC + (size_t)sc * ldC);
-      *reinterpret_cast<vec8 *>(smem + sc * LDST + sr) = pr;
-      *reinterpret_cast<vec8 *>(smem + CH + sc * LDST + sr) = pc;
-    }
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-      if (c + 1 < nchunk) {
-        pr = *reinterpret_cast<const vec8 *>(gR + (size_t)((c + 1) * KT + sc) * ldR);
-        pc = *reinterpret_cast<const vec8 *>(gC + (size_t)((c + 1) * KT + sc) * ldC);
-      }
-      compute(smem + (c & 1) * 2 * CH, c);
-      if (c + 1 < nchunk) {
-        T *nxt = smem + ((c + 1) & 1) * 2 * CH;
-        *reinterpret_cast<vec8 *>(nxt + sc * LDST + sr) = pr;
-        *reinterpret_cast<vec8 *>(nxt + CH + sc * LDST + sr) = pc;
-      }
-      __syncthreads();
-    }
-  }
-}
-
-#endif  // CGP_AB
-
 // exp(x) for x <= 0 (every covariance exponent is -0.5 r^2): n = rint(x log2 e), r = x - n ln2 in
 // two pieces, degree-13 Horner polynomial on |r| <= ln2/2, v_ldexp for 2^n (denormal-exact).  The
 // argument is clamped at -800 (result 0) instead of being special-cased.  Coefficients live in
@@ -326,208 +233,6 @@ __device__ __forceinline__ double exp_nonpos(double x, const ExpC &e) {
   return __builtin_amdgcn_ldexp(q, (int)n);
 }
 __device__ __forceinline__ float exp_nonpos(float x, const ExpC &) { return __expf(fmaxf(x, -104.f)); }
-
-#ifdef CGP_AB
-// Gram tile G(rt, k) evaluated from the inputs, then S = G - acc, stored to the factor panel.
-// Column points (16 per lane) are the outer static loops, the 4 row points the inner one.
-// FAST: interior tile -- every row and column is a real point and no diagonal / y-row entry is in
-// it, so the padding and noise selects vanish; the other tiles take the general path.
-template <typename T, bool BROWN, bool FAST>
-__device__ __forceinline__ void gram_tile(const FitArgs &p, typename Prec<T>::acc_t (&acc)[4][4], T *__restrict__ out,
-                                          const T *__restrict__ xr, const T *__restrict__ xc, const T *__restrict__ yc,
-                                          bool extra, int rowbase, int colbase, T amp, T inv_ell, T amp_b, T diag_add,
-                                          int lane, int wr, int wc) {
-  using P = Prec<T>;
-  const int N = p.N, M = p.M, ld = p.ld, l15 = lane & 15;
-  ExpC ec;
-  ec.load();
-  T xrow[4][MAXD];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int q = 0; q < MAXD; ++q) xrow[j][q] = (BROWN && q > 0) ? T(0) : xr[(wr * 64 + j * 16 + l15) * MAXD + q];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int cl = wc * 64 + i * 16 + P::drow(lane, r);  // local result column
-      const int gcol = colbase + cl;
-      T xcol[MAXD];
-#pragma unroll
-      for (int q = 0; q < MAXD; ++q) xcol[q] = (BROWN && q > 0) ? T(0) : xc[cl * MAXD + q];
-      const T ycl = FAST ? T(0) : yc[cl];
-      const bool colok = gcol < N;
-      T *__restrict__ ocol = out + (size_t)cl * ld + wr * 64 + l15;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int grow = rowbase + wr * 64 + j * 16 + l15;
-        T g;
-        if (!BROWN) {
-          T d2 = 0;
-#pragma unroll
-          for (int q = 0; q < MAXD; ++q) {
-            const T df = xrow[j][q] - xcol[q];
-            d2 = __builtin_fma(df, df, d2);
-          }
-          g = CGP_DBG_ON(p, 32) ? d2 : amp * exp_nonpos(T(-0.5) * d2, ec);
-        } else {
-          const T x = xrow[j][0], xp = xcol[0];
-          const bool same = !FAST && !extra && grow == gcol;  // GPy forces r^2 = 0 on the auto-covariance diagonal
-          T r2 = same ? T(0) : (T(-2) * x * xp + (x * x + xp * xp));
-          r2 = r2 < T(0) ? T(0) : r2;
-          const T rr = P::sqrt_(r2) * inv_ell;
-          const int sx = (x > T(0)) - (x < T(0)), sp = (xp > T(0)) - (xp < T(0));
-          const T ax = x < T(0) ? -x : x, ap = xp < T(0) ? -xp : xp;
-          const T kb = (sx == sp) ? amp_b * (ax < ap ? ax : ap) : T(0);
-          g = amp * exp_nonpos(T(-0.5) * rr * rr, ec) * kb;
-        }
-        if (!FAST) {
-          if (!extra) {
-            const bool dg = grow == gcol;
-            g = dg ? g + diag_add : g;
-            g = (grow < N && colok) ? g : (dg ? T(1) : T(0));  // identity padding keeps the factor well defined
-          } else {
-            g = (grow == M) ? ycl : g;
-            g = (!colok || grow > M) ? T(0) : g;
-          }
-        }
-        if (!CGP_DBG_ON(p, 16) || g == T(12345)) ocol[j * 16] = g - acc[i][j][r];
-      }
-      __builtin_amdgcn_sched_barrier(0);  // keep the 16 column points from being software-pipelined into spills
-    }
-  }
-}
-
-template <typename T, bool BROWN>
-__device__ __forceinline__ void gram_epilogue(const FitArgs &p, typename Prec<T>::acc_t (&acc)[4][4],
-                                              T *__restrict__ Lw, T *__restrict__ smem, int b, int k, int rt, int tid) {
-  const double *__restrict__ th = p.theta + (size_t)b * MAX_THETA;
-  const int kid = p.kernel_id, d = p.d, N = p.N, M = p.M, ld = p.ld;
-  const bool extra = rt >= p.NT;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  T *xr = smem;                    // [128][MAXD] rows of this tile (training or test points), zero padded
-  T *xc = smem + TS * MAXD;        // [128][MAXD] columns = training points of tile k
-  T *yc = smem + 2 * TS * MAXD;    // [128] y of the tile-k columns (only the y row uses it)
-  const T *__restrict__ Xb = reinterpret_cast<const T *>(p.X) + (size_t)b * d * N;
-  const T *__restrict__ Xsb = reinterpret_cast<const T *>(p.Xs) + (size_t)b * d * M;
-  const T *__restrict__ yb = reinterpret_cast<const T *>(p.y) + (size_t)b * N;
-  for (int idx = tid; idx < MAXD * TS; idx += 256) {
-    const int q = idx >> 7, r = idx & 127;
-    T vc = T(0), vr = T(0);
-    if (q < d) {
-      T sc_q = T(1);
-      if (kid == K_SE_ISO) sc_q = T(1.0 / th[1]);
-      else if (kid == K_SE_ARD) sc_q = T(1.0 / th[1 + q]);
-      const int gc = k * TS + r;
-      if (gc < N) vc = Xb[(size_t)q * N + gc] * sc_q;
-      if (!extra) {
-        const int gr = rt * TS + r;
-        if (gr < N) vr = Xb[(size_t)q * N + gr] * sc_q;
-      } else {
-        const int e = (rt - p.NT) * TS + r;
-        if (e < M) vr = Xsb[(size_t)q * M + e] * sc_q;
-      }
-    }
-    xc[r * MAXD + q] = vc;
-    xr[r * MAXD + q] = vr;
-  }
-  if (tid < TS) {
-    const int gc = k * TS + tid;
-    yc[tid] = (gc < N) ? yb[gc] : T(0);
-  }
-  __syncthreads();
-  const T amp = T(th[0]);
-  const T inv_ell = BROWN ? T(1.0 / th[1]) : T(1);
-  const T amp_b = BROWN ? T(th[2]) : T(0);
-  const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
-  const T diag_add = T(th[nth - 1] + 1e-8 + (p.jitter ? p.jitter[b] : 0.0));
-  const int rowbase = extra ? (rt - p.NT) * TS : rt * TS;  // global row index of local row 0
-  const int colbase = k * TS;
-  T *__restrict__ out = Lw + (size_t)rt * TS + (size_t)colbase * ld;
-  const bool cols_full = colbase + TS <= N;
-  const bool fast = cols_full && (extra ? (rowbase + TS <= M) : (rt != k && rowbase + TS <= N));
-  if (fast) gram_tile<T, BROWN, true>(p, acc, out, xr, xc, yc, extra, rowbase, colbase, amp, inv_ell, amp_b, diag_add, lane, wr, wc);
-  else gram_tile<T, BROWN, false>(p, acc, out, xr, xc, yc, extra, rowbase, colbase, amp, inv_ell, amp_b, diag_add, lane, wr, wc);
-}
-
-// --------------------------------------------------------------------------------------------------
-// k_update: S(rt, k) = Gram(rt, k) - sum_{j < k} L(rt, j) L(k, j)^T   (a2 gram + a3 syrk/gemm + a8)
-// grid (row tiles, batch).  The Gram tile is evaluated from the inputs in the epilogue, so Ky and
-// K* never exist in HBM.
-// --------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_update(FitArgs p, int k) {
-  using P = Prec<T>;
-  using acc_t = typename P::acc_t;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T *smem = reinterpret_cast<T *>(smem_raw);
-
-  int bt, b;
-  tile_fit_of_block(bt, b);
-  const int rt = row_tile_of(bt, k, p.NT, p.rows_from_extra);
-  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
-  const int ld = p.ld;
-  const int tid = threadIdx.x;
-
-  acc_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-
-  mfma_panel_loop<T, false>(acc, Lw + (size_t)rt * TS, (size_t)ld, Lw + (size_t)k * TS, (size_t)ld,
-                            (k * TS) / KT, smem, tid, p.dbg);
-  if (CGP_DBG_ON(p, 8)) return;
-
-  // ---- epilogue: Gram tile from the inputs, S = G - acc ----
-  if (p.kernel_id == K_RBF_BROWNIAN) gram_epilogue<T, true>(p, acc, Lw, smem, b, k, rt, tid);
-  else gram_epilogue<T, false>(p, acc, Lw, smem, b, k, rt, tid);
-}
-
-// --------------------------------------------------------------------------------------------------
-// k_trmm: L(rt, k) = S(rt, k) W_k^T with W_k = L(k,k)^-1 from k_potf2 (a3 "trsm_panel" and, for the
-// extra tiles, a8 "trsm_var", done as a triangular MFMA product instead of a substitution).
-// grid (row tiles below k, batch).  In place: a workgroup reads only its own tile before writing it.
-// --------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_trmm(FitArgs p, int k) {
-  using P = Prec<T>;
-  using acc_t = typename P::acc_t;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T *smem = reinterpret_cast<T *>(smem_raw);
-  int bt, b;
-  tile_fit_of_block(bt, b);
-  const int rt = row_tile_of(bt, k + 1, p.NT, p.rows_from_extra);
-  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
-  const int ld = p.ld;
-  const T *Wk = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * TS * TS;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int l15 = lane & 15;
-  acc_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-  T *tile = Lw + (size_t)(k * TS) * ld + (size_t)rt * TS;
-  mfma_panel_loop<T, true>(acc, tile, (size_t)ld, Wk, (size_t)TS, TS / KT, smem, tid);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rl = wr * 64 + j * 16 + l15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cl = wc * 64 + i * 16 + P::drow(lane, r);
-        tile[(size_t)cl * ld + rl] = acc[i][j][r];
-      }
-  }
-}
-
-#endif  // CGP_AB
 
 // One 16x16 diagonal block in the registers of a wavefront: lane holds row (lane & 15) of the block
 // in a[] (replicated over the four 16-lane groups).  On return a[] holds the row of the Cholesky
@@ -775,47 +480,29 @@ __device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, i
   }
 }
 
-// Phase (e): write L (upper triangle zeroed) to the factor panel and W_k (column-major 128 x 128).
+// Phase (e): write L (upper triangle zeroed) to the factor panel and the block image of -W_k.
 template <typename T>
 __device__ __forceinline__ void potf2_store(const FitArgs &p, const T *At, const T *Dv, const int *flag, T *tile,
                                             int ld, int b, int k, int tid) {
   if (tid == 0 && *flag != 0 && p.info[b] == 0) p.info[b] = *flag;
-  T *Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * TS * TS;
+  T *Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * WIMG;
   for (int idx = tid; idx < TS * TS; idx += 256) {
     const int c = idx >> 7, r = idx & 127;
     tile[(size_t)c * ld + r] = (r >= c) ? At[c * LDP + r] : T(0);
-    T w = T(0);
-    if (r >= c) {
-      if ((r >> 4) == (c >> 4)) w = Dv[(r >> 4) * DB * DB + (c & 15) * DB + (r & 15)];
-      else w = At[r * LDP + c];
+  }
+  for (int idx = tid; idx < WIMG; idx += 256) {
+    const int blk = idx >> 8, q = (idx >> 4) & 15, cc = idx & 15;
+    int cb = 0, rem = blk;
+    while (rem > cb) {
+      rem -= cb + 1;
+      ++cb;
     }
-    Wk[(size_t)c * TS + r] = w;
+    const int qb = rem, r = cb * DB + cc, c = qb * DB + q;  // W[r][c]
+    // diagonal blocks: Dv[jb][q][x] = Dinv_jb[x][q] (zero above the diagonal); others: W^T in the upper triangle of At
+    const T w = (cb == qb) ? Dv[cb * DB * DB + q * DB + cc] : At[r * LDP + c];
+    Wk[idx] = -w;
   }
 }
-
-#ifdef CGP_AB
-template <typename T>
-__global__ __launch_bounds__(256) void k_potf2(FitArgs p, int k) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T *At = reinterpret_cast<T *>(smem_raw);  // element (r, c) at At[c * LDP + r]
-  T *Dv = At + TS * LDP;                     // Dv[jb][q][x] = Dinv_jb[x][q]
-  T *Ts = Dv + 8 * DB * DB;                  // per-wave 16x16 scratch
-  int *flag = reinterpret_cast<int *>(Ts + 4 * DB * DB);
-  const int b = blockIdx.x, tid = threadIdx.x;
-  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
-  const int ld = p.ld;
-  T *tile = Lw + (size_t)(k * TS) * ld + (size_t)k * TS;
-  for (int idx = tid; idx < TS * TS; idx += 256) {
-    const int c = idx >> 7, r = idx & 127;
-    At[c * LDP + r] = tile[(size_t)c * ld + r];
-  }
-  if (tid == 0) *flag = 0;
-  __syncthreads();
-  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, nullptr, p.N - k * TS);
-  potf2_store<T>(p, At, Dv, flag, tile, ld, b, k, tid);
-}
-
-#endif  // CGP_AB
 
 // --------------------------------------------------------------------------------------------------
 // k_finalize: mean_m = V_m . z ; var_m = k** - |V_m|^2 (clip 1e-15, + sigma_n^2) ;
@@ -909,9 +596,9 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs p, int do_logml) {
 // of the factor panel.  Per 128-tile (last to first):
 //   rhs      = z_tile - L(below, tile)^T alpha(below)      one wave per column, shuffle reduction
 //   alpha_t  = L(t,t)^-T rhs = W_t^T rhs                    W_t = L(t,t)^-1 is already in Winv (the panel
-// kernels multiply by it), so the in-tile back substitution is a triangular matrix-vector product with
-// no sequential dependency: two barriers per tile instead of one per column.  Only entries r >= c of a
-// W_t column are read (at 16-row block granularity: the strictly upper 16x16 blocks are never written).
+// kernels multiply by it; negated block image, see WIMG), so the in-tile back substitution is a
+// triangular matrix-vector product with no sequential dependency: two barriers per tile instead of
+// one per column.
 // --------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_alpha(FitArgs p) {
@@ -934,11 +621,12 @@ __global__ __launch_bounds__(256) void k_alpha(FitArgs p) {
       if (lane == 0) rhs[cl] = (double)col[rb + M] - s;
     }
     __syncthreads();
-    const T *Wt = Winv + (size_t)tb * TS * TS;  // column-major: W[r][c] at Wt[c * 128 + r], zero for r < c
+    const T *Wt = Winv + (size_t)tb * WIMG;
     for (int cl = wave; cl < TS; cl += 4) {
-      const T *wc = Wt + (size_t)cl * TS;
+      const int qb = cl >> 4, q = cl & 15;
       double s = 0;
-      for (int r = (cl & ~(DB - 1)) + lane; r < TS; r += 64) s += (double)wc[r] * rhs[r];
+      for (int r = qb * DB + lane; r < TS; r += 64)   // -W[r][cl] at block (r >> 4, qb), entry [q][r & 15]
+        s -= (double)Wt[wimg_blk(r >> 4, qb) + q * DB + (r & 15)] * rhs[r];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
       if (lane == 0) al[c0 + cl] = s;

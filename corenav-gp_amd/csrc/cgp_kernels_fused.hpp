@@ -20,7 +20,6 @@
 
 namespace cgp {
 
-constexpr int NCB = TS / DB;  // 8 column blocks of 16
 
 // acc[cb][j][reg] = C[row = wave*32 + 2*(lane&15) + j][col = cb*16 + drow(lane, reg)].
 // Rows are interleaved (2*l15 + j) so one lane owns two adjacent rows: 16-byte stores, and the two
@@ -499,7 +498,8 @@ __device__ __forceinline__ void gram_prefetch(const FitArgs &p, int b, int k, in
 // acc <- G - acc.
 template <typename T, bool TRI = false>
 __device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
-                                           int b, int k, int rt, int tid, const GramPre<T> &g) {
+                                           int b, int k, int rt, int tid, const GramPre<T> &g, PhaseClock *pc = nullptr,
+                                           int slot = 0) {
   const double *__restrict__ pr = p.prep + (size_t)b * PREP_N;
   const int kid = p.kernel_id, N = p.N, M = p.M;
   const bool extra = rt >= p.NT;
@@ -533,6 +533,7 @@ __device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::a
     }
   }
   __syncthreads();
+  if (pc) pc->lap(p, slot);  // inputs fetched and staged
   const T amp = T(pr[9]), amp_b = T(pr[10]), diag_add = T(pr[11]);
   const int rowbase = extra ? (rt - p.NT) * TS : rt * TS;
   const int colbase = k * TS;
@@ -600,7 +601,7 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
         for (int i = 0; i < DB; ++i) {
           Dv[l15 * DB + i] = w[i];
           dvt[i * DB + l15] = w[i];
-          Wk[(size_t)(j0 + l15) * TS + j0 + i] = w[i];
+          Wk[wimg_blk(jb, jb) + l15 * DB + i] = -w[i];  // w[i] = W[j0 + i][j0 + l15]
         }
 #pragma unroll
         for (int c = 0; c < DB; ++c) tile[(size_t)(j0 + c) * ld + j0 + l15] = (l15 >= c) ? a[c] : T(0);
@@ -687,7 +688,7 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
     __syncthreads();
   }
   if (tid == 0 && bad != 0 && p.info[b] == 0) p.info[b] = bad;
-  // strictly lower blocks of W -> HBM (column-major 128 x 128, as the panel kernels stage it)
+  // strictly lower blocks of W -> the negated block image in HBM (Bk holds W_ij[r][c], the image [q = c][r])
   for (int idx = tid; idx < 28 * DB * DB; idx += 256) {
     const int blk = idx >> 8, e = idx & 255;
     int i = 1, rem = blk;
@@ -696,7 +697,7 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
       ++i;
     }
     const int j = rem, c = e >> 4, r = e & 15;
-    Wk[(size_t)(j * DB + c) * TS + i * DB + r] = Bk[tri_blk(i, j) + r * DB + c];
+    Wk[wimg_blk(i, j) + c * DB + r] = -Bk[tri_blk(i, j) + r * DB + c];
   }
 }
 
@@ -772,7 +773,7 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
     tile[(size_t)(i * DB + (e >> 4)) * ld + rem * DB + (e & 15)] = T(0);
   }
   __syncthreads();
-  T *Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)kn * TS * TS;
+  T *Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)kn * WIMG;
   diag_factor_packed<T>(p, smem, tile, ld, Wk, b, kn, tid);
 }
 
@@ -799,19 +800,22 @@ __device__ __forceinline__ void trmm_in_registers(const FitArgs &p, typename Pre
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
   const int lane = tid & 63, l15 = lane & 15;
-  // W_k (lower triangular) -> LDS as 36 blocks of 16x16: Wl[blk(cb,qb)][q][c] = W[cb*16 + c][qb*16 + q]
-  const T *__restrict__ Wk = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * TS * TS;
+  // -W_k's block image (WIMG) -> LDS, a straight copy by LDS-DMA: 1 KiB per wave-instruction, no VGPR
+  // staging, no ds_write.  Wl[blk(cb,qb)][q][c] = -W[cb*16 + c][qb*16 + q].
+  const T *__restrict__ Wk = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * WIMG;
   {
-    const int q = tid >> 4, c = tid & 15;
-    int cb = 0, qb = 0;
-#pragma unroll 6
-    for (int blk = 0; blk < NCB * (NCB + 1) / 2; ++blk) {
-      smem[blk * DB * DB + tid] = Wk[(size_t)(qb * DB + q) * TS + cb * DB + c];
-      if (++qb > cb) {
-        ++cb;
-        qb = 0;
-      }
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int PER = 1024 / (int)sizeof(T);            // elements per wave-instruction
+    constexpr int NI = WIMG / PER / 4;                     // wave-instructions per wave: 9 (fp32) / 18 (fp64)
+    static_assert(WIMG % (4 * PER) == 0, "image is a whole number of 4 KiB rounds");
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int off = (i * 4 + wave) * PER;
+      __builtin_amdgcn_global_load_lds((gbl_void *)(Wk + off + lane * (16 / (int)sizeof(T))), (lds_void *)(smem + off), 16, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
   if (pc) pc->lap(p, wslot);  // W_k staged
@@ -825,7 +829,7 @@ __device__ __forceinline__ void trmm_in_registers(const FitArgs &p, typename Pre
     for (int qb = 0; qb <= cb; ++qb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const T a = -wrow[qb * DB * DB + P::drow(lane, r) * DB];  // -W[cb*16 + l15][qb*16 + drow(lane, r)] (acc = -S)
+        const T a = wrow[qb * DB * DB + P::drow(lane, r) * DB];  // -W[cb*16 + l15][qb*16 + drow(lane, r)] (acc = -S)
         t0 = P::mfma(a, acc[qb][0][r], t0);
         t1 = P::mfma(a, acc[qb][1][r], t1);
       }
@@ -912,7 +916,7 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
       GramPre<T> gp;
       gram_prefetch<T>(p, b, k, rt, tid, gp);
       rdirect_prologue<T>(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
-      gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
+      gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
     }
     pc.lap(p, ps + 0);
     mfma_rowpanel_loop_rdirect<T>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
@@ -921,7 +925,7 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
       GramPre<T> gp;
       gram_prefetch<T>(p, b, k, rt, tid, gp);
       if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
-      gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp);
+      gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
     }
     pc.lap(p, ps + 0);
     mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, accm ? zs : nullptr, ms);

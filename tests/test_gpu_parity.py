@@ -285,9 +285,8 @@ def test_ragged_shapes_fp32(engine, N, d, M, kid):
     check_fit_predict(engine, kid, theta, X, y, Xs, engine.F32, TOL32)
 
 
-def test_classic_schedule_still_matches(engine, monkeypatch):
-    """The three-launch schedule kept for A/B (CGP_SCHED=classic is read once per process, so this only
-    checks the default path is the fused one and agrees with the oracle on a multi-tile problem)."""
+def test_multi_tile_single_fit(engine):
+    """A multi-tile single fit (N = 700: 6 block steps, ragged last tile) through cgp_fit / cgp_predict."""
     kid, X, y, Xs, th, _ = synth.config(2, N=700)
     check_fit_predict(engine, kid, th[0], X[0], y[0], Xs[0], engine.F64, TOL64)
 
@@ -325,13 +324,13 @@ def test_latency_schedule_is_deterministic(engine):
         assert np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3])
 
 
-@pytest.mark.parametrize("env", [{"CGP_SCHED": "classic"}, {"CGP_SCHED": "overlap"}, {"CGP_SCHED": "fuseddiag"},
+@pytest.mark.parametrize("env", [{"CGP_SCHED": "overlap"}, {"CGP_SCHED": "fuseddiag"},
                                  {"CGP_SCHED": "throughput"}, {"CGP_SCHED": "throughput", "CGP_DIAG": "fat"},
                                  {"CGP_SK_TRMM": "fused"}, {"CGP_SCHED": "throughput", "CGP_ACC": "off"}],
                          ids=lambda e: "-".join(e.values()))
 def test_alternate_schedules_match_oracle(env):
     """The schedules kept behind CGP_SCHED / CGP_DIAG for A/B measurements (read once per process, hence
-    the child process): three launches per step, two-stream look-ahead, next diagonal tile fused into
+    the child process): two-stream look-ahead, next diagonal tile fused into
     the panel launch, the 157 KB one-per-CU diagonal kernel.  Same parity bar as the default schedule,
     multi-tile fp64 and fp32 problems."""
     import os, subprocess, sys

@@ -22,7 +22,7 @@ W.step(); torch.cuda.synchronize(); W.ctx.debug_read()
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
 t0.record(); W.step(); t1.record(); torch.cuda.synchronize()
 out = W.ctx.debug_read()
-names = ["gram", "loop", "fold", "wstage", "trmm", "store"]
+names = ["gram", "loop", "fold", "wstage", "trmm", "store", "gfetch"]   # gfetch: kernel entry -> Gram inputs staged; gram: the tile itself
 rows = []
 for k in range(32):
     s = out[64 + 8 * k: 64 + 8 * k + 8]
