@@ -58,6 +58,7 @@ struct cgp_ctx {
   int *dticket = nullptr;  //                   arrival tickets [LAT_FITS][slots]
   int *dwready = nullptr;  //                   published block steps [LAT_FITS]
   double *dmacc = nullptr;  // [max_batch][2][max_m] running predictive sums (throughput schedule, fp64)
+  void *ddiagimg = nullptr;  // [max_batch][2][DPART] pre-updated diagonal tiles (throughput schedule, diag_next)
   // cgp_fit_predict_batch staging, grown on demand and kept: pinned host buffers (hipHostMalloc) so the
   // H2D / D2H copies are real asynchronous DMA, and a raw fp64 device buffer the pack kernels read
   void *pin_in = nullptr, *pin_out = nullptr, *draw = nullptr;
@@ -153,8 +154,8 @@ template <typename T> int set_lds_attrs(int device) {
   ok = ok && set(reinterpret_cast<const void *>(&k_tile_sk<T>), tile);
   ok = ok && set(reinterpret_cast<const void *>(&k_trmm_sk<T>), upd);
   ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T>), paneldiag_lds_bytes<T>());
-#ifdef CGP_AB
   ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true>), paneldiag_lds_bytes<T>());
+#ifdef CGP_AB
   ok = ok && set(reinterpret_cast<const void *>(&k_diag<T>), tile);
 #endif
   if (!ok) return -1;
@@ -191,6 +192,7 @@ template <typename T> FitArgs group_view(const FitArgs &a, int g0) {
   };
   v.Lw = const_cast<void *>(adv(a.Lw, (size_t)g0 * a.lw_stride));
   v.Winv = const_cast<void *>(adv(a.Winv, (size_t)g0 * a.winv_stride));
+  v.dpart = const_cast<void *>(adv(a.dpart, (size_t)g0 * 2 * DPART));
   v.X = adv(a.X, (size_t)g0 * a.d * a.N);
   v.Xs = adv(a.Xs, (size_t)g0 * a.d * a.M);
   v.y = adv(a.y, (size_t)g0 * a.N);
@@ -207,11 +209,11 @@ template <typename T> FitArgs group_view(const FitArgs &a, int g0) {
 
 // A/B switches of the schedule.  The shipped library has ONE schedule pair (throughput: k_diag_lean +
 // k_panel with running predictive sums; latency: k_tile_sk + k_trmm_sk for <= LAT_FITS fits); the
-// alternatives measured in DESIGN.md (two-stream overlap, fused next diagonal,
+// alternatives measured in DESIGN.md (one diagonal launch per step, two-stream overlap,
 // fat diagonal, finalize without accumulators, fused trmm) exist only in a -DCGP_AB build, where the
 // environment selects them once per process.
 struct SchedSwitches {
-  bool no_latency = false, fuse_next_diag = false, overlap = false, fat_diag = false, acc_off = false,
+  bool no_latency = false, split_diag = false, overlap = false, fat_diag = false, acc_off = false,
        sk_fused_trmm = false;
 };
 const SchedSwitches &sched_switches() {
@@ -223,8 +225,8 @@ const SchedSwitches &sched_switches() {
     const std::string sch = e ? e : "";
     w.no_latency = sch == "throughput";
 #ifdef CGP_AB
-    w.no_latency = w.no_latency || sch == "overlap" || sch == "fuseddiag";
-    w.fuse_next_diag = sch == "fuseddiag";
+    w.no_latency = w.no_latency || sch == "overlap" || sch == "splitdiag";
+    w.split_diag = sch == "splitdiag";
     w.overlap = sch == "overlap";
     const char *dg = getenv("CGP_DIAG");
     w.fat_diag = dg && std::string(dg) == "fat";
@@ -374,30 +376,31 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     HIP_TRY(c, hipGetLastError());
     return CGP_OK;
   }
+  // Fit launches: the diagonal tile k + 1 is finished inside the panel launch of step k and tile k + 2 is
+  // pre-updated there (k_panel<T, true>, diag_next), so only tile 0 has a launch of its own: NT + 1
+  // launches per fit schedule instead of 2 NT, and no launch in which one workgroup per fit factors a tile
+  // while the rest of the chip waits.  -DCGP_AB, CGP_SCHED=splitdiag: one k_diag_lean launch per step.
+  const bool split_diag = sw.split_diag || !in_rows;
   for (int k = 0; k < a.NT; ++k) {
     const int gx_t = (in_rows ? a.NT - k - 1 : 0) + a.ET;
     for (int g = 0; g < G; ++g) {
-#ifdef CGP_AB
-      // CGP_SCHED=fuseddiag: diagonal tile k+1 rides in the panel launch of step k (measured: +0.6 %
-      // fp64 N=2048, -5 % fp32 N=1024 -- DESIGN.md)
-      const bool fuse_next = sw.fuse_next_diag && in_rows && k + 1 < a.NT;
-      const bool own_diag = in_rows && (!sw.fuse_next_diag || k == 0);
-#else
-      const bool fuse_next = false;
-      const bool own_diag = in_rows;
-#endif
-      if (own_diag) {
+      if (in_rows && (split_diag || k == 0)) {
         L[g].begin(1, diag_flops(a.N, a.d, k, gb[g]));
         launch_diag<T>(ga[g], gb[g], k, sw.fat_diag, gs[g]);
         L[g].end();
       }
-      L[g].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, gb[g]) + (fuse_next ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0));
-#ifdef CGP_AB
-      if (fuse_next)
-        hipLaunchKernelGGL((k_panel<T, true>), dim3(gx_t, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ga[g], k);
-      else
-#endif
+      if (split_diag) {
+        L[g].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, gb[g]));
         hipLaunchKernelGGL((k_panel<T, false>), dim3(gx_t, gb[g]), dim3(256), panel_lds, gs[g], ga[g], k);
+        L[g].end();
+        continue;
+      }
+      const bool hasA = k + 1 < a.NT, hasB = k + 2 < a.NT && k >= 1;
+      FitArgs ak = ga[g];
+      ak.diag_slots = (hasA ? 1 : 0) | (hasB ? 2 : 0);
+      const int gx = gx_t + (hasB ? 1 : 0);  // gx_t already counts row tile k + 1 (kind A)
+      L[g].begin(0, panel_flops(a.N, a.M, a.d, k, true, gb[g]) + (hasA ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0));
+      hipLaunchKernelGGL((k_panel<T, true>), dim3(gx, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ak, k);
       L[g].end();
     }
   }
@@ -436,6 +439,7 @@ FitArgs base_args(cgp_ctx *c, int N, int d, int M, int kid, int include_noise) {
   a.alpha = c->dalpha;
   a.alpha_stride = c->alpha_stride;
   a.prep = c->dprep;
+  a.dpart = c->ddiagimg;
   a.dbgbuf = c->ddbg;
   a.N = N;
   a.d = d;
@@ -608,6 +612,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMemset(c->dticket, 0, sizeof(int) * LAT_FITS * c->sk_slots) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dwready, sizeof(int) * LAT_FITS) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dmacc, sizeof(double) * 2 * B * std::max(c->max_m, 1)) == hipSuccess;
+  ok = ok && hipMalloc(&c->ddiagimg, B * 2 * DPART * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->ddbg, DBG_SLOTS * sizeof(long long)) == hipSuccess;
   ok = ok && hipMemset(c->ddbg, 0, DBG_SLOTS * sizeof(long long)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dprep, B * PREP_N * sizeof(double)) == hipSuccess;
@@ -629,7 +634,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->la_buf, c->la_ibuf, c->dmacc};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {

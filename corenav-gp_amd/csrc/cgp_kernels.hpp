@@ -67,7 +67,9 @@ struct FitArgs {
   double *macc, *vacc;   // [batch][M] running sums V_m . z and |V_m|^2 over the block columns already
                          // final (fp64 throughput schedule: accumulated inside k_panel); null = k_finalize
                          // reads the whole of V
-  int tile_off;          // first block-tile index of this launch (split panel launches)
+  int tile_off;          // first block-tile index of this launch (split panel launches, A/B overlap schedule)
+  void *dpart;           // [batch][2][DPART] register images of pre-updated diagonal tiles (see diag_next)
+  int diag_slots;        // k_panel<T, true>: bit 0 = the launch finishes diagonal tile k+1, bit 1 = pre-updates tile k+2
   int xid;               // 1: the M (= N) "test rows" are the identity, so the extra block becomes (L^-1)^T (gradient mode)
   double *gpart;         // [batch][pairs][GRAD_N] per-tile-pair partial sums of k_grad
   long long *dbgbuf;     // 64 slots of s_memtime stamps / per-phase cycle sums (-DCGP_ABLATION builds)
@@ -167,28 +169,6 @@ __device__ __forceinline__ void tile_fit_of_block(int &t, int &b) {
     const int xcd = lin & 7, slot = lin >> 3;
     t = slot % T;
     b = (slot / T) * 8 + xcd;
-  }
-}
-
-// Same, for launches whose tile slot 0 is a long-running workgroup (k_panel with the next diagonal
-// tile fused in): the slot-0 workgroup of every fit gets the lowest linear ids, i.e. is dispatched
-// first, and the other slots follow in the XCD-steered order.
-__device__ __forceinline__ void tile_fit_of_block_first(int &t, int &b) {
-  const int T = gridDim.x, B = gridDim.y;
-  const int lin = blockIdx.y * T + blockIdx.x;
-  if (lin < B) {
-    t = 0;
-    b = lin;
-    return;
-  }
-  const int l2 = lin - B;
-  if ((B & 7) == 0) {
-    const int xcd = l2 & 7, slot = l2 >> 3;
-    t = 1 + slot % (T - 1);
-    b = (slot / (T - 1)) * 8 + xcd;
-  } else {
-    t = 1 + l2 % (T - 1);
-    b = l2 / (T - 1);
   }
 }
 

@@ -701,10 +701,39 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
   }
 }
 
-// Gram + update of the diagonal tile kn, then the packed factorisation, in <= 78 KB of LDS.
-// FUSED: called by the workgroup that has just stored tile (kn, kn - 1) inside the panel launch.
-// TRI (fp64): triangular update loop, see mfma_syrk_tri_loop.
-template <typename T, bool FUSED, bool TRI>
+// The diagonal tile kn in <= 78 KB of LDS: S(kn,kn) = G(kn,kn) - sum_{j<kn} L(kn,j) L(kn,j)^T, then the packed
+// factorisation (L(kn,kn), -W_kn written).  TRI (fp64): triangular update loop, see mfma_syrk_tri_loop.
+//
+// In the throughput schedule the tile never gets a launch of its own (after step 0): its update is cut at
+// block column kn - 2, and both pieces ride in panel launches whose other workgroups keep the CUs busy
+// ("diagonal tile inside the panel launches"):
+//   DIAG_PARTIAL  launch kn - 2, one extra workgroup per fit: acc = -G + sum_{j < kn-2} L L^T (every operand
+//                 is final since launch kn - 3), dumped as a raw register image to p.dpart[kn & 1];
+//   DIAG_FINISH   launch kn - 1, by the workgroup that has just stored tile (kn, kn-1): reloads the image
+//                 (kn <= 2: starts from the Gram tile instead), adds block columns kn-2 and kn-1, factors.
+// so every dependency of the diagonal tile crosses a launch boundary except the workgroup's own tile,
+// which it fences.  DIAG_FULL is the whole thing in one go (k_diag_lean: step 0, A/B schedules).
+enum { DIAG_FULL = 0, DIAG_PARTIAL = 1, DIAG_FINISH = 2 };
+constexpr int DPART = 2 * NCB * 4 * 256;  // elements of one register image: 64 accumulator values x 256 threads
+
+template <typename T, bool TRI, bool STORE>
+__device__ __forceinline__ void acc_image(typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ img, int tid) {
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (TRI && cb > (j ? NCB - 1 - wave : wave)) continue;  // wave-uniform: block not part of the triangle
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T *q = img + ((cb * 2 + j) * 4 + r) * 256 + tid;
+        if constexpr (STORE) *q = acc[cb][j][r];
+        else acc[cb][j][r] = *q;
+      }
+    }
+}
+
+template <typename T, int MODE, bool TRI>
 __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
                                           T *__restrict__ Lw, int b, int kn, int tid) {
   using P = Prec<T>;
@@ -714,25 +743,40 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15;
   constexpr int CH2 = 2 * KT * LDST;
-  if constexpr (FUSED) {
-    // tile (kn, kn-1), written by this workgroup a moment ago, is the last chunk of the row panel
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if constexpr (MODE == DIAG_FINISH) {
+    // Tile (kn, kn-1), written by THIS workgroup a moment ago, is the last block column of the row panel.
+    // Workgroup scope is enough and is all that is wanted: the waves of a workgroup share their CU's
+    // write-through L1, nobody else reads that tile in this launch and this CU never held its lines
+    // before, so "every wave's stores have left the CU" (vmcnt(0)) + a barrier orders them before the
+    // loads below.  An agent-scope pair here would write back the whole XCD L2 and drop the CU's L1 once
+    // per fit in every launch -- measured: it costs more than the diagonal launches it replaces.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
-  const T *gR = Lw + (size_t)kn * TS;
-  const int nchunk = (kn * TS) / KT;
+  // block columns [c_first, c_last) of the row panel are applied here
+  const bool from_image = MODE == DIAG_FINISH && kn >= 3;
+  const int c_first = from_image ? (kn - 2) * (TS / KT) : 0;
+  const int c_last = (MODE == DIAG_PARTIAL ? kn - 2 : kn) * (TS / KT);
+  const int nchunk = c_last - c_first;
+  const T *gR = Lw + (size_t)kn * TS + (size_t)c_first * KT * ld;
+  T *img = reinterpret_cast<T *>(p.dpart) + ((size_t)b * 2 + (kn & 1)) * DPART;
   {
     GramPre<T> gp;
-    gram_prefetch<T>(p, b, kn, kn, tid, gp);
+    if (!from_image) gram_prefetch<T>(p, b, kn, kn, tid, gp);
     if constexpr (TRI) {
       if (nchunk > 0) stage_chunk_tri<T>(gR, (size_t)ld, 0, smem + tri_buf(0), tid);
       if (nchunk > 1) stage_chunk_tri<T>(gR, (size_t)ld, 1, smem + tri_buf(1), tid);
     } else if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gR, (size_t)ld, smem, tid);
-    gram_apply<T, TRI>(p, acc, smem + CH2, b, kn, kn, tid, gp);
+    if (from_image) acc_image<T, TRI, false>(acc, img, tid);
+    else gram_apply<T, TRI>(p, acc, smem + CH2, b, kn, kn, tid, gp);
   }
   if constexpr (TRI) mfma_syrk_tri_loop<T>(acc, gR, (size_t)ld, nchunk, smem, tid);
   else mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gR, (size_t)ld, nchunk, smem, tid);
+  if constexpr (MODE == DIAG_PARTIAL) {
+    acc_image<T, TRI, true>(acc, img, tid);
+    return;
+  }
   __syncthreads();
   T *tile = Lw + (size_t)(kn * TS) * ld + (size_t)kn * TS;
   // S = -acc -> the 36 lower blocks
@@ -786,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void k_diag_lean(FitArgs p, int k) {
   const int b = blockIdx.x;
   T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
   typename Prec<T>::acc_t acc[NCB][2];
-  diag_next<T, false, sizeof(T) == 8>(p, acc, smem, Lw, b, k, threadIdx.x);
+  diag_next<T, DIAG_FULL, sizeof(T) == 8>(p, acc, smem, Lw, b, k, threadIdx.x);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -881,19 +925,54 @@ __device__ __forceinline__ void load_tile(typename Prec<T>::acc_t (&acc)[NCB][2]
 // keeps the register-staged loop.
 constexpr bool RDIRECT = true;
 
+// DIAGNEXT (throughput schedule, fit launches): besides the row tiles below the diagonal and the extra
+// tiles the launch carries, per fit, the workgroup that finishes the next diagonal tile (kind A: row tile
+// k + 1, then DIAG_FINISH of tile k + 1) and the one that pre-updates the one after (kind B: DIAG_PARTIAL of
+// tile k + 2); both kinds get the lowest linear block ids, i.e. are dispatched first, so their longer
+// chains end inside the launch.  grid.x = A + B + other tiles; p.diag_slots = {has A, has B}.
 template <typename T, bool DIAGNEXT = false>
-__global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p, int k) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
-  int bt, b;
-  if constexpr (DIAGNEXT) tile_fit_of_block_first(bt, b);  // the long-running (k+1, k) workgroups start first
-  else tile_fit_of_block(bt, b);
-  const int rt = row_tile_of(bt + p.tile_off, k + 1, p.NT, p.rows_from_extra);
+  const int tid = threadIdx.x;
+  int bt, b, rt;
+  bool finish_next = false;
+  acc_t acc[NCB][2];
+  if constexpr (DIAGNEXT) {
+    const int Tg = gridDim.x, B = gridDim.y;
+    const int lin = blockIdx.y * Tg + blockIdx.x;
+    const int nA = (p.diag_slots & 1) ? B : 0, nB = (p.diag_slots & 2) ? B : 0;
+    if (lin < nA) {
+      b = lin;
+      rt = k + 1;
+      finish_next = true;
+    } else if (lin < nA + nB) {
+      b = lin - nA;
+      T *LwB = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+      diag_next<T, DIAG_PARTIAL, sizeof(T) == 8>(p, acc, smem, LwB, b, k + 2, tid);
+      return;
+    } else {
+      const int l2 = lin - nA - nB, To = Tg - (nA ? 1 : 0) - (nB ? 1 : 0);  // the other tiles, XCD-steered
+      if ((B & 7) == 0) {
+        const int xcd = l2 & 7, slot = l2 >> 3;
+        bt = slot % To;
+        b = (slot / To) * 8 + xcd;
+      } else {
+        bt = l2 % To;
+        b = l2 / To;
+      }
+      const int first = k + 1 + (nA ? 1 : 0);  // first in-matrix row tile among the others
+      const int nin = p.NT - first > 0 ? p.NT - first : 0;
+      rt = bt < nin ? first + bt : p.NT + (bt - nin);
+    }
+  } else {
+    tile_fit_of_block(bt, b);
+    rt = row_tile_of(bt + p.tile_off, k + 1, p.NT, p.rows_from_extra);
+  }
   T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
   const int ld = p.ld;
-  const int tid = threadIdx.x;
   PhaseClock pc;
   pc.start(p, tid);
   const int ps = 64 + 8 * (k & 31);  // debug slots of this step
@@ -901,7 +980,6 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
   // Gram first: acc = -G(rt, k) while nothing else is live in the register file, with chunk 0 of the
   // panels already in flight into LDS buffer 0 (the Gram inputs are staged in buffer 1's space).
   constexpr int CH2 = 2 * KT * LDST;
-  acc_t acc[NCB][2];
   const T *gR = Lw + (size_t)rt * TS, *gC = Lw + (size_t)k * TS;
   const int nchunk = (k * TS) / KT;
   // running predictive sums (extra tiles, throughput schedule): z of the newest block column
@@ -959,11 +1037,9 @@ __global__ __launch_bounds__(256, 2) void k_panel(FitArgs p, int k) {
   store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
   pc.lap(p, ps + 5);
   pc.count(p, ps + 7);
-#ifdef CGP_AB
   if constexpr (DIAGNEXT) {
-    if (rt == k + 1) diag_next<T, true, false>(p, acc, smem, Lw, b, k + 1, tid);
+    if (finish_next) diag_next<T, DIAG_FINISH, sizeof(T) == 8>(p, acc, smem, Lw, b, k + 1, tid);
   }
-#endif
 }
 
 #ifdef CGP_AB
