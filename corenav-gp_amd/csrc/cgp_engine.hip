@@ -398,6 +398,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       const bool hasA = k + 1 < a.NT, hasB = k + 2 < a.NT && k >= 1;
       FitArgs ak = ga[g];
       ak.diag_slots = (hasA ? 1 : 0) | (hasB ? 2 : 0);
+      ak.diag_stride = sizeof(T) == 8 ? 2 : 4;  // workgroups per CU of k_panel<T, true> (LDS / VGPR bound)
       const int gx = gx_t + (hasB ? 1 : 0);  // gx_t already counts row tile k + 1 (kind A)
       L[g].begin(0, panel_flops(a.N, a.M, a.d, k, true, gb[g]) + (hasA ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0));
       hipLaunchKernelGGL((k_panel<T, true>), dim3(gx, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ak, k);

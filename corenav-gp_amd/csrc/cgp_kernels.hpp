@@ -70,6 +70,7 @@ struct FitArgs {
   int tile_off;          // first block-tile index of this launch (split panel launches, A/B overlap schedule)
   void *dpart;           // [batch][2][DPART] register images of pre-updated diagonal tiles (see diag_next)
   int diag_slots;        // k_panel<T, true>: bit 0 = the launch finishes diagonal tile k+1, bit 1 = pre-updates tile k+2
+  int diag_stride;       // k_panel<T, true>: workgroups per CU (one block of 256 ids in `stride` holds the finishers)
   int xid;               // 1: the M (= N) "test rows" are the identity, so the extra block becomes (L^-1)^T (gradient mode)
   double *gpart;         // [batch][pairs][GRAD_N] per-tile-pair partial sums of k_grad
   long long *dbgbuf;     // 64 slots of s_memtime stamps / per-phase cycle sums (-DCGP_ABLATION builds)

@@ -944,17 +944,30 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
     const int Tg = gridDim.x, B = gridDim.y;
     const int lin = blockIdx.y * Tg + blockIdx.x;
     const int nA = (p.diag_slots & 1) ? B : 0, nB = (p.diag_slots & 2) ? B : 0;
-    if (lin < nA) {
-      b = lin;
+    // Dispatch follows the linear block id and an XCD hands consecutive workgroups to different CUs, so ids
+    // are dealt in blocks of 256 (8 XCDs x 32 CUs): every `stride`-th block (stride = workgroups per CU)
+    // is a block of kind-A workgroups and the blocks between hold the other tiles.  A CU then hosts one
+    // latency-bound diagonal factorisation next to MFMA-bound tiles instead of several at once.  Speed only.
+    int ia = -1, io = lin;  // index among the A kinds / among everything else
+    const int stride = p.diag_stride, ablk = nA >> 8, oblk = (Tg * B - nA) >> 8;
+    if (nA > 0 && (B & 255) == 0 && stride > 0 && (ablk - 1) * stride < ablk + oblk) {
+      const int j = lin >> 8, r = lin & 255;
+      const int before = min((j + stride - 1) / stride, ablk);  // A blocks at positions < j
+      if (j % stride == 0 && j / stride < ablk) ia = (j / stride) * 256 + r;
+      else io = (j - before) * 256 + r;
+    } else if (lin < nA) ia = lin;
+    else io = lin - nA;
+    if (ia >= 0) {
+      b = ia;
       rt = k + 1;
       finish_next = true;
-    } else if (lin < nA + nB) {
-      b = lin - nA;
+    } else if (io < nB) {
+      b = io;
       T *LwB = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
       diag_next<T, DIAG_PARTIAL, sizeof(T) == 8>(p, acc, smem, LwB, b, k + 2, tid);
       return;
     } else {
-      const int l2 = lin - nA - nB, To = Tg - (nA ? 1 : 0) - (nB ? 1 : 0);  // the other tiles, XCD-steered
+      const int l2 = io - nB, To = Tg - (nA ? 1 : 0) - (nB ? 1 : 0);  // the other tiles, XCD-steered
       if ((B & 7) == 0) {
         const int xcd = l2 & 7, slot = l2 >> 3;
         bt = slot % To;

@@ -122,3 +122,31 @@ def test_lbfgs_selftest_rosenbrock(n):
     assert f.value < 1e-10
     ref = so.minimize(so.rosen, np.where(np.arange(n) % 2, 1.0, -1.2), jac=so.rosen_der, method="L-BFGS-B")
     assert nev < 4 * ref.nfev + 50      # same order of work as the reference optimiser
+
+
+def test_gppredictor_header_offers_the_reference_signature():
+    """inside a catkin workspace (<ros/ros.h>, <Eigen/Dense> found) csrc/gp_predictor.h is the
+    reference's class -- GpPredictor(ros::NodeHandle &), typedef Eigen::MatrixXd Matrix, the private
+    gp_sub_ / stop_cmd_pub_ / clt_setStopping_ / nh_ (gp_predictor.h:22,25,57-60) -- and the node's main is
+    the reference's main.  That configuration cannot be compiled in this image (no roscpp, no Eigen); this
+    checks the surface is spelled out and that the ROS-free configuration, which the library ships, builds."""
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "corenav-gp_amd", "csrc")
+    h = open(os.path.join(csrc, "gp_predictor.h")).read()
+    for needle in ("typedef ros::NodeHandle NodeHandle;", "GpPredictor(corenav_types::NodeHandle &);",
+                   "typedef Eigen::MatrixXd Matrix;", "ros::Subscriber gp_sub_;", "ros::Publisher stop_cmd_pub_;",
+                   "ros::ServiceClient clt_setStopping_;", "corenav_types::NodeHandle &nh_;",
+                   "typedef Eigen::Matrix<double, 3, 1> Vector3;", "int main(int argc, char **argv);"):
+        assert needle in h, needle
+    cpp = open(os.path.join(csrc, "gp_predictor.cpp")).read()
+    for needle in ('nh.subscribe("/core_nav/core_nav/gp_result", 1, &GpPredictor::GPCallBack, this)',
+                   'serviceClient<core_nav::SetStopping>("/core_nav/core_nav/stopping_service")',
+                   'advertise<std_msgs::Float64>("/core_nav/core_nav/stop_cmd", 1)'):
+        assert needle in cpp, needle
+    node = open(os.path.join(ROOT, "corenav-gp_amd", "ros", "gp_predictor_node.cpp")).read()
+    body = re.sub(r"\s+", " ", node[node.index("int main"):])
+    assert 'ros::init(argc, argv, "gp_predictor"); ros::NodeHandle nh(""); GpPredictor gp_predictor(nh); ros::spin();' in body
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-DCORENAV_NO_ROS", "-DCORENAV_NO_EIGEN",
+                        os.path.join(csrc, "gp_predictor.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
