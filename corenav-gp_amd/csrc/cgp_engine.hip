@@ -27,6 +27,12 @@ static_assert(CGP_MAX_THETA == MAX_THETA, "header / kernel MAX_THETA mismatch");
 
 namespace {
 
+#ifdef CGP_AB
+constexpr bool kAbBuild = true;
+#else
+constexpr bool kAbBuild = false;
+#endif
+
 struct ProfRec {
   int kernel;
   hipEvent_t a, b;
@@ -154,7 +160,7 @@ template <typename T> int set_lds_attrs(int device) {
   ok = ok && set(reinterpret_cast<const void *>(&k_tile_sk<T>), tile);
   ok = ok && set(reinterpret_cast<const void *>(&k_trmm_sk<T>), upd);
   ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T>), paneldiag_lds_bytes<T>());
-  ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true>), paneldiag_lds_bytes<T>());
+  if constexpr (sizeof(T) == 4 || kAbBuild) ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true>), paneldiag_lds_bytes<T>());
 #ifdef CGP_AB
   ok = ok && set(reinterpret_cast<const void *>(&k_diag<T>), tile);
 #endif
@@ -213,7 +219,7 @@ template <typename T> FitArgs group_view(const FitArgs &a, int g0) {
 // fat diagonal, finalize without accumulators, fused trmm) exist only in a -DCGP_AB build, where the
 // environment selects them once per process.
 struct SchedSwitches {
-  bool no_latency = false, split_diag = false, overlap = false, fat_diag = false, acc_off = false,
+  bool no_latency = false, split_diag = false, fused_diag = false, overlap = false, fat_diag = false, acc_off = false,
        sk_fused_trmm = false;
 };
 const SchedSwitches &sched_switches() {
@@ -227,6 +233,8 @@ const SchedSwitches &sched_switches() {
 #ifdef CGP_AB
     w.no_latency = w.no_latency || sch == "overlap" || sch == "splitdiag";
     w.split_diag = sch == "splitdiag";
+    w.fused_diag = sch == "fuseddiag";
+    w.no_latency = w.no_latency || w.fused_diag;
     w.overlap = sch == "overlap";
     const char *dg = getenv("CGP_DIAG");
     w.fat_diag = dg && std::string(dg) == "fat";
@@ -380,7 +388,12 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // pre-updated there (k_panel<T, true>, diag_next), so only tile 0 has a launch of its own: NT + 1
   // launches per fit schedule instead of 2 NT, and no launch in which one workgroup per fit factors a tile
   // while the rest of the chip waits.  -DCGP_AB, CGP_SCHED=splitdiag: one k_diag_lean launch per step.
-  const bool split_diag = sw.split_diag || !in_rows;
+  // Measured (same box, alternating libraries): fp32 N = 1024 +2.6 % fits/s, fp64 N = 2048 -0.7 % -- in fp64
+  // the diagonal launches are already MFMA-bound in their syrk part and two workgroups per CU leave the
+  // finisher's factorisation chain nothing to hide behind -- so fp64 keeps one k_diag_lean launch per step
+  // (CGP_SCHED=fuseddiag in a -DCGP_AB build selects the fused form there too).
+  constexpr bool kFusedBuilt = sizeof(T) == 4 || kAbBuild;
+  const bool split_diag = sw.split_diag || !in_rows || !kFusedBuilt || (sizeof(T) == 8 && !sw.fused_diag);
   for (int k = 0; k < a.NT; ++k) {
     const int gx_t = (in_rows ? a.NT - k - 1 : 0) + a.ET;
     for (int g = 0; g < G; ++g) {
@@ -401,7 +414,8 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       ak.diag_stride = sizeof(T) == 8 ? 2 : 4;  // workgroups per CU of k_panel<T, true> (LDS / VGPR bound)
       const int gx = gx_t + (hasB ? 1 : 0);  // gx_t already counts row tile k + 1 (kind A)
       L[g].begin(0, panel_flops(a.N, a.M, a.d, k, true, gb[g]) + (hasA ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0));
-      hipLaunchKernelGGL((k_panel<T, true>), dim3(gx, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ak, k);
+      if constexpr (kFusedBuilt)
+        hipLaunchKernelGGL((k_panel<T, true>), dim3(gx, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ak, k);
       L[g].end();
     }
   }

@@ -295,16 +295,22 @@ __device__ __forceinline__ constexpr int tri_buf(int i) { return i * KT * LDST; 
 
 template <typename T>
 __device__ __forceinline__ void stage_chunk_tri(const T *gR, size_t ldR, int chunk, T *buf, int tid) {
-  static_assert(sizeof(T) == 8, "LDS-DMA staging: fp64 only");
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void gbl_void;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if constexpr (sizeof(T) == 8) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-  for (int i = 0; i < KT / 4; ++i) {
-    const int col = wave * (KT / 4) + i;
-    __builtin_amdgcn_global_load_lds((gbl_void *)(gR + (size_t)(chunk * KT + col) * ldR + lane * 2),
-                                     (lds_void *)(buf + col * LDST), 16, 0, 0);
+    for (int i = 0; i < KT / 4; ++i) {
+      const int col = wave * (KT / 4) + i;
+      __builtin_amdgcn_global_load_lds((gbl_void *)(gR + (size_t)(chunk * KT + col) * ldR + lane * 2),
+                                       (lds_void *)(buf + col * LDST), 16, 0, 0);
+    }
+  } else {
+    // fp32: a 512-byte column does not fill a 1 KiB LDS-DMA wave-instruction; 32 bytes per thread through registers
+    using vec8 = T __attribute__((ext_vector_type(8)));
+    const int sc = tid >> 4, sr = (tid & 15) * 8;
+    *reinterpret_cast<vec8 *>(buf + sc * LDST + sr) = *reinterpret_cast<const vec8 *>(gR + sr + (size_t)(chunk * KT + sc) * ldR);
   }
 }
 
@@ -332,14 +338,30 @@ __device__ __forceinline__ void syrk_tri_wave(typename Prec<T>::acc_t (&acc)[NCB
     }
   };
 
-  // prefetch distance TRI_PD over a ring of TRI_PD + 1: one workgroup per CU, so nothing else hides the HBM latency
-  static_assert(sizeof(T) == 8, "LDS-DMA staging: fp64 only");
-  for (int c = 0; c < nchunk; ++c) {
-    // chunk c has landed when at most the 4 loads of chunk c + 1 are still in flight
-    if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (c + TRI_PD < nchunk) stage_chunk_tri<T>(gR, ldR, c + TRI_PD, smem + tri_buf((c + TRI_PD) % (TRI_PD + 1)), tid);
-    compute(smem + tri_buf(c % (TRI_PD + 1)));
+  if constexpr (sizeof(T) == 8) {
+    // prefetch distance TRI_PD over a ring of TRI_PD + 1 (LDS-DMA): with one or two workgroups per CU nothing
+    // else hides the HBM latency
+    for (int c = 0; c < nchunk; ++c) {
+      // chunk c has landed when at most the 4 loads of chunk c + 1 are still in flight
+      if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (c + TRI_PD < nchunk) stage_chunk_tri<T>(gR, ldR, c + TRI_PD, smem + tri_buf((c + TRI_PD) % (TRI_PD + 1)), tid);
+      compute(smem + tri_buf(c % (TRI_PD + 1)));
+    }
+  } else {
+    // fp32: register-staged, two buffers, one chunk ahead (chunk 0 was written by the prologue); four
+    // workgroups per CU cover the latency
+    using vec8 = T __attribute__((ext_vector_type(8)));
+    const int sc = tid >> 4, sr = (tid & 15) * 8;
+    const T *src = gR + sr + (size_t)sc * ldR;
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+      vec8 pr;
+      if (c + 1 < nchunk) pr = *reinterpret_cast<const vec8 *>(src + (size_t)((c + 1) * KT) * ldR);
+      compute(smem + tri_buf(c & 1));
+      if (c + 1 < nchunk) *reinterpret_cast<vec8 *>(smem + tri_buf((c + 1) & 1) + sc * LDST + sr) = pr;
+      __syncthreads();
+    }
   }
 }
 
@@ -714,6 +736,7 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
 // so every dependency of the diagonal tile crosses a launch boundary except the workgroup's own tile,
 // which it fences.  DIAG_FULL is the whole thing in one go (k_diag_lean: step 0, A/B schedules).
 enum { DIAG_FULL = 0, DIAG_PARTIAL = 1, DIAG_FINISH = 2 };
+constexpr bool kTriDiag = true;  // diagonal tile: only its lower 16x16 blocks are updated (9 of 16 MFMA tiles per k-step)
 constexpr int DPART = 2 * NCB * 4 * 256;  // elements of one register image: 64 accumulator values x 256 threads
 
 template <typename T, bool TRI, bool STORE>
@@ -766,7 +789,7 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
     if (!from_image) gram_prefetch<T>(p, b, kn, kn, tid, gp);
     if constexpr (TRI) {
       if (nchunk > 0) stage_chunk_tri<T>(gR, (size_t)ld, 0, smem + tri_buf(0), tid);
-      if (nchunk > 1) stage_chunk_tri<T>(gR, (size_t)ld, 1, smem + tri_buf(1), tid);
+      if (sizeof(T) == 8 && nchunk > 1) stage_chunk_tri<T>(gR, (size_t)ld, 1, smem + tri_buf(1), tid);  // fp64: DMA ring, 2 ahead
     } else if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gR, (size_t)ld, smem, tid);
     if (from_image) acc_image<T, TRI, false>(acc, img, tid);
     else gram_apply<T, TRI>(p, acc, smem + CH2, b, kn, kn, tid, gp);
@@ -830,7 +853,7 @@ __global__ __launch_bounds__(256, 2) void k_diag_lean(FitArgs p, int k) {
   const int b = blockIdx.x;
   T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
   typename Prec<T>::acc_t acc[NCB][2];
-  diag_next<T, DIAG_FULL, sizeof(T) == 8>(p, acc, smem, Lw, b, k, threadIdx.x);
+  diag_next<T, DIAG_FULL, kTriDiag>(p, acc, smem, Lw, b, k, threadIdx.x);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -964,7 +987,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
     } else if (io < nB) {
       b = io;
       T *LwB = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
-      diag_next<T, DIAG_PARTIAL, sizeof(T) == 8>(p, acc, smem, LwB, b, k + 2, tid);
+      diag_next<T, DIAG_PARTIAL, kTriDiag>(p, acc, smem, LwB, b, k + 2, tid);
       return;
     } else {
       const int l2 = io - nB, To = Tg - (nA ? 1 : 0) - (nB ? 1 : 0);  // the other tiles, XCD-steered
@@ -1051,7 +1074,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
   pc.lap(p, ps + 5);
   pc.count(p, ps + 7);
   if constexpr (DIAGNEXT) {
-    if (finish_next) diag_next<T, DIAG_FINISH, sizeof(T) == 8>(p, acc, smem, Lw, b, k + 1, tid);
+    if (finish_next) diag_next<T, DIAG_FINISH, kTriDiag>(p, acc, smem, Lw, b, k + 1, tid);
   }
 }
 

@@ -324,7 +324,7 @@ def test_latency_schedule_is_deterministic(engine):
         assert np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3])
 
 
-@pytest.mark.parametrize("env", [{"CGP_SCHED": "overlap"}, {"CGP_SCHED": "splitdiag"},
+@pytest.mark.parametrize("env", [{"CGP_SCHED": "overlap"}, {"CGP_SCHED": "splitdiag"}, {"CGP_SCHED": "fuseddiag"},
                                  {"CGP_SCHED": "throughput"}, {"CGP_SCHED": "throughput", "CGP_DIAG": "fat"},
                                  {"CGP_SK_TRMM": "fused"}, {"CGP_SCHED": "throughput", "CGP_ACC": "off"}],
                          ids=lambda e: "-".join(e.values()))
