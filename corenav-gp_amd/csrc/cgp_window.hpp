@@ -31,6 +31,10 @@ static_assert(WPB == 16, "phase A broadcasts with DPP row_newbcast: one 16-lane 
 #define WIN_OCC 2
 #endif
 
+#ifndef WIN_BPREFETCH
+#define WIN_BPREFETCH 0  // sweep waves: next trip's row in flight during the current one (+32 VGPRs: measured)
+#endif
+
 struct WindowArgs {
   double *L;        // [nwin][CAP*CAP] column-major
   double *z;        // [nwin][CAP]
@@ -111,6 +115,10 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
     }
     double vz = drop ? z[o] : 0.0;  // the dropped sample's component of z (uniform)
     double sl2 = 0, slz = 0, slog = 0, szz = 0;
+    // sum of log(diag) without a log on the serial path: every lane of wave 0's first row keeps the running
+    // product of its diagonal entries as (mantissa in [0.5, 1), exponent); ONE log per lane and tick at the end
+    double pmant = 1.0;
+    int pexp = 0;
     __syncthreads();
 
     // Panel pipeline.  Per 16-column panel the work is  A(p): wave 0 rotates and solves the 16x16
@@ -122,23 +130,35 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
     const int i = lane & (WPB - 1);
     const int npan = (n2 + WPB - 1) / WPB;
     double vi = 0, ki = 0, zi = 0;  // wave 0: the diagonal block's rows of v, k, z (registers across panels)
+    // Addressing of the factor: a buffer descriptor on the window's slab + one 32-bit byte offset per lane
+    // + one scalar offset per column, instead of 64-bit pointer arithmetic per entry (the sweep is bound by
+    // instruction issue, not by HBM: DESIGN.md section 9).
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(L, 0, (int)((size_t)CAP * CAP * sizeof(double)), 0x00020000);
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    auto ld64 = [&](unsigned off, int soff) {
+      const u2 q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, soff, 0);
+      return __hiloint2double((int)q[1], (int)q[0]);
+    };
+    auto st64 = [&](double x, unsigned off, int soff) {
+      u2 q;
+      q[0] = (unsigned)__double2loint(x);
+      q[1] = (unsigned)__double2hiint(x);
+      __builtin_amdgcn_raw_buffer_store_b64(q, rsrc, off, soff, 0);
+    };
+    const int colb = CAP * (int)sizeof(double);  // bytes between columns
     // the 16x16 diagonal block of panel p0 (lane = row), identity-padded; issued early by the caller
     auto load_diag = [&](int p0, int nb, double (&a)[WPB]) {
-      const double *src = L + (size_t)(o2 + p0) * CAP + o2 + p0 + i;
+      const unsigned off = (unsigned)(((o2 + p0) * CAP + o2 + p0 + i) * (int)sizeof(double));
 #pragma unroll
-      for (int j = 0; j < WPB; ++j) {
-        a[j] = (j <= i && i < nb && j < nb) ? *src : (i == j ? 1.0 : 0.0);
-        src += CAP;
-        asm volatile("" : "+v"(src));
-      }
+      for (int j = 0; j < WPB; ++j) a[j] = (j <= i && i < nb && j < nb) ? ld64(off, j * colb) : (i == j ? 1.0 : 0.0);
       zi = i < nb ? z[o2 + p0 + i] : 0.0;
     };
     auto phase_a = [&](int p0, int nb, double *csb, double (&a)[WPB]) {
-      double *Lp = L + (size_t)(o2 + p0) * CAP + o2;
       // Givens rotation (c, s) = (l_jj, v_j) / sqrt(l_jj^2 + v_j^2) that folds v_j into the diagonal:
       // one hardware-seeded rsqrt with a third-order step; this chain is the serial critical path
       // of the tick.  Broadcasts of lane j's values are 64-bit DPP row_newbcast moves (the four
       // 16-lane rows hold identical copies).
+      double idg = 1.0;  // 1 / (new diagonal entry of this lane's row): the rotation's own rsqrt, no division
       static_for<0, WPB>([&](auto jc) {
         constexpr int J = decltype(jc)::value;
         if (J < nb) {
@@ -152,7 +172,10 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
           if (i > J) {
             a[J] = tv;
             vi = nv;
-          } else if (i == J) a[J] = r2 * ri;
+          } else if (i == J) {
+            a[J] = r2 * ri;  // sqrt(l_jj^2 + v_j^2)
+            idg = ri;
+          }
           const double zn = __builtin_fma(sn, vz, c * zj);
           vz = __builtin_fma(c, vz, -(sn * zj));
           if (i == J) zi = zn;
@@ -164,15 +187,15 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       });
-      // diagonal of the finished block: logs and reciprocals once per lane, in parallel
-      double dg = 1.0;
+      // diagonal of the finished block into the running product (off the critical path: nothing below reads it)
+      if (lane < nb) {
+        double dg = 1.0;
 #pragma unroll
-      for (int j = 0; j < WPB; ++j) dg = (i == j) ? a[j] : dg;
-      double lg = (lane < nb) ? log(dg) : 0.0;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
-      slog += lg;
-      const double idg = 1.0 / dg;
+        for (int j = 0; j < WPB; ++j) dg = (i == j) ? a[j] : dg;
+        pmant *= dg;
+        pexp += __builtin_amdgcn_frexp_exp(pmant);
+        pmant = __builtin_amdgcn_frexp_mant(pmant);
+      }
       // forward substitution inside the block for the incoming point
       static_for<0, WPB>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
@@ -186,13 +209,10 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
         }
       });
       if (lane < nb) {
-        double *dst = Lp + p0 + i;
+        const unsigned off = (unsigned)(((o2 + p0) * CAP + o2 + p0 + i) * (int)sizeof(double));
 #pragma unroll
-        for (int j = 0; j < WPB; ++j) {
-          if (j <= i && j < nb) *dst = a[j];
-          dst += CAP;
-          asm volatile("" : "+v"(dst));
-        }
+        for (int j = 0; j < WPB; ++j)
+          if (j <= i && j < nb) st64(a[j], off, j * colb);
         z[o2 + p0 + i] = zi;
       }
     };
@@ -219,7 +239,6 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
     for (int pi = 0; pi < npan; ++pi) {
       __syncthreads();  // A(pi) and B(pi-1) are complete
       const int p0 = pi * WPB;
-      double *Lp = L + (size_t)(o2 + p0) * CAP + o2;  // column p0 of the window, row 0 of the window
       const double *csb = cs + (pi & 1) * 2 * WPB;
       if (wave == 0) {
         if (pi + 1 < npan) {
@@ -229,26 +248,15 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
           double ad[WPB];
           load_diag(p0 + WPB, nb1, ad);  // in flight while the 16 rows below take B(pi)
           double a[WPB];
-          {
-            const double *src = Lp + r;
+          const unsigned offr = (unsigned)(((o2 + p0) * CAP + o2 + r) * (int)sizeof(double));
 #pragma unroll
-            for (int j = 0; j < WPB; ++j) {
-              a[j] = i < nb1 ? *src : 0.0;
-              src += CAP;
-              asm volatile("" : "+v"(src));
-            }
-          }
+          for (int j = 0; j < WPB; ++j) a[j] = i < nb1 ? ld64(offr, j * colb) : 0.0;
           vi = i < nb1 ? vv[r] : 0.0;
           ki = i < nb1 ? kk[r] : 0.0;
           sweep_row(a, vi, ki, csb, p0);
           if (lane < nb1) {
-            double *dst = Lp + r;
 #pragma unroll
-            for (int j = 0; j < WPB; ++j) {
-              *dst = a[j];
-              dst += CAP;
-              asm volatile("" : "+v"(dst));
-            }
+            for (int j = 0; j < WPB; ++j) st64(a[j], offr, j * colb);
           }
           phase_a(p0 + WPB, nb1, cs + ((pi + 1) & 1) * 2 * WPB, ad);
         }
@@ -256,27 +264,14 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
         // ---- B(pi): rows below the next diagonal block, three waves
         for (int r = p0 + 2 * WPB + (tid - 64); r < n2; r += 192) {
           asm volatile("" ::: "memory");  // keep the panel's LDS scalars from being hoisted across rows
+          const unsigned offr = (unsigned)(((o2 + p0) * CAP + o2 + r) * (int)sizeof(double));
           double a[WPB];
-          {
-            const double *src = Lp + r;
 #pragma unroll
-            for (int j = 0; j < WPB; ++j) {
-              a[j] = *src;
-              src += CAP;
-              asm volatile("" : "+v"(src));
-            }
-          }
+          for (int j = 0; j < WPB; ++j) a[j] = ld64(offr, j * colb);
           double v = vv[r], k = kk[r];
           sweep_row(a, v, k, csb, p0);
-          {
-            double *dst = Lp + r;
 #pragma unroll
-            for (int j = 0; j < WPB; ++j) {
-              *dst = a[j];
-              dst += CAP;
-              asm volatile("" : "+v"(dst));
-            }
-          }
+          for (int j = 0; j < WPB; ++j) st64(a[j], offr, j * colb);
           vv[r] = v;
           kk[r] = k;
         }
@@ -285,6 +280,12 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
     __syncthreads();
 
     // ---- append the new sample as the last row of the factor
+    if (wave == 0) {
+      double lg = log(pmant) + (double)pexp * 0.6931471805599453;  // lanes that never multiplied: log(1) + 0
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
+      slog = lg;
+    }
     if (tid == 0) {
       red[0] = sl2; red[1] = slz; red[2] = slog; red[3] = szz;
     }

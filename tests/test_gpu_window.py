@@ -63,6 +63,29 @@ def test_config4_window512_checkpoints(engine):
         assert abs(pm[t] - mu[0]) <= TOL * max(abs(mu[0]), 1e-3) and abs(pv[t] - var[0]) <= TOL * var[0]
 
 
+def test_config4_as_written_10000_ticks(engine):
+    """BASELINE configs[3] as written: N = 512 ring, 10 000 ticks streamed (one append + one drop per tick, fed
+    in blocks of 2 500 so the state also crosses launches), checked against a from-scratch refit of the
+    current window at checkpoints up to the last tick: ~9 500 chained rank-1 up/downdates and ~19 ring
+    compactions keep the 1e-6 bar."""
+    N, d, T = 512, 3, 10000
+    X, y = stream(T, d, 11)
+    theta = np.array([0.02, 1.0, 1.4, 0.9, 1e-3])
+    ctx = engine.Context(max_n=8, max_m=8, max_d=d)
+    ctx.window_init(1, N, d, 1, theta)
+    outs = [ctx.window_push(X[a:a + 2500][None], y[a:a + 2500][None]) for a in range(0, T, 2500)]
+    pm, pv, lm = (np.concatenate([o[q][0] for o in outs]) for q in range(3))
+    assert ctx.window_state(0) == (N, 0)
+    assert np.all(np.isfinite(lm)) and np.all(pv > theta[-1] * (1 - 1e-9))
+    for t in (N - 1, N, 2499, 2500, 5000, 7777, T - 1):
+        lo = max(0, t + 1 - N)
+        f = go.fit(1, theta, X[lo:t + 1], y[lo:t + 1])
+        assert abs(lm[t] - f.logml) <= TOL * abs(f.logml), t
+        fp = go.fit(1, theta, X[max(0, t - N + 1):t], y[max(0, t - N + 1):t]) if t >= N else go.fit(1, theta, X[:t], y[:t])
+        mu, var = go.predict(fp, X[t:t + 1])
+        assert abs(pm[t] - mu[0]) <= TOL * max(abs(mu[0]), 1e-3) and abs(pv[t] - var[0]) <= TOL * var[0], t
+
+
 def test_many_windows_independent(engine):
     nwin, N, d, T = 5, 24, 1, 70
     Xs, ys = zip(*[stream(T, d, 300 + w, tick0=11 + 5 * w) for w in range(nwin)])
