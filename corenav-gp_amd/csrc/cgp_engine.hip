@@ -63,6 +63,7 @@ struct cgp_ctx {
   void *dpart = nullptr;   // latency schedule: partial tiles [LAT_FITS][slots][SK_MAX][128*128]
   int *dticket = nullptr;  //                   arrival tickets [LAT_FITS][slots]
   int *dwready = nullptr;  //                   published block steps [LAT_FITS]
+  void *dlatimg = nullptr;  //                  pre-updated diagonal tiles [LAT_FITS][2][LAT_IMG_MAX][DPART]
   double *dmacc = nullptr;  // [max_batch][2][max_m] running predictive sums (throughput schedule, fp64)
   void *ddiagimg = nullptr;  // [max_batch][2][DPART] pre-updated diagonal tiles (throughput schedule, diag_next)
   // cgp_fit_predict_batch staging, grown on demand and kept: pinned host buffers (hipHostMalloc) so the
@@ -355,7 +356,11 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // the panel tiles of a step in one launch, inner dimension split over up to SK_MAX workgroups.
   if (latency) {
     const bool split_trmm = !sw.sk_fused_trmm;
-    SplitArgs q{c->dpart, c->dticket, c->sk_slots, 1, in_rows ? 1 : 0, c->dwready, split_trmm ? 0 : 1};
+    if (in_rows && lat_images(a.NT - 1) > LAT_IMG_MAX) {
+      c->err = "window too long for the latency schedule's diagonal images";
+      return CGP_ECAPACITY;
+    }
+    SplitArgs q{c->dpart, c->dticket, c->sk_slots, 1, in_rows ? 1 : 0, c->dwready, c->dlatimg, split_trmm ? 0 : 1};
     if (in_rows) HIP_TRY(c, hipMemsetAsync(c->dwready, 0, sizeof(int) * LAT_FITS, s));
     for (int k = 0; k < a.NT; ++k) {
       const int tiles = (in_rows ? a.NT - k - 1 : 0) + a.ET;
@@ -365,7 +370,9 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       const int sk = std::max(1, std::min(SK_MAX, k));
       q.sk = sk;
       L[0].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, batch) + (in_rows ? diag_flops(a.N, a.d, k, batch) : 0.0));
-      hipLaunchKernelGGL(k_tile_sk<T>, dim3(nslots, batch, sk), dim3(256), in_rows ? tile_lds : upd_lds, s, ga[0], q, k);
+      // z also carries the pre-update workgroups of the NEXT diagonal tile (1 + images of tile k + 1)
+      const int gz = in_rows ? std::max(sk, 1 + (k + 1 < a.NT ? lat_images(k + 1) : 0)) : sk;
+      hipLaunchKernelGGL(k_tile_sk<T>, dim3(nslots, batch, gz), dim3(256), in_rows ? tile_lds : upd_lds, s, ga[0], q, k);
       L[0].end();
       if (split_trmm) {
         L[0].begin(2, trsm_flops(a.N, a.M, k, in_rows, batch));
@@ -626,6 +633,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc((void **)&c->dticket, sizeof(int) * LAT_FITS * c->sk_slots) == hipSuccess;
   ok = ok && hipMemset(c->dticket, 0, sizeof(int) * LAT_FITS * c->sk_slots) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dwready, sizeof(int) * LAT_FITS) == hipSuccess;
+  ok = ok && hipMalloc(&c->dlatimg, (size_t)LAT_FITS * 2 * LAT_IMG_MAX * DPART * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dmacc, sizeof(double) * 2 * B * std::max(c->max_m, 1)) == hipSuccess;
   ok = ok && hipMalloc(&c->ddiagimg, B * 2 * DPART * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->ddbg, DBG_SLOTS * sizeof(long long)) == hipSuccess;
@@ -649,7 +657,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {

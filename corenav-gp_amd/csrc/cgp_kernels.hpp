@@ -322,31 +322,98 @@ __device__ __forceinline__ void factor_block16(T (&a)[DB], T (&w)[DB], int &bad,
 }
 
 // --------------------------------------------------------------------------------------------------
-// k_potf2: factor the 128x128 diagonal tile (a3 "potf2_diag") and invert the factor, one workgroup
-// per fit, everything resident in LDS:
-//   for each 16-column panel:  (a) wave 0 factors the 16x16 diagonal block and inverts it in
-//       registers (lane = row, v_readlane broadcasts, no barriers);
-//       (b) panel rows below  P = A Dinv^T          -- MFMA 16x16x4, one 16-row block per wave-slot
-//       (c) trailing update   C -= P P^T            -- MFMA, lower block pairs round-robin over waves
-//   then (d) W = L^-1 by block levels (MFMA), kept transposed in the unused upper triangle.
-// LDS tile is column-major with leading dimension LDP.  info = first non-positive pivot (1-based).
+// potf2_tile: factor the LDS-resident 128x128 diagonal tile (a3 "potf2_diag"), invert the factor, and write
+// L(k,k) and the block image of -W_k to HBM -- the latency schedule's per-step critical path, so it is
+// organised around its one serial chain, the eight 16x16 diagonal blocks (factor_block16, wave 0):
+//   F(jb)  wave 0: factor + invert diagonal block jb in registers (lane = row, DPP broadcasts)
+//          waves 1-3, meanwhile: everything that is NOT on the chain -- the trailing update with panel
+//          jb-1 of the block columns >= jb+1, row jb-1 of W = L^-1 (the inverse grows with the factor:
+//          W_ij = -Dinv_i sum_{j <= q < i} L_iq W_qj only needs rows < i of W and Dinv_i), and the HBM stores
+//          of column jb-1 of L and row jb-1 of the W image
+//   P(jb)  all waves: panel  L(i,jb) = A(i,jb) Dinv_jb^T,  i > jb                       (MFMA 16x16x4)
+//   U(jb)  all waves: update of block column jb+1 ONLY with panel jb -- all the next diagonal block needs
+// so the chain is 8 x (factor + two short MFMA phases) and the ~60 % of the tile's work that used to
+// follow the last pivot (inverse by levels, stores) or sit between pivots (whole trailing update) runs
+// beside it.  LDS tile column-major with leading dimension LDP; W_ij is kept transposed in the unused upper
+// triangle; Dv[jb] = Dinv_jb.  info = first non-positive pivot (1-based).
 // --------------------------------------------------------------------------------------------------
-// Phases (a)-(d) on an LDS-resident tile: factor it in place (lower triangle), leave W = L^-1
-// transposed in the strict upper triangle and the inverted 16x16 diagonal blocks in Dv.
 template <typename T>
-__device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, int k, int tid, long long *dbgbuf = nullptr,
-                                               int live = TS) {
+__device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts, int *flag, T *__restrict__ tile, int ld,
+                                           int b, int k, int tid) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
+  constexpr int NB = TS / DB;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
-  long long tA = 0, tB = 0, tC = 0, t0 = __builtin_amdgcn_s_memtime();
-  for (int jb = 0; jb < TS / DB; ++jb) {
+  const int live = p.N - k * TS;
+  T *__restrict__ Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * WIMG;
+  T *tsw = Ts + wave * DB * DB;
+
+  // C(bi, bj) -= L(bi, jp) L(bj, jp)^T   (bi >= bj > jp)
+  auto trailing_block = [&](int bi, int bj, int jp) {
+    acc_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = At[(bj * DB + P::drow(lane, r)) * LDP + bi * DB + l15];
+    T fa[4], fb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fa[ks] = -At[(jp * DB + ks * 4 + lq) * LDP + bj * DB + l15];
+      fb[ks] = At[(jp * DB + ks * 4 + lq) * LDP + bi * DB + l15];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) At[(bj * DB + P::drow(lane, r)) * LDP + bi * DB + l15] = acc[r];
+  };
+  // W(i, j) = -Dinv_i sum_{j <= q < i} L(i, q) W(q, j), written to LDS (transposed, upper triangle) and, negated,
+  // to its block of the HBM image straight from the accumulator
+  auto inverse_block = [&](int i, int j) {
+    acc_t acc = acc_t{0, 0, 0, 0};
+    for (int kk = j; kk < i; ++kk) {
+      T fa[4], fb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        fa[ks] = At[(kk * DB + ks * 4 + lq) * LDP + i * DB + l15];  // L_{i,kk}[r = l15][q]
+        fb[ks] = (kk == j) ? Dv[j * DB * DB + l15 * DB + ks * 4 + lq]  // Dinv_j[q][c = l15]
+                           : At[(kk * DB + ks * 4 + lq) * LDP + j * DB + l15];  // W_{kk,j}[q][c]
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tsw[P::drow(lane, r) * DB + l15] = acc[r];  // T[r][c] (wave-private scratch)
+    acc_t acc2 = acc_t{0, 0, 0, 0};
+    T ga[4], gb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      ga[ks] = -Dv[i * DB * DB + (ks * 4 + lq) * DB + l15];  // -Dinv_i[r = l15][q]
+      gb[ks] = tsw[(ks * 4 + lq) * DB + l15];                // T[q][c = l15]
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc2 = P::mfma(ga[ks], gb[ks], acc2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      At[(i * DB + P::drow(lane, r)) * LDP + j * DB + l15] = acc2[r];          // W_ij[row drow][col l15]
+      Wk[wimg_blk(i, j) + l15 * DB + P::drow(lane, r)] = -acc2[r];             // image [q = col][c = row]
+    }
+  };
+  // column block jp of L (rows >= 16 jp; zero above the diagonal inside the diagonal block) and the image of
+  // Dinv_jp, by the `nthr` threads whose index among them is `t`
+  auto store_column = [&](int jp, int t, int nthr) {
+    const int rows = TS - jp * DB;
+    for (int idx = t; idx < DB * rows; idx += nthr) {
+      const int c = jp * DB + idx / rows, r = jp * DB + idx % rows;
+      tile[(size_t)c * ld + r] = (r >= c) ? At[c * LDP + r] : T(0);
+    }
+    for (int e = t; e < DB * DB; e += nthr) Wk[wimg_blk(jp, jp) + e] = -Dv[jp * DB * DB + e];
+  };
+
+  for (int jb = 0; jb < NB; ++jb) {
     const int j0 = jb * DB;
-    long long s0 = __builtin_amdgcn_s_memtime();
+    // ---- F(jb)
     if (wave == 0) {
-      // (a) lane holds row (lane & 15) of the diagonal block (replicated over the four 16-lane groups)
+      // lane holds row (lane & 15) of the diagonal block (replicated over the four 16-lane groups)
       T a[DB], w[DB];
       int bad = 0;
       if (j0 < live) {
@@ -362,17 +429,43 @@ __device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, i
 #pragma unroll
         for (int c = 0; c < DB; ++c)
           if (l15 >= c) At[(j0 + c) * LDP + j0 + l15] = a[c];
-      }
-      if (lane < DB) {
 #pragma unroll
         for (int i = 0; i < DB; ++i) Dv[jb * DB * DB + l15 * DB + i] = w[i];
       }
+    } else {
+      const int t3 = tid - 64;  // 0..191 among the three helper waves
+      if (jb == 0) {
+        // the strictly upper 16x16 blocks of the tile in HBM are zero
+        for (int idx = t3; idx < 28 * DB * DB; idx += 192) {
+          const int blk = idx >> 8, e = idx & 255;
+          int i = 1, rem = blk;
+          while (rem >= i) {
+            rem -= i;
+            ++i;
+          }
+          tile[(size_t)(i * DB + (e >> 4)) * ld + rem * DB + (e & 15)] = T(0);
+        }
+      } else {
+        const int jp = jb - 1, nb = NB - 1 - jb;  // block columns jb+1 .. 7 still take panel jp
+        const int ntr = nb * (nb + 1) / 2;
+        for (int idx = wave - 1; idx < ntr + jp; idx += 3) {
+          if (idx < ntr) {
+            int bj = 0, rem = idx;
+            while (rem >= nb - bj) {
+              rem -= nb - bj;
+              ++bj;
+            }
+            trailing_block(bj + rem + jb + 1, bj + jb + 1, jp);
+          } else {
+            inverse_block(jp, idx - ntr);
+          }
+        }
+        store_column(jp, t3, 192);
+      }
     }
     __syncthreads();
-    long long s1 = __builtin_amdgcn_s_memtime();
-    tA += s1 - s0;
-    // (b) panel: rows of block bi below the diagonal block, P[r][c] = sum_q A[r][q] Dinv[c][q]
-    for (int bi = jb + 1 + wave; bi < TS / DB; bi += 4) {
+    // ---- P(jb): rows of block bi below the diagonal block, P[r][c] = sum_q A[r][q] Dinv[c][q]
+    for (int bi = jb + 1 + wave; bi < NB; bi += 4) {
       acc_t acc = acc_t{0, 0, 0, 0};
       T fa[4], fb[4];
 #pragma unroll
@@ -386,103 +479,14 @@ __device__ __forceinline__ void potf2_lds_body(T *At, T *Dv, T *Ts, int *flag, i
       for (int r = 0; r < 4; ++r) At[(j0 + P::drow(lane, r)) * LDP + bi * DB + l15] = acc[r];
     }
     __syncthreads();
-    long long s2 = __builtin_amdgcn_s_memtime();
-    tB += s2 - s1;
-    // (c) trailing update of the lower block pairs (bi >= bj > jb)
-    const int nb = TS / DB - jb - 1;
-    for (int idx = wave; idx < nb * (nb + 1) / 2; idx += 4) {
-      int bj = 0, rem = idx;
-      while (rem >= nb - bj) {
-        rem -= nb - bj;
-        ++bj;
-      }
-      const int bi = bj + rem + jb + 1;
-      bj += jb + 1;
-      acc_t acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = At[(bj * DB + P::drow(lane, r)) * LDP + bi * DB + l15];
-      T fa[4], fb[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        fa[ks] = -At[(j0 + ks * 4 + lq) * LDP + bj * DB + l15];
-        fb[ks] = At[(j0 + ks * 4 + lq) * LDP + bi * DB + l15];
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) At[(bj * DB + P::drow(lane, r)) * LDP + bi * DB + l15] = acc[r];
-    }
-    __syncthreads();
-    tC += __builtin_amdgcn_s_memtime() - s2;
-  }
-  long long t1 = __builtin_amdgcn_s_memtime();
-
-  // (d) W = L^-1: block (i, j), i > j:  W_ij = -Dinv_i * sum_{kk=j}^{i-1} L_{i,kk} W_{kk,j}.
-  // Blocks with the same i - j are independent (one level per barrier).  W_ij is stored transposed
-  // at the upper-triangle position, i.e. W_ij[r][c] at At[(16 i + r) * LDP + 16 j + c].
-  T *tsw = Ts + wave * DB * DB;
-  for (int lev = 1; lev < TS / DB; ++lev) {
-    for (int j = wave; j + lev < TS / DB; j += 4) {
-      const int i = j + lev;
-      acc_t acc = acc_t{0, 0, 0, 0};
-      for (int kk = j; kk < i; ++kk) {
-        T fa[4], fb[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          fa[ks] = At[(kk * DB + ks * 4 + lq) * LDP + i * DB + l15];  // L_{i,kk}[r = l15][q]
-          fb[ks] = (kk == j) ? Dv[j * DB * DB + l15 * DB + ks * 4 + lq]  // Dinv_j[q][c = l15]
-                             : At[(kk * DB + ks * 4 + lq) * LDP + j * DB + l15];  // W_{kk,j}[q][c]
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tsw[P::drow(lane, r) * DB + l15] = acc[r];  // T[r][c]
-      acc_t acc2 = acc_t{0, 0, 0, 0};
-      T ga[4], gb[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        ga[ks] = -Dv[i * DB * DB + (ks * 4 + lq) * DB + l15];  // -Dinv_i[r = l15][q]
-        gb[ks] = tsw[(ks * 4 + lq) * DB + l15];                // T[q][c = l15]
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc2 = P::mfma(ga[ks], gb[ks], acc2);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) At[(i * DB + P::drow(lane, r)) * LDP + j * DB + l15] = acc2[r];
-    }
+    // ---- U(jb): block column jb + 1 with panel jb
+    for (int bi = jb + 1 + wave; bi < NB; bi += 4) trailing_block(bi, jb + 1, jb);
     __syncthreads();
   }
-  if (dbgbuf && tid == 0 && blockIdx.x == 0) {
-    dbgbuf[0] = tA;
-    dbgbuf[1] = tB;
-    dbgbuf[2] = tC;
-    dbgbuf[3] = t1 - t0;
-    dbgbuf[4] = __builtin_amdgcn_s_memtime() - t1;
-  }
-}
-
-// Phase (e): write L (upper triangle zeroed) to the factor panel and the block image of -W_k.
-template <typename T>
-__device__ __forceinline__ void potf2_store(const FitArgs &p, const T *At, const T *Dv, const int *flag, T *tile,
-                                            int ld, int b, int k, int tid) {
+  // ---- tail: row 7 of W and the last column
+  for (int j = wave; j < NB - 1; j += 4) inverse_block(NB - 1, j);
+  store_column(NB - 1, tid, 256);
   if (tid == 0 && *flag != 0 && p.info[b] == 0) p.info[b] = *flag;
-  T *Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * WIMG;
-  for (int idx = tid; idx < TS * TS; idx += 256) {
-    const int c = idx >> 7, r = idx & 127;
-    tile[(size_t)c * ld + r] = (r >= c) ? At[c * LDP + r] : T(0);
-  }
-  for (int idx = tid; idx < WIMG; idx += 256) {
-    const int blk = idx >> 8, q = (idx >> 4) & 15, cc = idx & 15;
-    int cb = 0, rem = blk;
-    while (rem > cb) {
-      rem -= cb + 1;
-      ++cb;
-    }
-    const int qb = rem, r = cb * DB + cc, c = qb * DB + q;  // W[r][c]
-    // diagonal blocks: Dv[jb][q][x] = Dinv_jb[x][q] (zero above the diagonal); others: W^T in the upper triangle of At
-    const T w = (cb == qb) ? Dv[cb * DB * DB + q * DB + cc] : At[r * LDP + c];
-    Wk[idx] = -w;
-  }
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -1148,8 +1148,7 @@ __global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
   if (tid == 0) *flag = 0;
   __syncthreads();
   const long long tq = __builtin_amdgcn_s_memtime();
-  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, CGP_DBG_ON(p, 512) ? p.dbgbuf : nullptr, p.N - k * TS);
-  potf2_store<T>(p, At, Dv, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
+  potf2_tile<T>(p, At, Dv, Ts, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
   if (CGP_DBG_ON(p, 512) && tid == 0 && b == 0) { p.dbgbuf[5] = __builtin_amdgcn_s_memtime() - tq; p.dbgbuf[6] = tq - tstart; }
 }
 
@@ -1164,7 +1163,7 @@ __global__ __launch_bounds__(256) void k_diag(FitArgs p, int k) {
 //                  0.  Partial tiles go to a scratch slab; the workgroup that arrives last (atomic
 //                  ticket) adds them in fixed order 0..SK-1 -- results do not depend on arrival
 //                  order -- and finishes the tile: the diagonal tile is factored and inverted in
-//                  LDS (potf2_lds_body), the others are stored as -S into their slot of the panel.
+//                  LDS (potf2_tile), the others are stored as -S into their slot of the panel.
 //                  The diagonal update and the panel updates of a step thus run side by side.
 //   k_trmm_sk(k) : L(i,k) = S(i,k) W_k^T in registers, as the tail of k_panel.
 //                  (CGP_SK_TRMM=fused: the other finishers of k_tile_sk wait -- bounded -- for W_k and
@@ -1177,15 +1176,22 @@ struct SplitArgs {
   int sk;           // ranges the inner dimension is cut into (1..SK_MAX)
   int has_diag;     // fit: slot 0 is the diagonal tile; predict-only: extra tiles only
   int *wready;      // [fits] number of block steps whose W_k is published (fit schedule); see k_tile_sk
+  void *diag_img;   // [fits][2][LAT_IMG_MAX][DPART] pre-updated diagonal tiles (register images), by parity of the tile
   int fuse_trmm;    // finishers of the non-diagonal tiles wait for W_k and apply it (one launch per step)
 };
 constexpr int SK_MAX = 8;
+
+// Chunks of one pre-update workgroup of the diagonal tile (latency schedule): 6 block columns.
+constexpr int LAT_IMG_CHUNKS = 6 * (TS / KT);
+constexpr int LAT_IMG_MAX = 3;  // images per diagonal tile: covers (LAT_IMG_MAX * 6 + 1) * 128 = 2432 columns
+__host__ __device__ __forceinline__ constexpr int lat_images(int kn) {  // images of diagonal tile kn: columns < (kn-1)*128
+  return kn >= 2 ? ((kn - 1) * (TS / KT) + LAT_IMG_CHUNKS - 1) / LAT_IMG_CHUNKS : 0;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
-  using vec2 = T __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   __shared__ int s_last;
@@ -1199,7 +1205,93 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
   const int l15 = lane & 15;
   constexpr int CH2 = 2 * KT * LDST;
 
+  // phase clock of the workgroup that finishes the DIAGONAL tile (CGP_DBG & 1024, measurement build):
+  // slots 8.. = Gram / images + last block column, -, -, LDS fill, factorisation + stores; slot 15 = count
+  PhaseClock pc;
+  pc.start(p, tid);
   acc_t acc[NCB][2];
+
+  if (diag) {
+    // ---- the diagonal tile is the per-step critical path (its factorisation is serial), so its update never
+    // goes through the split-K slabs: the block columns < k - 1 were pre-applied during the PREVIOUS step's
+    // launch (workgroups z >= 1 below, hidden behind that step's factorisation) and left as register images;
+    // this workgroup sums them in fixed order, adds block column k - 1 (final since the trmm launch in
+    // between) on the triangular loop and factors.  Same arithmetic order whatever shares the launch.
+    T *imgs = reinterpret_cast<T *>(q.diag_img) + (size_t)b * 2 * LAT_IMG_MAX * DPART;
+    if (sp >= 1) {
+      const int kn = k + 1, s = sp - 1;  // pre-update of the NEXT diagonal tile, image s
+      if (kn >= p.NT || s >= lat_images(kn)) return;
+      const int c0 = s * LAT_IMG_CHUNKS, c1 = min((s + 1) * LAT_IMG_CHUNKS, (kn - 1) * (TS / KT));
+      const T *gR = Lw + (size_t)kn * TS + (size_t)(c0 * KT) * ld;
+      const int nchunk = c1 - c0;
+      GramPre<T> gp;
+      if (s == 0) gram_prefetch<T>(p, b, kn, kn, tid, gp);
+      stage_chunk_tri<T>(gR, (size_t)ld, 0, smem + tri_buf(0), tid);
+      if (sizeof(T) == 8 && nchunk > 1) stage_chunk_tri<T>(gR, (size_t)ld, 1, smem + tri_buf(1), tid);
+      if (s == 0) gram_apply<T, true>(p, acc, smem + CH2, b, kn, kn, tid, gp);
+      else {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = acc_t{0, 0, 0, 0};
+      }
+      mfma_syrk_tri_loop<T>(acc, gR, (size_t)ld, nchunk, smem, tid);
+      acc_image<T, true, true>(acc, imgs + ((size_t)(kn & 1) * LAT_IMG_MAX + s) * DPART, tid);
+      return;
+    }
+    const int nimg = lat_images(k);
+    const int c0 = k >= 1 ? (k - 1) * (TS / KT) : 0, nchunk = k * (TS / KT) - c0;
+    const T *gR = Lw + (size_t)k * TS + (size_t)(c0 * KT) * ld;
+    {
+      GramPre<T> gp;
+      if (nimg == 0) gram_prefetch<T>(p, b, k, k, tid, gp);
+      if (nchunk > 0) stage_chunk_tri<T>(gR, (size_t)ld, 0, smem + tri_buf(0), tid);
+      if (sizeof(T) == 8 && nchunk > 1) stage_chunk_tri<T>(gR, (size_t)ld, 1, smem + tri_buf(1), tid);
+      if (nimg == 0) gram_apply<T, true>(p, acc, smem + CH2, b, k, k, tid, gp);
+      else {
+        T *im = imgs + (size_t)(k & 1) * LAT_IMG_MAX * DPART;
+        acc_image<T, true, false>(acc, im, tid);
+        for (int s = 1; s < nimg; ++s) {  // fixed order
+          acc_t add[NCB][2];
+          acc_image<T, true, false>(add, im + (size_t)s * DPART, tid);
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (cb <= (j ? NCB - 1 - wave : wave)) acc[cb][j] += add[cb][j];
+        }
+      }
+    }
+    mfma_syrk_tri_loop<T>(acc, gR, (size_t)ld, nchunk, smem, tid);
+    __syncthreads();
+    pc.lap(p, 8);
+    T *At = smem;  // element (r, c) at At[c * LDP + r]
+    T *Dv = At + TS * LDP;
+    T *Ts = Dv + 8 * DB * DB;
+    int *flag = reinterpret_cast<int *>(Ts + 4 * DB * DB);
+    // lower 16x16 blocks only (wave w: block rows w and 7 - w); the factorisation never reads the others
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rb = j ? NCB - 1 - wave : wave;
+        if (cb <= rb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) At[(cb * DB + P::drow(lane, r)) * LDP + rb * DB + l15] = -acc[cb][j][r];
+        }
+      }
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    pc.lap(p, 11);  // tile into LDS
+    potf2_tile<T>(p, At, Dv, Ts, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
+    pc.lap(p, 12);  // factorisation, inverse, stores
+    pc.count(p, 15);
+    __threadfence();   // W_k (and L(k,k)) visible device-wide before the step is announced
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(q.wready + b, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+
+  // ---- panel / extra tiles: inner dimension split over q.sk workgroups, ticketed fixed-order reduction
+  if (sp >= q.sk) return;  // the grid's z extent also covers the diagonal tile's pre-update workgroups
   if (sp == 0) {
     GramPre<T> gp;
     gram_prefetch<T>(p, b, k, rt, tid, gp);
@@ -1232,49 +1324,26 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
   }
   __syncthreads();
 
-  if (!diag && !q.fuse_trmm) {
+  if (!q.fuse_trmm) {
     store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
     return;
   }
-  if (!diag) {
-    // L(rt, k) = S W_k^T here as well: W_k comes from the diagonal tile's finishing workgroup of THIS
-    // launch.  Its workgroups have been dispatched by now or will be without this one's help (at
-    // most one waiting workgroup per tile, far fewer than CUs), so waiting cannot deadlock; the wait
-    // is bounded all the same and a timeout is reported through info[] instead of hanging the GPU.
-    if (q.has_diag) {
-      if (tid == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(q.wready + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <= k && ++spins < (1 << 22))
-          __builtin_amdgcn_s_sleep(8);
-        if (spins >= (1 << 22)) atomicCAS(p.info + b, 0, -(k + 1));
-      }
-      __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // L(rt, k) = S W_k^T here as well (CGP_SK_TRMM=fused, measurement build): W_k comes from the diagonal tile's
+  // workgroup of THIS launch.  Its workgroup has been dispatched by now or will be without this one's help
+  // (at most one waiting workgroup per tile, far fewer than CUs), so waiting cannot deadlock; the wait is
+  // bounded all the same and a timeout is reported through info[] instead of hanging the GPU.
+  if (q.has_diag) {
+    if (tid == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(q.wready + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <= k && ++spins < (1 << 22))
+        __builtin_amdgcn_s_sleep(8);
+      if (spins >= (1 << 22)) atomicCAS(p.info + b, 0, -(k + 1));
     }
-    trmm_in_registers<T>(p, acc, smem, b, k, tid);
-    store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
-    return;
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  T *At = smem;  // element (r, c) at At[c * LDP + r]
-  T *Dv = At + TS * LDP;
-  T *Ts = Dv + 8 * DB * DB;
-  int *flag = reinterpret_cast<int *>(Ts + 4 * DB * DB);
-#pragma unroll
-  for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      vec2 v;
-      v[0] = -acc[cb][0][r];
-      v[1] = -acc[cb][1][r];
-      *reinterpret_cast<vec2 *>(At + (cb * DB + P::drow(lane, r)) * LDP + wave * 32 + 2 * l15) = v;
-    }
-  if (tid == 0) *flag = 0;
-  __syncthreads();
-  potf2_lds_body<T>(At, Dv, Ts, flag, k, tid, nullptr, p.N - k * TS);
-  potf2_store<T>(p, At, Dv, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
-  __threadfence();   // W_k (and L(k,k)) visible device-wide before the step is announced
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(q.wready + b, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  trmm_in_registers<T>(p, acc, smem, b, k, tid);
+  store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
 }
 
 template <typename T>

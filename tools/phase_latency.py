@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Per-phase cycle sums of the latency schedule's diagonal-tile workgroup (k_tile_sk, CGP_DBG & 1024):
+   CGP_LIB=corenav-gp_amd/libcorenav_gp_ab.so CGP_DBG=1024 python tools/phase_latency.py"""
+import json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import bench
+import corenav_gp_amd.engine as engine
+import corenav_gp_amd.synth as synth
+kid, X, y, Xs, th, dts = synth.config(2, batch=1)
+W = bench.Workload(engine, torch, torch.device("cuda", 0), 0, kid, X, y, Xs, th, dts, 1)
+for _ in range(3):
+    W._call(1)
+torch.cuda.synchronize(); W.ctx.debug_read()
+reps = 10
+for _ in range(reps):
+    W._call(1)
+torch.cuda.synchronize()
+o = W.ctx.debug_read()
+n = max(int(o[15]), 1)
+names = ["update", "slab_ticket", "reduce", "lds_fill", "potf2"]
+print(json.dumps({"diag_wgs": n, "ticks_per_step": {nm: float(o[8 + i]) / n for i, nm in enumerate(names)}, "latency_ms": W.single_fit_latency_ms()}))
