@@ -283,15 +283,14 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     gs[g] = (G == 1) ? s : c->wstream[g];
     g0 += gb[g];
   }
-  hipLaunchKernelGGL(k_prep, dim3(cdiv(batch, 64)), dim3(64), 0, s, a, batch, c->dprep);
+  hipLaunchKernelGGL(k_prep, dim3(cdiv(batch, 64)), dim3(64), 0, s, a, batch, c->dprep, in_rows ? 1 : 0,
+                     (latency && in_rows) ? c->dwready : nullptr);
   if (G > 1) {
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
     for (int g = 0; g < G; ++g) HIP_TRY(c, hipStreamWaitEvent(gs[g], c->ev_fork, 0));
   }
   std::vector<Launcher> L;
   for (int g = 0; g < G; ++g) L.push_back(Launcher{c, gs[g]});
-  if (in_rows)
-    for (int g = 0; g < G; ++g) HIP_TRY(c, hipMemsetAsync(ga[g].info, 0, sizeof(int) * gb[g], gs[g]));
   // throughput schedule: the predictive sums V z and |V|^2 accumulate inside k_panel (block column
   // k - 1 while it streams through the row fragments of step k); k_finalize then only adds the last
   // block column instead of reading all of V.
@@ -361,7 +360,6 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       return CGP_ECAPACITY;
     }
     SplitArgs q{c->dpart, c->dticket, c->sk_slots, 1, in_rows ? 1 : 0, c->dwready, c->dlatimg, split_trmm ? 0 : 1};
-    if (in_rows) HIP_TRY(c, hipMemsetAsync(c->dwready, 0, sizeof(int) * LAT_FITS, s));
     for (int k = 0; k < a.NT; ++k) {
       const int tiles = (in_rows ? a.NT - k - 1 : 0) + a.ET;
       const int nslots = tiles + (in_rows ? 1 : 0);
@@ -381,7 +379,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       }
     }
     L[0].begin(3, batch * (4.0 * a.M * a.N + 2.0 * a.N));
-    hipLaunchKernelGGL((k_finalize<T, 16>), dim3(cdiv(a.M, 16) + 1, batch), dim3(256), 0, s, ga[0], in_rows ? 1 : 0);
+    hipLaunchKernelGGL((k_finalize<T, 8>), dim3(cdiv(a.M, 8) + 1, batch), dim3(256), 0, s, ga[0], in_rows ? 1 : 0);
     L[0].end();
     if (want_alpha) {
       L[0].begin(4, batch * (double)a.N * a.N);

@@ -467,9 +467,11 @@ __device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<
 
 // Per-fit derived constants (inverse length-scales, log amplitude, diagonal addend), computed once
 // per schedule so the tile kernels read them with scalar loads instead of dividing per thread.
-__global__ void k_prep(FitArgs p, int batch, double *prep) {
+__global__ void k_prep(FitArgs p, int batch, double *prep, int zero_info, int *wready) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
+  if (zero_info) p.info[b] = 0;      // a fit schedule starts with a clean status (no separate memset node)
+  if (wready) wready[b] = 0;
   const double *th = p.theta + (size_t)b * MAX_THETA;
   double *o = prep + (size_t)b * PREP_N;
   const int kid = p.kernel_id, d = p.d;
@@ -1181,9 +1183,10 @@ struct SplitArgs {
 };
 constexpr int SK_MAX = 8;
 
-// Chunks of one pre-update workgroup of the diagonal tile (latency schedule): 6 block columns.
-constexpr int LAT_IMG_CHUNKS = 6 * (TS / KT);
-constexpr int LAT_IMG_MAX = 3;  // images per diagonal tile: covers (LAT_IMG_MAX * 6 + 1) * 128 = 2432 columns
+// Chunks of one pre-update workgroup of the diagonal tile (latency schedule): 3 block columns, so that it is
+// shorter than the factorisation it hides behind.
+constexpr int LAT_IMG_CHUNKS = 3 * (TS / KT);
+constexpr int LAT_IMG_MAX = 6;  // images per diagonal tile: covers (LAT_IMG_MAX * 3 + 1) * 128 = 2432 columns
 __host__ __device__ __forceinline__ constexpr int lat_images(int kn) {  // images of diagonal tile kn: columns < (kn-1)*128
   return kn >= 2 ? ((kn - 1) * (TS / KT) + LAT_IMG_CHUNKS - 1) / LAT_IMG_CHUNKS : 0;
 }
@@ -1235,6 +1238,8 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
       }
       mfma_syrk_tri_loop<T>(acc, gR, (size_t)ld, nchunk, smem, tid);
       acc_image<T, true, true>(acc, imgs + ((size_t)(kn & 1) * LAT_IMG_MAX + s) * DPART, tid);
+      pc.lap(p, 24);  // a pre-update workgroup, whole life
+      pc.count(p, 25);
       return;
     }
     const int nimg = lat_images(k);
@@ -1301,31 +1306,77 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = acc_t{0, 0, 0, 0};
   }
+  // Ranges of the inner dimension: range 0 also builds the Gram tile, which costs about as much as
+  // GRAM_UNITS chunks, so the n chunks + GRAM_UNITS are split evenly and range 0 gets that many fewer
+  // chunks.  A function of (k, sk) only: the summation order does not depend on what shares the launch.
   const int n = (k * TS) / KT;
-  const int c0 = (int)((long long)sp * n / q.sk), c1 = (int)((long long)(sp + 1) * n / q.sk);
+  constexpr int GRAM_UNITS = 4;
+  auto bound = [&](int i) {
+    if (q.sk == 1) return i == 0 ? 0 : n;
+    const int u = (int)((long long)i * (n + GRAM_UNITS) / q.sk) - GRAM_UNITS;
+    return i >= q.sk ? n : (u < 0 ? 0 : u);
+  };
+  const int c0 = sp == 0 ? 0 : bound(sp), c1 = bound(sp + 1);
   const T *gR = Lw + (size_t)rt * TS + (size_t)(c0 * KT) * ld, *gC = Lw + (size_t)k * TS + (size_t)(c0 * KT) * ld;
   mfma_rowpanel_loop<T, false>(acc, gR, (size_t)ld, gC, (size_t)ld, c1 - c0, smem, tid);
+  pc.lap(p, sp == 0 ? 16 : 17);  // panel tiles: Gram + update (range 0) / update (other ranges), every workgroup
+  pc.count(p, sp == 0 ? 22 : 23);
 
   if (q.sk > 1) {
     T *slab = reinterpret_cast<T *>(q.part) + ((size_t)(b * q.slots + t) * SK_MAX) * TS * TS;
     store_tile<T>(acc, slab + (size_t)sp * TS * TS, TS, tid);
-    __threadfence();
+    // publish: every wave's stores have left the CU, then ONE lane's agent-scope release ahead of the ticket
+    // (the guide's counter form of the hand-off; 256 threads fencing cost 2-4x one lane's)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      const int old = atomicAdd(q.ticket + b * q.slots + t, 1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int old = __hip_atomic_fetch_add(q.ticket + b * q.slots + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = old == q.sk - 1;
-      if (s_last) q.ticket[b * q.slots + t] = 0;
+      if (s_last) {
+        __hip_atomic_store(q.ticket + b * q.slots + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the last arriver reads the other slabs below
+      }
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
-    load_tile<T, false>(acc, slab, TS, tid);
-    for (int s2 = 1; s2 < q.sk; ++s2) load_tile<T, true>(acc, slab + (size_t)s2 * TS * TS, TS, tid);
+    pc.lap(p, 18);  // last arriver: slab store + fence + ticket
+    // fixed-order sum 0 .. sk-1 with the next partial tile's loads in flight while the current one is added
+    using vec2 = T __attribute__((ext_vector_type(2)));
+    const T *src = slab + wave * 32 + 2 * l15;
+    vec2 nx[NCB][4];
+    auto fetch = [&](int s2) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          nx[cb][r] = *reinterpret_cast<const vec2 *>(src + (size_t)s2 * TS * TS + (size_t)(cb * DB + P::drow(lane, r)) * TS);
+    };
+    fetch(0);
+    for (int s2 = 0; s2 < q.sk; ++s2) {
+      vec2 cur[NCB][4];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cur[cb][r] = nx[cb][r];
+      if (s2 + 1 < q.sk) fetch(s2 + 1);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[cb][0][r] = s2 ? acc[cb][0][r] + cur[cb][r][0] : cur[cb][r][0];
+          acc[cb][1][r] = s2 ? acc[cb][1][r] + cur[cb][r][1] : cur[cb][r][1];
+        }
+    }
   }
   __syncthreads();
+  pc.lap(p, 19);  // reduction
 
   if (!q.fuse_trmm) {
     store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
+    pc.lap(p, 20);
+    pc.count(p, 21);
     return;
   }
   // L(rt, k) = S W_k^T here as well (CGP_SK_TRMM=fused, measurement build): W_k comes from the diagonal tile's

@@ -19,4 +19,10 @@ torch.cuda.synchronize()
 o = W.ctx.debug_read()
 n = max(int(o[15]), 1)
 names = ["update", "slab_ticket", "reduce", "lds_fill", "potf2"]
+def avg(slot, cnt):
+    return float(o[slot]) / max(int(o[cnt]), 1)
+extra = {"panel_update_range0": avg(16, 22), "panel_update_other": avg(17, 23), "panel_last_slab_ticket": avg(18, 21),
+         "panel_last_reduce": avg(19, 21), "panel_last_store": avg(20, 21), "preupdate_wg_total": avg(24, 25),
+         "counts": [int(o[c]) for c in (22, 23, 21, 25)]}
+print(json.dumps({"panel": extra}))
 print(json.dumps({"diag_wgs": n, "ticks_per_step": {nm: float(o[8 + i]) / n for i, nm in enumerate(names)}, "latency_ms": W.single_fit_latency_ms()}))
