@@ -84,6 +84,13 @@ struct FitArgs {
 #else
 #define CGP_DBG_ON(p, bit) false
 #endif
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence on ALL memory: hipcc puts
+// s_waitcnt vmcnt(0) in front of s_barrier, so a phase that also issued fire-and-forget HBM stores (a finished
+// column of L, a block of the W image, a swept row of a window) would wait for their acknowledgements --
+// microseconds -- at every barrier.  Use it only where no thread reads, before the next __syncthreads() or the
+// end of the kernel, global memory another thread of the workgroup wrote since the last one.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int DBG_SLOTS = 512;  // cgp_debug_read: [0, 8) potf2 phases, [64 + 8 k, 64 + 8 k + 8) k_panel phases of step k
 
 // Per-phase cycle sums of a kernel (CGP_DBG & 1024 in a -DCGP_ABLATION build): thread 0 of every
@@ -328,8 +335,8 @@ __device__ __forceinline__ void factor_block16(T (&a)[DB], T (&w)[DB], int &bad,
 //   F(jb)  wave 0: factor + invert diagonal block jb in registers (lane = row, DPP broadcasts)
 //          waves 1-3, meanwhile: everything that is NOT on the chain -- the trailing update with panel
 //          jb-1 of the block columns >= jb+1, row jb-1 of W = L^-1 (the inverse grows with the factor:
-//          W_ij = -Dinv_i sum_{j <= q < i} L_iq W_qj only needs rows < i of W and Dinv_i), and the HBM stores
-//          of column jb-1 of L and row jb-1 of the W image
+//          W_ij = -Dinv_i sum_{j <= q < i} L_iq W_qj only needs rows < i of W and Dinv_i; its image blocks go to
+//          HBM straight from the accumulators)
 //   P(jb)  all waves: panel  L(i,jb) = A(i,jb) Dinv_jb^T,  i > jb                       (MFMA 16x16x4)
 //   U(jb)  all waves: update of block column jb+1 ONLY with panel jb -- all the next diagonal block needs
 // so the chain is 8 x (factor + two short MFMA phases) and the ~60 % of the tile's work that used to
@@ -366,11 +373,39 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
 #pragma unroll
     for (int r = 0; r < 4; ++r) At[(bj * DB + P::drow(lane, r)) * LDP + bi * DB + l15] = acc[r];
   };
+  // two independent trailing blocks at once: 24 LDS reads in flight, two MFMA chains interleaved
+  auto trailing_pair = [&](int bi0, int bj0, int bi1, int bj1, int jp) {
+    acc_t a0, a1;
+    T fa0[4], fb0[4], fa1[4], fb1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a0[r] = At[(bj0 * DB + P::drow(lane, r)) * LDP + bi0 * DB + l15];
+      a1[r] = At[(bj1 * DB + P::drow(lane, r)) * LDP + bi1 * DB + l15];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fa0[ks] = -At[(jp * DB + ks * 4 + lq) * LDP + bj0 * DB + l15];
+      fb0[ks] = At[(jp * DB + ks * 4 + lq) * LDP + bi0 * DB + l15];
+      fa1[ks] = -At[(jp * DB + ks * 4 + lq) * LDP + bj1 * DB + l15];
+      fb1[ks] = At[(jp * DB + ks * 4 + lq) * LDP + bi1 * DB + l15];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      a0 = P::mfma(fa0[ks], fb0[ks], a0);
+      a1 = P::mfma(fa1[ks], fb1[ks], a1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      At[(bj0 * DB + P::drow(lane, r)) * LDP + bi0 * DB + l15] = a0[r];
+      At[(bj1 * DB + P::drow(lane, r)) * LDP + bi1 * DB + l15] = a1[r];
+    }
+  };
   // W(i, j) = -Dinv_i sum_{j <= q < i} L(i, q) W(q, j), written to LDS (transposed, upper triangle) and, negated,
-  // to its block of the HBM image straight from the accumulator
+  // to its block of the HBM image straight from the accumulator.  The sum runs on two accumulators (even / odd
+  // q) so that consecutive 4-MFMA products do not wait for each other.
   auto inverse_block = [&](int i, int j) {
-    acc_t acc = acc_t{0, 0, 0, 0};
-    for (int kk = j; kk < i; ++kk) {
+    acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc0;
+    auto term = [&](int kk, acc_t &acc) {
       T fa[4], fb[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -380,9 +415,15 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
+    };
+    int kk = j;
+    for (; kk + 1 < i; kk += 2) {
+      term(kk, acc0);
+      term(kk + 1, acc1);
     }
+    if (kk < i) term(kk, acc0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tsw[P::drow(lane, r) * DB + l15] = acc[r];  // T[r][c] (wave-private scratch)
+    for (int r = 0; r < 4; ++r) tsw[P::drow(lane, r) * DB + l15] = acc0[r] + acc1[r];  // T[r][c] (wave-private scratch)
     acc_t acc2 = acc_t{0, 0, 0, 0};
     T ga[4], gb[4];
 #pragma unroll
@@ -398,17 +439,18 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
       Wk[wimg_blk(i, j) + l15 * DB + P::drow(lane, r)] = -acc2[r];             // image [q = col][c = row]
     }
   };
-  // column block jp of L (rows >= 16 jp; zero above the diagonal inside the diagonal block) and the image of
-  // Dinv_jp, by the `nthr` threads whose index among them is `t`
-  auto store_column = [&](int jp, int t, int nthr) {
-    const int rows = TS - jp * DB;
-    for (int idx = t; idx < DB * rows; idx += nthr) {
-      const int c = jp * DB + idx / rows, r = jp * DB + idx % rows;
-      tile[(size_t)c * ld + r] = (r >= c) ? At[c * LDP + r] : T(0);
-    }
-    for (int e = t; e < DB * DB; e += nthr) Wk[wimg_blk(jp, jp) + e] = -Dv[jp * DB * DB + e];
+  // The blocks of a row of W cost i - j + 1 products each (j = 0 the longest): dealt in snake order over
+  // `nw` waves (0 1 2 2 1 0 0 1 ...) the loads come out equal.
+  auto snake = [](int idx, int nw) {
+    const int q = idx / nw, r = idx % nw;
+    return (q & 1) ? nw - 1 - r : r;
   };
-
+#ifdef CGP_ABLATION
+  long long tF = 0, tP = 0, tU = 0, tm = __builtin_amdgcn_s_memtime();
+#define POTF2_LAP(x) { const long long nn = __builtin_amdgcn_s_memtime(); x += nn - tm; tm = nn; }
+#else
+#define POTF2_LAP(x)
+#endif
   for (int jb = 0; jb < NB; ++jb) {
     const int j0 = jb * DB;
     // ---- F(jb)
@@ -432,38 +474,56 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
 #pragma unroll
         for (int i = 0; i < DB; ++i) Dv[jb * DB * DB + l15 * DB + i] = w[i];
       }
+#ifdef CGP_ABLATION
+      if (CGP_DBG_ON(p, 1024) && tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(p.dbgbuf) + 37, (unsigned long long)(__builtin_amdgcn_s_memtime() - tm));
+#endif
     } else {
-      const int t3 = tid - 64;  // 0..191 among the three helper waves
-      if (jb == 0) {
-        // the strictly upper 16x16 blocks of the tile in HBM are zero
-        for (int idx = t3; idx < 28 * DB * DB; idx += 192) {
-          const int blk = idx >> 8, e = idx & 255;
-          int i = 1, rem = blk;
-          while (rem >= i) {
-            rem -= i;
-            ++i;
-          }
-          tile[(size_t)(i * DB + (e >> 4)) * ld + rem * DB + (e & 15)] = T(0);
-        }
-      } else {
+      if (jb > 0) {
         const int jp = jb - 1, nb = NB - 1 - jb;  // block columns jb+1 .. 7 still take panel jp
         const int ntr = nb * (nb + 1) / 2;
-        for (int idx = wave - 1; idx < ntr + jp; idx += 3) {
-          if (idx < ntr) {
-            int bj = 0, rem = idx;
-            while (rem >= nb - bj) {
-              rem -= nb - bj;
-              ++bj;
-            }
-            trailing_block(bj + rem + jb + 1, bj + jb + 1, jp);
-          } else {
-            inverse_block(jp, idx - ntr);
+#ifdef CGP_ABLATION
+        long long h0 = __builtin_amdgcn_s_memtime();
+#endif
+        for (int j = 0; j < jp; ++j)   // row jp of W, snake order over the three helper waves
+          if (snake(j, 3) == wave - 1) inverse_block(jp, j);
+#ifdef CGP_ABLATION
+        long long h1 = __builtin_amdgcn_s_memtime();
+#endif
+        auto tr_decode = [&](int idx, int &bi, int &bj) {
+          int c = 0, rem = idx;
+          while (rem >= nb - c) {
+            rem -= nb - c;
+            ++c;
           }
+          bi = c + rem + jb + 1;
+          bj = c + jb + 1;
+        };
+        int idx = wave - 1;
+        for (; idx + 3 < ntr; idx += 6) {
+          int bi0, bj0, bi1, bj1;
+          tr_decode(idx, bi0, bj0);
+          tr_decode(idx + 3, bi1, bj1);
+          trailing_pair(bi0, bj0, bi1, bj1, jp);
         }
-        store_column(jp, t3, 192);
+        if (idx < ntr) {
+          int bi0, bj0;
+          tr_decode(idx, bi0, bj0);
+          trailing_block(bi0, bj0, jp);
+        }
+#ifdef CGP_ABLATION
+        if (CGP_DBG_ON(p, 1024) && tid == 64) {
+          unsigned long long *d = reinterpret_cast<unsigned long long *>(p.dbgbuf);
+          atomicAdd(d + 40, (unsigned long long)(h1 - h0));
+          atomicAdd(d + 41, (unsigned long long)(__builtin_amdgcn_s_memtime() - h1));
+        }
+#endif
       }
+#ifdef CGP_ABLATION
+      if (CGP_DBG_ON(p, 1024) && tid == 64) atomicAdd(reinterpret_cast<unsigned long long *>(p.dbgbuf) + 38, (unsigned long long)(__builtin_amdgcn_s_memtime() - tm));
+#endif
     }
-    __syncthreads();
+    lds_barrier();  // HBM stores of the helpers stay in flight
+    POTF2_LAP(tF)
     // ---- P(jb): rows of block bi below the diagonal block, P[r][c] = sum_q A[r][q] Dinv[c][q]
     for (int bi = jb + 1 + wave; bi < NB; bi += 4) {
       acc_t acc = acc_t{0, 0, 0, 0};
@@ -478,15 +538,54 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
 #pragma unroll
       for (int r = 0; r < 4; ++r) At[(j0 + P::drow(lane, r)) * LDP + bi * DB + l15] = acc[r];
     }
-    __syncthreads();
+    lds_barrier();
+    POTF2_LAP(tP)
     // ---- U(jb): block column jb + 1 with panel jb
     for (int bi = jb + 1 + wave; bi < NB; bi += 4) trailing_block(bi, jb + 1, jb);
-    __syncthreads();
+    lds_barrier();
+    POTF2_LAP(tU)
   }
   // ---- tail: row 7 of W and the last column
-  for (int j = wave; j < NB - 1; j += 4) inverse_block(NB - 1, j);
-  store_column(NB - 1, tid, 256);
+  for (int j = 0; j < NB - 1; ++j)
+    if (snake(j + 1, 4) == wave) inverse_block(NB - 1, j);   // offset 1: wave 0 comes out of the last factor block last
+  // L and the Dinv blocks of the image go to HBM once, here, by all four waves: the helper waves are the longer
+  // side of every phase above (measured), so nothing that can wait is done there.  The strictly upper 16x16
+  // blocks of the tile in HBM are never read by anybody and are left alone.
+  {
+    // 128 columns dealt to the four waves; per column the rows from the top of its diagonal block down (lanes
+    // along the rows, two trips); LDS reads of four columns are batched ahead of their stores
+#pragma unroll 1
+    for (int c0 = wave * 4; c0 < TS; c0 += 16) {
+      T v[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c = c0 + q, r = (c & ~(DB - 1)) + lane + 64 * h;
+          v[q][h] = (r < TS && r >= c) ? At[c * LDP + r] : T(0);
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c = c0 + q, r = (c & ~(DB - 1)) + lane + 64 * h;
+          if (r < TS) tile[(size_t)c * ld + r] = v[q][h];
+        }
+    }
+    for (int e = tid; e < NB * DB * DB; e += 256) Wk[wimg_blk(e >> 8, e >> 8) + (e & 255)] = -Dv[e];
+  }
   if (tid == 0 && *flag != 0 && p.info[b] == 0) p.info[b] = *flag;
+#ifdef CGP_ABLATION
+  if (CGP_DBG_ON(p, 1024) && tid == 0) {
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(p.dbgbuf);
+    atomicAdd(d + 32, (unsigned long long)tF);
+    atomicAdd(d + 33, (unsigned long long)tP);
+    atomicAdd(d + 34, (unsigned long long)tU);
+    atomicAdd(d + 35, (unsigned long long)(__builtin_amdgcn_s_memtime() - tm));
+    atomicAdd(d + 36, 1ull);
+  }
+#endif
+#undef POTF2_LAP
 }
 
 // --------------------------------------------------------------------------------------------------

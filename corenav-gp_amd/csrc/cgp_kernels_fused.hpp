@@ -649,7 +649,7 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
         for (int r = 0; r < 4; ++r) blk[P::drow(lane, r) * DB + l15] = acc[r];  // T_i,pj[r][c]
       }
     }
-    __syncthreads();
+    lds_barrier();
     // (b) and (b'): NB - 1 independent 16x16 products
     for (int t = wave; t < NB - 1; t += 4) {
       const bool below = t < NB - 1 - jb;
@@ -666,7 +666,7 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) blk[P::drow(lane, r) * DB + l15] = below ? acc[r] : -acc[r];
     }
-    __syncthreads();
+    lds_barrier();
     // (c) and (c')
     const int nb = NB - 1 - jb;
     const int nc = nb * (nb + 1) / 2;
@@ -709,7 +709,7 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) cblk[P::drow(lane, r) * DB + l15] = acc[r];
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (tid == 0 && bad != 0 && p.info[b] == 0) p.info[b] = bad;
   // strictly lower blocks of W -> the negated block image in HBM (Bk holds W_ij[r][c], the image [q = c][r])
@@ -831,16 +831,7 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
         }
       }
   }
-  // the strictly upper blocks of the tile in HBM are zero
-  for (int idx = tid; idx < 28 * DB * DB; idx += 256) {
-    const int blk = idx >> 8, e = idx & 255;
-    int i = 1, rem = blk;
-    while (rem >= i) {
-      rem -= i;
-      ++i;
-    }
-    tile[(size_t)(i * DB + (e >> 4)) * ld + rem * DB + (e & 15)] = T(0);
-  }
+  // (the strictly upper 16x16 blocks of the tile in HBM are never read by anybody and are left alone)
   __syncthreads();
   T *Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)kn * WIMG;
   diag_factor_packed<T>(p, smem, tile, ld, Wk, b, kn, tid);
@@ -1397,19 +1388,59 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
   store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
 }
 
+// k_trmm_sk: L(i,k) = S(i,k) W_k^T for the tiles of step k, on the latency schedule's critical path (every tile
+// of the next step needs its result), so: EIGHT waves per tile (16 rows each: half the MFMA chain of the
+// four-wave in-register product of k_panel), and the W image's LDS-DMA issued first, in flight while the S
+// tile is loaded into the accumulators.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void k_trmm_sk(FitArgs p, int k) {
-  using acc_t = typename Prec<T>::acc_t;
+__global__ __launch_bounds__(512) void k_trmm_sk(FitArgs p, int k) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
-  const int b = blockIdx.y;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
   const int rt = row_tile_of(blockIdx.x, k + 1, p.NT, p.rows_from_extra);
   T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
-  T *tile = Lw + (size_t)(k * TS) * p.ld + (size_t)rt * TS;
-  acc_t acc[NCB][2];
-  load_tile<T, false>(acc, tile, p.ld, threadIdx.x);
-  trmm_in_registers<T>(p, acc, smem, b, k, threadIdx.x);
-  store_tile<T>(acc, tile, p.ld, threadIdx.x);
+  const int ld = p.ld;
+  T *tile = Lw + (size_t)(k * TS) * ld + (size_t)rt * TS + wave * DB + l15;  // this lane's row
+  const T *__restrict__ Wk = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * WIMG;
+  {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    constexpr int PER = 1024 / (int)sizeof(T);
+    constexpr int NI = WIMG / PER / 8;
+    static_assert(WIMG % (8 * PER) == 0 || WIMG / PER == 36, "image rounds");
+#pragma unroll
+    for (int i = 0; i < (WIMG / PER + 7) / 8; ++i) {
+      const int blk = i * 8 + wave;
+      if (blk < WIMG / PER)
+        __builtin_amdgcn_global_load_lds((gbl_void *)(Wk + blk * PER + lane * (16 / (int)sizeof(T))), (lds_void *)(smem + blk * PER), 16, 0, 0);
+    }
+    (void)NI;
+  }
+  acc_t acc[NCB];  // acc[cb][r] = -S[row][cb*16 + drow(lane, r)]
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[cb][r] = tile[(size_t)(cb * DB + P::drow(lane, r)) * ld];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int cb = NCB - 1; cb >= 0; --cb) {
+    acc_t t0 = acc_t{0, 0, 0, 0};
+    const T *wrow = smem + (cb * (cb + 1) / 2) * DB * DB + l15;
+#pragma unroll
+    for (int qb = 0; qb <= cb; ++qb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t0 = P::mfma(wrow[qb * DB * DB + P::drow(lane, r) * DB], acc[qb][r], t0);
+    acc[cb] = t0;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[(size_t)(cb * DB + P::drow(lane, r)) * ld] = acc[cb][r];
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
       phase_a(0, nb, cs, ad);
     }
     for (int pi = 0; pi < npan; ++pi) {
-      __syncthreads();  // A(pi) and B(pi-1) are complete
+      lds_barrier();  // A(pi) and B(pi-1) are complete.  LDS only: within a tick no thread reads factor entries another
+                      // thread wrote (a panel's entries have one owner), so the sweep's HBM stores stay in flight
       const int p0 = pi * WPB;
       const double *csb = cs + (pi & 1) * 2 * WPB;
       if (wave == 0) {
