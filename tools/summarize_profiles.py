@@ -11,10 +11,13 @@ import sys
 
 tag, rnd = sys.argv[1], sys.argv[2]          # e.g. r1 r01
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 512   # fits per step of the profiled bench command
+N = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
+dtype = sys.argv[5] if len(sys.argv) > 5 else "f64"
+suffix = "" if dtype == "f64" else "_" + dtype
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-shutil.copy(os.path.join(src, f"{tag}_stats", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{rnd}_kernel_stats.csv"))
+shutil.copy(os.path.join(src, f"{tag}_stats", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{rnd}_kernel_stats{suffix}.csv"))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 dur = collections.defaultdict(float)
@@ -48,6 +51,6 @@ for k, v in agg.items():
     if "TCC_HIT_sum" in v:
         e["L2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
     out[k] = e
-out["_workload"] = {"batch": batch, "N": 2048, "dtype": "f64", "command": "python3 bench.py --no-cpu"}
-json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_summary.json"), "w"), indent=1)
+out["_workload"] = {"batch": batch, "N": N, "dtype": dtype, "command": "python3 bench.py --no-cpu --no-extra --steps 1 --warmup 1" + ("" if dtype == "f64" else " --config 3")}
+json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_summary{suffix}.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
