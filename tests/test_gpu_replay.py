@@ -39,3 +39,37 @@ def test_closed_loop_with_optimiser():
         assert -go.nll_and_grad(2, th, xtr, ytr[:, 0])[0] > -go.nll_and_grad(2, np.ones(4), xtr, ytr[:, 0])[0]
         em, es = go.slip_node_callback(t, s, th)
         assert np.max(np.abs(mean - em)) <= 1e-6 * np.max(np.abs(em))
+
+
+def test_replay_ensemble_two_ranks_match_one():
+    """BASELINE configs[4] stand-in across ranks: tools/replay_ensemble.py with two ranks (both on GPU 0, summaries
+    over gloo -- RCCL refuses two ranks on one device) gathers, in global trajectory order, exactly the
+    per-trajectory summaries one rank computes for the whole ensemble: the block partition and the seeds
+    do not depend on the world size."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "replay_ensemble.py")
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+
+    def line(out):
+        return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    one = subprocess.run([sys.executable, tool, "--traj", "6", "--ticks", "400"], capture_output=True, text=True,
+                         timeout=600, env=base)
+    assert one.returncode == 0, one.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   CGP_BENCH_SAME_DEVICE="1", CGP_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, tool, "--traj", "6", "--ticks", "400"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:] + outs[1][1][-2000:]
+    a, b = line(one.stdout), line(outs[0][0])
+    assert b["n_gpus"] == 2 and a["n_gpus"] == 1
+    # (6 windows fitted in one call take the throughput schedule, 3 per rank the latency schedule: same numbers to
+    # rounding, so the stop times are compared to 1e-9 s, the counts exactly)
+    assert np.allclose(np.array(a["per_trajectory"]), np.array(b["per_trajectory"]), rtol=0, atol=1e-9)
+    assert a["windows"] == b["windows"] >= 6 and a["stops"] == b["stops"]
