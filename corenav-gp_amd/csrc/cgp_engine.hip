@@ -272,7 +272,9 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   const int tile_lds = potf2_lds_bytes<T>();
   int G = std::max(1, std::min(std::min(c->nstreams, (int)cgp_ctx::kMaxStreams), batch));
   if (c->prof || !in_rows) G = 1;  // per-kernel timing wants isolated launches
-  const bool latency = !sw.no_latency && batch <= LAT_FITS && a.NT >= 3;
+  // latency schedule: a handful of fits, windows long enough for splitting to pay and short enough for the
+  // diagonal tile's pre-update images (N <= 2432); anything else takes the throughput schedule
+  const bool latency = !sw.no_latency && batch <= LAT_FITS && a.NT >= 3 && lat_images(a.NT - 1) <= LAT_IMG_MAX;
   if (latency) G = 1;
   std::vector<FitArgs> ga(G);
   std::vector<int> gb(G);
@@ -355,10 +357,6 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // the panel tiles of a step in one launch, inner dimension split over up to SK_MAX workgroups.
   if (latency) {
     const bool split_trmm = !sw.sk_fused_trmm;
-    if (in_rows && lat_images(a.NT - 1) > LAT_IMG_MAX) {
-      c->err = "window too long for the latency schedule's diagonal images";
-      return CGP_ECAPACITY;
-    }
     SplitArgs q{c->dpart, c->dticket, c->sk_slots, 1, in_rows ? 1 : 0, c->dwready, c->dlatimg, split_trmm ? 0 : 1};
     for (int k = 0; k < a.NT; ++k) {
       const int tiles = (in_rows ? a.NT - k - 1 : 0) + a.ET;

@@ -312,6 +312,17 @@ def test_throughput_schedule_matches_oracle(engine, dtype_name, N):
     assert relmax(m2, mean[:2]) < tol and np.max(np.abs(l2 - logml[:2]) / np.abs(logml[:2])) < tol
 
 
+def test_window_longer_than_the_latency_schedule_covers(engine):
+    """The latency schedule's look-ahead images cover windows up to N = 2432; a single longer window (N = 2500,
+    20 block steps) must fall through to the throughput schedule, not fail -- same parity bar."""
+    rng = np.random.default_rng(2500)
+    N, d, M = 2500, 2, 40
+    X, Xs = rng.normal(size=(N, d)), rng.normal(size=(M, d))
+    theta = np.array([0.8, 0.9, 1.4, 0.05])
+    y = 0.1 * np.sin(np.arange(N) / 7.0) + 0.03 * rng.normal(size=N)
+    check_fit_predict(engine, 1, theta, X, y, Xs, engine.F64, TOL64)
+
+
 def test_latency_schedule_is_deterministic(engine):
     """k_tile_sk adds the split-K partial tiles in range order whichever workgroup arrives last: repeated
     calls are bitwise identical (tools/stress_latency.py is the long version)."""
