@@ -372,7 +372,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       L[0].end();
       if (split_trmm) {
         L[0].begin(2, trsm_flops(a.N, a.M, k, in_rows, batch));
-        hipLaunchKernelGGL(k_trmm_sk<T>, dim3(tiles, batch), dim3(512), upd_lds, s, ga[0], k);
+        hipLaunchKernelGGL(k_trmm_sk<T>, dim3(tiles * TRMM_SPLIT, batch), dim3(64 * TRMM_WAVES), upd_lds, s, ga[0], k);
         L[0].end();
       }
     }

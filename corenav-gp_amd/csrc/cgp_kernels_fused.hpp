@@ -1389,35 +1389,41 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
 }
 
 // k_trmm_sk: L(i,k) = S(i,k) W_k^T for the tiles of step k, on the latency schedule's critical path (every tile
-// of the next step needs its result), so: EIGHT waves per tile (16 rows each: half the MFMA chain of the
-// four-wave in-register product of k_panel), and the W image's LDS-DMA issued first, in flight while the S
-// tile is loaded into the accumulators.
+// of the next step needs its result), so a tile is cut into TRMM_SPLIT row slabs, one workgroup (one CU's MFMA
+// pipe) each, 16 rows per wave, and the W image's LDS-DMA is issued first, in flight while the S rows are
+// loaded into the accumulators.  In-kernel clocks of the one-workgroup form: loads 6.7 k, product 13.4 k (the
+// tile's 1152 MFMAs on one CU), stores 6.1 k cycles.
+#ifndef CGP_TRMM_SPLIT
+#define CGP_TRMM_SPLIT 2
+#endif
+constexpr int TRMM_SPLIT = CGP_TRMM_SPLIT;
+constexpr int TRMM_WAVES = TS / DB / TRMM_SPLIT;  // 4 waves of 16 rows per workgroup
 template <typename T>
-__global__ __launch_bounds__(512) void k_trmm_sk(FitArgs p, int k) {
+__global__ __launch_bounds__(64 * TRMM_WAVES) void k_trmm_sk(FitArgs p, int k) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, l15 = lane & 15;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
-  const int rt = row_tile_of(blockIdx.x, k + 1, p.NT, p.rows_from_extra);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slab = blockIdx.x % TRMM_SPLIT;
+  const int rt = row_tile_of(blockIdx.x / TRMM_SPLIT, k + 1, p.NT, p.rows_from_extra);
   T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
   const int ld = p.ld;
-  T *tile = Lw + (size_t)(k * TS) * ld + (size_t)rt * TS + wave * DB + l15;  // this lane's row
+  T *tile = Lw + (size_t)(k * TS) * ld + (size_t)rt * TS + (slab * TRMM_WAVES + wave) * DB + l15;  // this lane's row
   const T *__restrict__ Wk = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * WIMG;
+  PhaseClock pc;  // measurement build: slots 44.. = loads landed, product, stores issued; 47 = count
+  pc.start(p, tid);
   {
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void gbl_void;
     constexpr int PER = 1024 / (int)sizeof(T);
-    constexpr int NI = WIMG / PER / 8;
-    static_assert(WIMG % (8 * PER) == 0 || WIMG / PER == 36, "image rounds");
 #pragma unroll
-    for (int i = 0; i < (WIMG / PER + 7) / 8; ++i) {
-      const int blk = i * 8 + wave;
+    for (int i = 0; i < (WIMG / PER + TRMM_WAVES - 1) / TRMM_WAVES; ++i) {
+      const int blk = i * TRMM_WAVES + wave;
       if (blk < WIMG / PER)
         __builtin_amdgcn_global_load_lds((gbl_void *)(Wk + blk * PER + lane * (16 / (int)sizeof(T))), (lds_void *)(smem + blk * PER), 16, 0, 0);
     }
-    (void)NI;
   }
   acc_t acc[NCB];  // acc[cb][r] = -S[row][cb*16 + drow(lane, r)]
 #pragma unroll
@@ -1426,6 +1432,7 @@ __global__ __launch_bounds__(512) void k_trmm_sk(FitArgs p, int k) {
     for (int r = 0; r < 4; ++r) acc[cb][r] = tile[(size_t)(cb * DB + P::drow(lane, r)) * ld];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  pc.lap(p, 44);
 #pragma unroll
   for (int cb = NCB - 1; cb >= 0; --cb) {
     acc_t t0 = acc_t{0, 0, 0, 0};
@@ -1437,10 +1444,13 @@ __global__ __launch_bounds__(512) void k_trmm_sk(FitArgs p, int k) {
     acc[cb] = t0;
     __builtin_amdgcn_sched_barrier(0);
   }
+  pc.lap(p, 45);
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) tile[(size_t)(cb * DB + P::drow(lane, r)) * ld] = acc[cb][r];
+  pc.lap(p, 46);
+  pc.count(p, 47);
 }
 
 // --------------------------------------------------------------------------------------------------

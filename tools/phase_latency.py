@@ -26,4 +26,5 @@ extra = {"panel_update_range0": avg(16, 22), "panel_update_other": avg(17, 23), 
          "counts": [int(o[c]) for c in (22, 23, 21, 25)]}
 print(json.dumps({"panel": extra}))
 print(json.dumps({"potf2_tile_per_call": {nm: float(o[32 + i]) / max(int(o[36]), 1) for i, nm in enumerate(["F_total", "P_total", "U_total", "tail"])}, "factor_wave0_total": float(o[37]) / max(int(o[36]), 1), "helpers_wave1_total": float(o[38]) / max(int(o[36]), 1), "wave1_inverse": float(o[40]) / max(int(o[36]), 1), "wave1_trailing": float(o[41]) / max(int(o[36]), 1)}))
+print(json.dumps({"trmm_sk_per_wg": {nm: float(o[44 + i]) / max(int(o[47]), 1) for i, nm in enumerate(["loads_landed", "product", "stores_issued"])}}))
 print(json.dumps({"diag_wgs": n, "ticks_per_step": {nm: float(o[8 + i]) / n for i, nm in enumerate(names)}, "latency_ms": W.single_fit_latency_ms()}))
