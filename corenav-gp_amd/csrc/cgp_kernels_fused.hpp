@@ -1208,9 +1208,9 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
   if (diag) {
     // ---- the diagonal tile is the per-step critical path (its factorisation is serial), so its update never
     // goes through the split-K slabs: the block columns < k - 1 were pre-applied during the PREVIOUS step's
-    // launch (workgroups z >= 1 below, hidden behind that step's factorisation) and left as register images;
-    // this workgroup sums them in fixed order, adds block column k - 1 (final since the trmm launch in
-    // between) on the triangular loop and factors.  Same arithmetic order whatever shares the launch.
+    // launch (workgroups z >= 1 below, hidden behind that step's factorisation) and left as ONE register image
+    // (their fixed-order sum); this workgroup adds block column k - 1 (final since the trmm launch in between)
+    // on the triangular loop and factors.  Same arithmetic order whatever shares the launch.
     T *imgs = reinterpret_cast<T *>(q.diag_img) + (size_t)b * 2 * LAT_IMG_MAX * DPART;
     if (sp >= 1) {
       const int kn = k + 1, s = sp - 1;  // pre-update of the NEXT diagonal tile, image s
@@ -1228,7 +1228,40 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
         for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = acc_t{0, 0, 0, 0};
       }
       mfma_syrk_tri_loop<T>(acc, gR, (size_t)ld, nchunk, smem, tid);
-      acc_image<T, true, true>(acc, imgs + ((size_t)(kn & 1) * LAT_IMG_MAX + s) * DPART, tid);
+      T *im = imgs + (size_t)(kn & 1) * LAT_IMG_MAX * DPART;
+      acc_image<T, true, true>(acc, im + (size_t)s * DPART, tid);
+      const int nimg_next = lat_images(kn);
+      if (nimg_next > 1) {
+        // the last pre-update workgroup to arrive folds the images into image 0 in fixed order 0, 1, 2, ... (still
+        // hidden behind this step's factorisation), so the next step's diagonal workgroup loads ONE image
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          int *tk = q.ticket + b * q.slots;  // slot 0 = the diagonal tile, which no longer uses the slab tickets
+          const int old = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_last = old == nimg_next - 1;
+          if (s_last) {
+            __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+        }
+        __syncthreads();
+        if (s_last) {
+          acc_image<T, true, false>(acc, im, tid);
+          for (int s2 = 1; s2 < nimg_next; ++s2) {
+            acc_t add[NCB][2];
+            acc_image<T, true, false>(add, im + (size_t)s2 * DPART, tid);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                if (cb <= (j ? NCB - 1 - wave : wave)) acc[cb][j] += add[cb][j];
+          }
+          acc_image<T, true, true>(acc, im, tid);
+        }
+      }
       pc.lap(p, 24);  // a pre-update workgroup, whole life
       pc.count(p, 25);
       return;
@@ -1243,17 +1276,7 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
       if (sizeof(T) == 8 && nchunk > 1) stage_chunk_tri<T>(gR, (size_t)ld, 1, smem + tri_buf(1), tid);
       if (nimg == 0) gram_apply<T, true>(p, acc, smem + CH2, b, k, k, tid, gp);
       else {
-        T *im = imgs + (size_t)(k & 1) * LAT_IMG_MAX * DPART;
-        acc_image<T, true, false>(acc, im, tid);
-        for (int s = 1; s < nimg; ++s) {  // fixed order
-          acc_t add[NCB][2];
-          acc_image<T, true, false>(add, im + (size_t)s * DPART, tid);
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              if (cb <= (j ? NCB - 1 - wave : wave)) acc[cb][j] += add[cb][j];
-        }
+        acc_image<T, true, false>(acc, imgs + (size_t)(k & 1) * LAT_IMG_MAX * DPART, tid);  // already the fixed-order sum
       }
     }
     mfma_syrk_tri_loop<T>(acc, gR, (size_t)ld, nchunk, smem, tid);
