@@ -445,6 +445,32 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
     const int q = idx / nw, r = idx % nw;
     return (q & 1) ? nw - 1 - r : r;
   };
+  // Column blocks [jb0, jb1) of L (from the top of each diagonal block down; zero above the diagonal inside it) and
+  // the images of their Dinv blocks -> HBM, by waves w0 .. w0 + nw - 1: one column per wave-instruction, two rows
+  // per lane (16-byte accesses), the LDS reads of eight columns batched ahead of their stores.
+  auto store_blocks = [&](int jb0, int jb1, int w0, int nw) {
+    using vec2 = T __attribute__((ext_vector_type(2)));
+    const int wl = wave - w0;
+#pragma unroll 1
+    for (int c0 = jb0 * DB + wl * 8; c0 < jb1 * DB; c0 += nw * 8) {
+      vec2 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + q, r = 2 * lane;   // rows r, r + 1 of column c: one 16-byte LDS read, one 16-byte store
+        vec2 x = *reinterpret_cast<const vec2 *>(At + c * LDP + r);
+        x[0] = r >= c ? x[0] : T(0);
+        x[1] = r + 1 >= c ? x[1] : T(0);
+        v[q] = x;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + q, r = 2 * lane;
+        if (r + 1 >= (c & ~(DB - 1))) *reinterpret_cast<vec2 *>(tile + (size_t)c * ld + r) = v[q];
+      }
+    }
+    for (int e = jb0 * DB * DB + wl * 64 + lane; e < jb1 * DB * DB; e += nw * 64) Wk[wimg_blk(e >> 8, e >> 8) + (e & 255)] = -Dv[e];
+  };
+
 #ifdef CGP_ABLATION
   long long tF = 0, tP = 0, tU = 0, tm = __builtin_amdgcn_s_memtime();
 #define POTF2_LAP(x) { const long long nn = __builtin_amdgcn_s_memtime(); x += nn - tm; tm = nn; }
@@ -548,32 +574,11 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
   // ---- tail: row 7 of W and the last column
   for (int j = 0; j < NB - 1; ++j)
     if (snake(j + 1, 4) == wave) inverse_block(NB - 1, j);   // offset 1: wave 0 comes out of the last factor block last
-  // L and the Dinv blocks of the image go to HBM once, here, by all four waves: the helper waves are the longer
-  // side of every phase above (measured), so nothing that can wait is done there.  The strictly upper 16x16
-  // blocks of the tile in HBM are never read by anybody and are left alone.
-  {
-    // 128 columns dealt to the four waves; per column the rows from the top of its diagonal block down (lanes
-    // along the rows, two trips); LDS reads of four columns are batched ahead of their stores
-#pragma unroll 1
-    for (int c0 = wave * 4; c0 < TS; c0 += 16) {
-      T v[4][2];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int c = c0 + q, r = (c & ~(DB - 1)) + lane + 64 * h;
-          v[q][h] = (r < TS && r >= c) ? At[c * LDP + r] : T(0);
-        }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int c = c0 + q, r = (c & ~(DB - 1)) + lane + 64 * h;
-          if (r < TS) tile[(size_t)c * ld + r] = v[q][h];
-        }
-    }
-    for (int e = tid; e < NB * DB * DB; e += 256) Wk[wimg_blk(e >> 8, e >> 8) + (e & 255)] = -Dv[e];
-  }
+  // L and the Dinv blocks of the image go to HBM once, here, by all four waves (16-byte stores: the tail is
+  // store-issue-bound).  Spreading them over the last factor phases, where the helper waves have few trailing
+  // blocks left, was measured: the phases grew by more than the tail shrank.  The strictly upper 16x16 blocks of
+  // the tile in HBM are never read by anybody and are left alone.
+  store_blocks(0, NB, 0, 4);
   if (tid == 0 && *flag != 0 && p.info[b] == 0) p.info[b] = *flag;
 #ifdef CGP_ABLATION
   if (CGP_DBG_ON(p, 1024) && tid == 0) {
