@@ -62,6 +62,7 @@ struct cgp_ctx {
   double *dgpart = nullptr;
   void *dpart = nullptr;   // latency schedule: partial tiles [LAT_FITS][slots][SK_MAX][128*128]
   int *dticket = nullptr;  //                   arrival tickets [LAT_FITS][slots]
+  int lat_cap = 0;         //                   fits the latency slabs are sized for: min(LAT_FITS, max_batch)
   int *dwready = nullptr;  //                   published block steps [LAT_FITS]
   void *dlatimg = nullptr;  //                  pre-updated diagonal tiles [LAT_FITS][2][LAT_IMG_MAX][DPART]
   double *dmacc = nullptr;  // [max_batch][2][max_m] running predictive sums (throughput schedule, fp64)
@@ -138,7 +139,16 @@ struct Launcher {
   }
 };
 
-constexpr int LAT_FITS = 4;  // batches up to this size take the latency schedule
+constexpr int LAT_FITS = 24;                     // batches up to this size take the latency schedule (measured
+                                                 // crossover, tools/lat_crossover.sh: 24 fits in fp64 and fp32)
+constexpr int LAT_FITS_ALLOC = kAbBuild ? 64 : LAT_FITS;  // slabs are sized for this many fits
+inline int lat_fits() {                           // ablation build: CGP_LAT_FITS moves the crossover (measurement)
+  if constexpr (kAbBuild) {
+    const char *e = getenv("CGP_LAT_FITS");
+    if (e) return std::max(0, std::min(atoi(e), LAT_FITS_ALLOC));
+  }
+  return LAT_FITS;
+}
 
 inline size_t alpha_lds_bytes(int NT) { return (size_t)(NT * TS + TS) * sizeof(double); }
 template <typename T> constexpr int upd_lds_bytes() { return 4 * KT * LDST * (int)sizeof(T); }
@@ -274,7 +284,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   if (c->prof || !in_rows) G = 1;  // per-kernel timing wants isolated launches
   // latency schedule: a handful of fits, windows long enough for splitting to pay and short enough for the
   // diagonal tile's pre-update images (N <= 2432); anything else takes the throughput schedule
-  const bool latency = !sw.no_latency && batch <= LAT_FITS && a.NT >= 3 && lat_images(a.NT - 1) <= LAT_IMG_MAX;
+  const bool latency = !sw.no_latency && batch <= std::min(lat_fits(), c->lat_cap) && a.NT >= 3 && lat_images(a.NT - 1) <= LAT_IMG_MAX;
   if (latency) G = 1;
   std::vector<FitArgs> ga(G);
   std::vector<int> gb(G);
@@ -625,11 +635,12 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc((void **)&c->djitter, B * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dgpart, B * c->NTmax * (c->NTmax + 1) / 2 * GRAD_N * sizeof(double)) == hipSuccess;
   c->sk_slots = c->NTmax + c->ETmax + 1;
-  ok = ok && hipMalloc(&c->dpart, (size_t)LAT_FITS * c->sk_slots * SK_MAX * TS * TS * c->esz) == hipSuccess;
-  ok = ok && hipMalloc((void **)&c->dticket, sizeof(int) * LAT_FITS * c->sk_slots) == hipSuccess;
-  ok = ok && hipMemset(c->dticket, 0, sizeof(int) * LAT_FITS * c->sk_slots) == hipSuccess;
-  ok = ok && hipMalloc((void **)&c->dwready, sizeof(int) * LAT_FITS) == hipSuccess;
-  ok = ok && hipMalloc(&c->dlatimg, (size_t)LAT_FITS * 2 * LAT_IMG_MAX * DPART * c->esz) == hipSuccess;
+  c->lat_cap = std::min(LAT_FITS_ALLOC, max_batch);
+  ok = ok && hipMalloc(&c->dpart, (size_t)c->lat_cap * c->sk_slots * SK_MAX * TS * TS * c->esz) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->dticket, sizeof(int) * c->lat_cap * c->sk_slots) == hipSuccess;
+  ok = ok && hipMemset(c->dticket, 0, sizeof(int) * c->lat_cap * c->sk_slots) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->dwready, sizeof(int) * c->lat_cap) == hipSuccess;
+  ok = ok && hipMalloc(&c->dlatimg, (size_t)c->lat_cap * 2 * LAT_IMG_MAX * DPART * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dmacc, sizeof(double) * 2 * B * std::max(c->max_m, 1)) == hipSuccess;
   ok = ok && hipMalloc(&c->ddiagimg, B * 2 * DPART * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->ddbg, DBG_SLOTS * sizeof(long long)) == hipSuccess;

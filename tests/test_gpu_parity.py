@@ -293,23 +293,46 @@ def test_multi_tile_single_fit(engine):
 
 @pytest.mark.parametrize("dtype_name,N", [("F64", 700), ("F32", 300)])
 def test_throughput_schedule_matches_oracle(engine, dtype_name, N):
-    """Batches above 4 fits take the throughput schedule (k_diag_lean + k_panel, what bench.py times);
-    smaller ones the latency schedule (k_tile_sk / k_trmm_sk).  Same parity bar for both, and a fit's
-    result must not depend on which other fits share the batch (bitwise, within a schedule)."""
+    """Batches above 24 fits take the throughput schedule (k_diag_lean + k_panel, what bench.py times);
+    smaller ones the latency schedule (k_tile_sk / k_trmm_sk; crossover measured with tools/lat_crossover.sh).
+    Same parity bar for both, and a fit's result must not depend on which other fits share the batch (bitwise,
+    within a schedule)."""
     dtype, tol = getattr(engine, dtype_name), (TOL64 if dtype_name == "F64" else TOL32)
-    kid, X, y, Xs, th, _ = synth.config(2, batch=6, N=N)
-    ctx = engine.Context(max_n=N, max_m=Xs.shape[1], max_d=X.shape[2], max_batch=6, dtype=dtype)
+    B = 27
+    kid, X, y, Xs, th, _ = synth.config(2, batch=B, N=N)
+    ctx = engine.Context(max_n=N, max_m=Xs.shape[1], max_d=X.shape[2], max_batch=B, dtype=dtype)
     rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
     assert rc == 0 and not info.any()
-    for b in range(6):
+    for b in (0, 1, 13, B - 1):
         f = go.fit(kid, th[b], X[b], y[b])
         omu, ovar = go.predict(f, Xs[b])
         assert relmax(mean[b], omu) < tol and releach(var[b], ovar) < tol
         assert abs(logml[b] - f.logml) <= tol * abs(f.logml)
-    rc, m5, v5, l5, _ = ctx.fit_predict_batch(X[1:], y[1:], Xs[1:], th[1:], kid)       # still throughput (5 fits)
+    rc, m5, v5, l5, _ = ctx.fit_predict_batch(X[1:], y[1:], Xs[1:], th[1:], kid)       # still throughput (26 fits)
     assert np.array_equal(m5, mean[1:]) and np.array_equal(v5, var[1:]) and np.array_equal(l5, logml[1:])
     rc, m2, v2, l2, _ = ctx.fit_predict_batch(X[:2], y[:2], Xs[:2], th[:2], kid)       # latency schedule
     assert relmax(m2, mean[:2]) < tol and np.max(np.abs(l2 - logml[:2]) / np.abs(logml[:2])) < tol
+
+
+@pytest.mark.parametrize("dtype_name,N", [("F64", 700), ("F32", 520)])
+def test_latency_schedule_mid_batch(engine, dtype_name, N):
+    """The latency schedule at the top of its range (24 fits per call): oracle parity, and a fit's result does not
+    depend on its companions or on its slot in the call (bitwise)."""
+    dtype, tol = getattr(engine, dtype_name), (TOL64 if dtype_name == "F64" else TOL32)
+    B = 24
+    kid, X, y, Xs, th, _ = synth.config(2, batch=B, N=N)
+    ctx = engine.Context(max_n=N, max_m=Xs.shape[1], max_d=X.shape[2], max_batch=B, dtype=dtype)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not info.any()
+    for b in (0, 7, B - 1):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        assert relmax(mean[b], omu) < tol and releach(var[b], ovar) < tol
+        assert abs(logml[b] - f.logml) <= tol * abs(f.logml)
+    sel = [23, 5, 11, 0, 17]
+    rc, ms, vs, ls, _ = ctx.fit_predict_batch(X[sel], y[sel], Xs[sel], th[sel], kid)
+    assert rc == 0
+    assert np.array_equal(ms, mean[sel]) and np.array_equal(vs, var[sel]) and np.array_equal(ls, logml[sel])
 
 
 def test_window_longer_than_the_latency_schedule_covers(engine):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stress test of the split-K latency schedule: the ticketed reduction must give bitwise identical
-results on every run (partials are added in range order), for 1..4 fits per call, fp64 and fp32."""
+results on every run (partials are added in range order), for 1..24 fits per call, fp64 and fp32."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -9,7 +9,7 @@ from corenav_gp_amd import engine, synth
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 bad = 0
 for cfg, dtype, N in ((2, engine.F64, 2048), (2, engine.F64, 1000), (3, engine.F32, 1024)):
-    for B in (1, 3, 4):
+    for B in (1, 3, 4, 13, 24):
         kid, X, y, Xs, th, _ = synth.config(cfg, batch=B, N=N)
         ctx = engine.Context(max_n=N, max_m=Xs.shape[1], max_d=X.shape[2], max_batch=B, dtype=dtype)
         ref = ctx.fit_predict_batch(X, y, Xs, th, kid)
