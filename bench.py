@@ -270,8 +270,22 @@ class Workload:
         are recorded around every launch on the stream it is launched on (cgp_profile_enable) in 2 EXTRA
         steps after the timed region: per-launch events serialise the launches, so the timed steps carry
         none and the two are labelled apart."""
+        # The profiled steps must run as the timed ones do: clocks up (whatever ran since the timed region --
+        # single-fit launches, the gather -- lets the part idle down, and a short step is over before it is back:
+        # measured 0.74 ms per fp32 launch cold against 0.62 warm = the in-kernel span, tools/launch_spans.py), and
+        # the event pool created beforehand.
         self.ctx.profile_enable(True)
-        for _ in range(2):
+        self.step()
+        self.torch.cuda.synchronize()
+        self.ctx.profile_read()
+        self.ctx.profile_enable(False)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.1:
+            self.step()
+            self.torch.cuda.synchronize()
+        self.ctx.profile_enable(True)
+        nprof = 2
+        for _ in range(nprof):
             self.step()
         self.torch.cuda.synchronize()
         prof = self.ctx.profile_read()
@@ -282,11 +296,11 @@ class Workload:
         rf = {"bound": "mfma", "kernel": "k_panel (syrk/gemm trailing update + fused Gram + in-register trmm)",
               "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
               "traffic": traffic, "traffic_source": tsrc,
-              "from": "HIP events around every k_panel launch, 2 extra profiled steps after the timed region "
-                      "(not the timed steps: per-launch events serialise the launches)",
+              "from": "HIP events around every k_panel launch, 2 extra profiled steps after the timed region and "
+                      "100 ms of untimed steps (not the timed steps: per-launch events serialise the launches)",
               "avg_launch_ms": upd["ms"] / max(upd["launches"], 1), "launches": upd["launches"],
               "algorithmic_flops_per_launch": upd["flops"] / max(upd["launches"], 1)}
-        return rf, {k: v["ms"] / 2 for k, v in prof.items()}
+        return rf, {k: v["ms"] / nprof for k, v in prof.items()}
 
 
 def pmc_traffic(B, N, dts):

@@ -12,11 +12,13 @@
 #include "slip_recorder.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace cgp;
@@ -88,6 +90,7 @@ struct cgp_ctx {
   double fjitter = 0.0;
   // profiling
   bool prof = false;
+  int prof_step = -1;  // >= 0: only the update launch of this block step is bracketed (cgp_profile_enable(2 + k))
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> pool;
   double prof_ms[CGP_PROF_KERNELS] = {0}, prof_flops[CGP_PROF_KERNELS] = {0};
@@ -125,8 +128,9 @@ struct Launcher {
   cgp_ctx *c;
   hipStream_t s;
   int pending = -1;
-  void begin(int kernel, double flops) {
+  void begin(int kernel, double flops, int step = -1) {
     if (!c->prof) return;
+    if (c->prof_step >= 0 && !(kernel == 0 && step == c->prof_step)) return;  // one update launch per schedule
     ProfRec r{kernel, get_event(c), get_event(c), flops};
     (void)hipEventRecord(r.a, s);
     c->recs.push_back(r);
@@ -375,7 +379,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       // depend on how many fits share the call (the partial sums are added in range order)
       const int sk = std::max(1, std::min(SK_MAX, k));
       q.sk = sk;
-      L[0].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, batch) + (in_rows ? diag_flops(a.N, a.d, k, batch) : 0.0));
+      L[0].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, batch) + (in_rows ? diag_flops(a.N, a.d, k, batch) : 0.0), k);
       // z also carries the pre-update workgroups of the NEXT diagonal tile (1 + images of tile k + 1)
       const int gz = in_rows ? std::max(sk, 1 + (k + 1 < a.NT ? lat_images(k + 1) : 0)) : sk;
       hipLaunchKernelGGL(k_tile_sk<T>, dim3(nslots, batch, gz), dim3(256), in_rows ? tile_lds : upd_lds, s, ga[0], q, k);
@@ -416,7 +420,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
         L[g].end();
       }
       if (split_diag) {
-        L[g].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, gb[g]));
+        L[g].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, gb[g]), k);
         hipLaunchKernelGGL((k_panel<T, false>), dim3(gx_t, gb[g]), dim3(256), panel_lds, gs[g], ga[g], k);
         L[g].end();
         continue;
@@ -426,7 +430,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       ak.diag_slots = (hasA ? 1 : 0) | (hasB ? 2 : 0);
       ak.diag_stride = sizeof(T) == 8 ? 2 : 4;  // workgroups per CU of k_panel<T, true> (LDS / VGPR bound)
       const int gx = gx_t + (hasB ? 1 : 0);  // gx_t already counts row tile k + 1 (kind A)
-      L[g].begin(0, panel_flops(a.N, a.M, a.d, k, true, gb[g]) + (hasA ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0));
+      L[g].begin(0, panel_flops(a.N, a.M, a.d, k, true, gb[g]) + (hasA ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0), k);
       if constexpr (kFusedBuilt)
         hipLaunchKernelGGL((k_panel<T, true>), dim3(gx, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ak, k);
       L[g].end();
@@ -722,6 +726,7 @@ int cgp_set_streams(cgp_ctx *c, int n) {
 int cgp_profile_enable(cgp_ctx *c, int on) {
   if (!c) return CGP_EINVAL;
   c->prof = on != 0;
+  c->prof_step = on >= 2 ? on - 2 : -1;
   return CGP_OK;
 }
 
@@ -785,6 +790,15 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
   HIP_TRY(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
   const size_t esz = c->esz;
+  const bool trace = kAbBuild && getenv("CGP_TRACE_E2E");
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t_start = now(), t_last = t_start;
+  auto lap = [&](const char *what) {
+    if (!trace) return;
+    auto t = now();
+    fprintf(stderr, "[e2e] %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   // Host side of the boundary (gp_slip_node.py:19-25 "list -> (n, 1) fp64"): the caller's row-major fp64
   // arrays go through ONE pinned staging block and ONE H2D DMA; the (n, d) -> SoA [d][n] transposition
   // and the fp64 -> device dtype conversion run on the device (k_pack_soa), not on a host core.
@@ -796,14 +810,44 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
       !grow_device(c->draw, c->draw_cap, in_bytes))
     return CGP_ENOMEM;
   double *hin = static_cast<double *>(c->pin_in);
-  memcpy(hin, X, nX * sizeof(double));
-  memcpy(hin + nX, y, ny * sizeof(double));
-  if (nXs) memcpy(hin + nX + ny, Xs, nXs * sizeof(double));
   double *hth = hin + nX + ny + nXs;
   for (size_t b = 0; b < B; ++b)
     for (int q = 0; q < CGP_MAX_THETA; ++q) hth[b * CGP_MAX_THETA + q] = q < nth ? theta[b * theta_stride + q] : 0.0;
   const double *draw = static_cast<const double *>(c->draw);
-  HIP_TRY(c, hipMemcpyAsync(c->draw, hin, in_bytes, hipMemcpyHostToDevice, s));
+  // Staging copy (pageable -> pinned) is the longest host step of a large call (66 MB for the headline batch:
+  // 6.6 ms on one core against 1.3 ms of DMA): ranges of fits are copied by up to 4 threads and each range's
+  // DMA is queued as soon as it is staged, so the copy engine works while the later ranges are still copied.
+  const int nthr = in_bytes > (4u << 20) ? (int)std::min<size_t>({4, B, std::max(1u, std::thread::hardware_concurrency())}) : 1;
+  auto stage = [&](size_t b0, size_t b1) {
+    memcpy(hin + b0 * N * d, X + b0 * N * d, (b1 - b0) * N * d * sizeof(double));
+    memcpy(hin + nX + b0 * N, y + b0 * N, (b1 - b0) * N * sizeof(double));
+    if (nXs) memcpy(hin + nX + ny + b0 * M * d, Xs + b0 * (size_t)M * d, (b1 - b0) * (size_t)M * d * sizeof(double));
+  };
+  auto dma = [&](size_t b0, size_t b1) -> hipError_t {
+    char *dd = static_cast<char *>(c->draw);
+    auto one = [&](size_t off, size_t cnt) {
+      return cnt ? hipMemcpyAsync(dd + off * sizeof(double), hin + off, cnt * sizeof(double), hipMemcpyHostToDevice, s) : hipSuccess;
+    };
+    hipError_t e = one(b0 * N * d, (b1 - b0) * N * d);
+    if (e == hipSuccess) e = one(nX + b0 * N, (b1 - b0) * N);
+    if (e == hipSuccess) e = one(nX + ny + b0 * M * d, (b1 - b0) * (size_t)M * d);
+    return e;
+  };
+  {
+    std::vector<std::thread> th;
+    auto lo = [&](int w) { return B * w / nthr; };
+    for (int w = 1; w < nthr; ++w) th.emplace_back(stage, lo(w), lo(w + 1));
+    stage(0, lo(1));
+    hipError_t e = dma(0, lo(1));
+    for (int w = 1; w < nthr; ++w) {
+      th[w - 1].join();
+      if (e == hipSuccess) e = dma(lo(w), lo(w + 1));
+    }
+    HIP_TRY(c, e);
+  }
+  lap("stage + queue DMA");
+  HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(c->draw) + (nX + ny + nXs) * sizeof(double), hth, nTh * sizeof(double),
+                            hipMemcpyHostToDevice, s));
   HIP_TRY(c, hipMemcpyAsync(c->dtheta, draw + nX + ny + nXs, nTh * sizeof(double), hipMemcpyDeviceToDevice, s));
   auto pack = [&](const double *src, void *dst, int n, int dd) {
     const dim3 grid(std::min(64, cdiv(n * dd, 256)), batch);
@@ -820,8 +864,10 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
   char *hout = static_cast<char *>(c->pin_out);
   double *hl = reinterpret_cast<double *>(hout + out_elems * esz);
   int *hinfo = reinterpret_cast<int *>(hl + B);
+  lap("queue schedule");
   HIP_TRY(c, hipMemcpyAsync(hinfo, c->dinfo, sizeof(int) * batch, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  lap("device done (info)");
   // GPy jitchol policy for the fits that failed: jitter = mean(diag) * 1e-6 * 10^k, k = 0..4,
   // re-submitted one fit at a time (rare path) into the same device slots.
   std::vector<double> hjit(batch, 0.0);
@@ -848,6 +894,7 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
   }
   HIP_TRY(c, hipMemcpyAsync(hl, c->dlogml, sizeof(double) * batch, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  lap("D2H");
   if (M > 0) {
     if (c->dtype == CGP_F64) {
       memcpy(mean, hout, B * M * sizeof(double));
@@ -866,6 +913,7 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
     if (info) info[b] = hinfo[b];
     if (first == 0 && hinfo[b] != 0) first = hinfo[b];
   }
+  lap("copy out");
   return first;
 }
 

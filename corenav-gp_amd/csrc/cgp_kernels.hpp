@@ -119,6 +119,37 @@ struct PhaseClock {
 #endif
 };
 
+// Execution span of a launch (CGP_DBG & 2048, -DCGP_ABLATION): thread 0 of every workgroup stamps the 100 MHz
+// real-time counter at entry and exit; dbgbuf[384 + k] = 2^62 - earliest entry, dbgbuf[416 + k] = latest exit of
+// block step k's k_panel launch (atomicMax both).  tools/launch_spans.py.  Nothing in the shipped library.
+struct SpanClock {
+#ifdef CGP_ABLATION
+  unsigned long long r0, c0;
+#endif
+  __device__ __forceinline__ void enter(const FitArgs &p, int k, int tid) {
+#ifdef CGP_ABLATION
+    if (CGP_DBG_ON(p, 2048) && tid == 0) {
+      r0 = __builtin_amdgcn_s_memrealtime();
+      c0 = __builtin_amdgcn_s_memtime();
+      atomicMax(reinterpret_cast<unsigned long long *>(p.dbgbuf) + 384 + (k & 31), (1ull << 62) - r0);
+    }
+#endif
+  }
+  // also sums, per block step, the workgroups' residence in real-time ticks (448 + k) and in s_memtime ticks
+  // (480 + k): their ratio is the shader clock, the first over span x slots the occupancy actually reached
+  __device__ __forceinline__ void leave(const FitArgs &p, int k, int tid) {
+#ifdef CGP_ABLATION
+    if (CGP_DBG_ON(p, 2048) && tid == 0) {
+      const unsigned long long r1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
+      unsigned long long *d = reinterpret_cast<unsigned long long *>(p.dbgbuf);
+      atomicMax(d + 416 + (k & 31), r1);
+      atomicAdd(d + 448 + (k & 31), r1 - r0);
+      atomicAdd(d + 480 + (k & 31), c1 - c0);
+    }
+#endif
+  }
+};
+
 template <typename T> struct Prec;
 template <> struct Prec<double> {
   using acc_t = double __attribute__((ext_vector_type(4)));

@@ -956,6 +956,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
   int bt, b, rt;
   bool finish_next = false;
   acc_t acc[NCB][2];
+  SpanClock sc;
+  sc.enter(p, k, tid);
   if constexpr (DIAGNEXT) {
     const int Tg = gridDim.x, B = gridDim.y;
     const int lin = blockIdx.y * Tg + blockIdx.x;
@@ -981,6 +983,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
       b = io;
       T *LwB = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
       diag_next<T, DIAG_PARTIAL, kTriDiag>(p, acc, smem, LwB, b, k + 2, tid);
+      sc.leave(p, k, tid);
       return;
     } else {
       const int l2 = io - nB, To = Tg - (nA ? 1 : 0) - (nB ? 1 : 0);  // the other tiles, XCD-steered
@@ -1069,6 +1072,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
   if constexpr (DIAGNEXT) {
     if (finish_next) diag_next<T, DIAG_FINISH, kTriDiag>(p, acc, smem, Lw, b, k + 1, tid);
   }
+  sc.leave(p, k, tid);
 }
 
 #ifdef CGP_AB

@@ -204,7 +204,9 @@ int cgp_window_push_device(cgp_ctx *ctx, int T, const double *dxs, const double 
 int cgp_window_state(cgp_ctx *ctx, int w, int *n, int *info);
 
 /* ---- per-kernel timing for the roofline line (bench.py) --------------------------------------
- * When enabled, every launch is bracketed by hipEvents on its stream; cgp_profile_read drains them.
+ * on = 1: every launch is bracketed by hipEvents on its stream; on = 2 + k: only the update launch of block
+ * step k (the other launches of the schedule stay back to back, so the bracketed one runs as it does in an
+ * untimed step); on = 0: off.  cgp_profile_read drains the events.
  * kernel index: 0 update(syrk/gemm+gram) 1 potf2(+inverse) 2 trmm 3 finalize(mean/var/logml) 4 alpha.
  * flops = algorithmic flops issued by those launches (DESIGN.md section "Kernels"). */
 #define CGP_PROF_KERNELS 5
