@@ -309,18 +309,18 @@ def pmc_traffic(B, N, dts):
     half-count).  Builder-run, not measured in this process; only valid for the configuration the
     profile was taken on, otherwise null."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-    if not files:
-        return None, None
-    try:
-        d = json.load(open(files[-1]))
-        w = d.get("_workload", {"batch": 256, "N": 2048, "dtype": "f64"})
-        if (B, N, dts) != (w["batch"], w["N"], w["dtype"]):
-            return None, None
-        return (d.get("k_panel", d.get("k_update"))["hbm_bytes_per_launch"],
-                f"profiles/{os.path.basename(files[-1])} (builder-run rocprofv3 --pmc passes of this command, not this process)")
-    except Exception:
-        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary*.json")), reverse=True)
+    for f in files:      # newest round first; one summary per profiled configuration
+        try:
+            d = json.load(open(f))
+            w = d.get("_workload", {"batch": 256, "N": 2048, "dtype": "f64"})
+            if (B, N, dts) != (w["batch"], w["N"], w["dtype"]):
+                continue
+            return (d.get("k_panel", d.get("k_update"))["hbm_bytes_per_launch"],
+                    f"profiles/{os.path.basename(f)} (builder-run rocprofv3 --pmc passes of this command, not this process)")
+        except Exception:
+            continue
+    return None, None
 
 
 def extras(engine, torch, dev, local, W):
