@@ -975,10 +975,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
       else io = (j - before) * 256 + r;
     } else if (lin < nA) ia = lin;
     else io = lin - nA;
+    if (CGP_DBG_ON(p, 65536) && (ia >= 0 || io < nB) && !(ia >= 0 && false)) {  // timing probe: no diagonal work in the launch
+      if (ia < 0) return;
+    }
     if (ia >= 0) {
       b = ia;
       rt = k + 1;
-      finish_next = true;
+      finish_next = !CGP_DBG_ON(p, 65536);
     } else if (io < nB) {
       b = io;
       T *LwB = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
@@ -1013,6 +1016,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
   // panels already in flight into LDS buffer 0 (the Gram inputs are staged in buffer 1's space).
   constexpr int CH2 = 2 * KT * LDST;
   const T *gR = Lw + (size_t)rt * TS, *gC = Lw + (size_t)k * TS;
+  // timing probes (wrong results): 4096 = every tile reads fit (b & 7)'s first row panel (L2-resident row
+  // panels), 8192 = the same for the column panel
+  if (CGP_DBG_ON(p, 4096)) gR = reinterpret_cast<const T *>(p.Lw) + (size_t)(b & 7) * p.lw_stride + (size_t)p.NT * TS;
+  if (CGP_DBG_ON(p, 8192)) gC = reinterpret_cast<const T *>(p.Lw) + (size_t)(b & 7) * p.lw_stride + (size_t)k * TS;
   const int nchunk = (k * TS) / KT;
   // running predictive sums (extra tiles, throughput schedule): z of the newest block column
   // (k - 1) goes to LDS behind the chunk ring; zeros when nothing is to be accumulated
@@ -1035,6 +1042,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
       GramPre<T> gp;
       gram_prefetch<T>(p, b, k, rt, tid, gp);
       if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
+      if (CGP_DBG_ON(p, 16384)) {  // timing probe: no Gram tile
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[cb][j][r] = gp.v[0];
+      } else
       gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
     }
     pc.lap(p, ps + 0);
@@ -1066,6 +1081,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
   pc.lap(p, ps + 2);
   if (!CGP_DBG_ON(p, 64)) trmm_in_registers<T>(p, acc, smem, b, k, tid, &pc, ps + 3);
   pc.lap(p, ps + 4);
+  if (!CGP_DBG_ON(p, 32768) || acc[0][0][0] == T(12345.678))  // timing probe: no store
   store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
   pc.lap(p, ps + 5);
   pc.count(p, ps + 7);
