@@ -251,7 +251,7 @@ class Workload:
 
     def single_fit_latency_ms(self):
         """Latency of ONE fit of the same shape (BASELINE configs[1] reads "single GP fit"): the engine
-        switches to its latency schedule for <= 24 fits; synchronised per call."""
+        switches to its latency schedule for a handful of fits; synchronised per call."""
         torch = self.torch
         keep = (self.dmean[0].clone(), self.dvar[0].clone(), self.dlogml[0].clone())
         for _ in range(3):

@@ -143,15 +143,17 @@ struct Launcher {
   }
 };
 
-constexpr int LAT_FITS = 24;                     // batches up to this size take the latency schedule (measured
-                                                 // crossover, tools/lat_crossover.sh: 24 fits in fp64 and fp32)
-constexpr int LAT_FITS_ALLOC = kAbBuild ? 64 : LAT_FITS;  // slabs are sized for this many fits
-inline int lat_fits() {                           // ablation build: CGP_LAT_FITS moves the crossover (measurement)
+// Batches up to this size take the latency schedule: the measured crossover against the throughput schedule
+// (tools/lat_crossover.sh) is 16 fits in fp64 and 24 in fp32.
+constexpr int LAT_FITS_F64 = 16, LAT_FITS_F32 = 24;
+constexpr int FUSED64_BELOW = 512;                // fp64 throughput schedule: diagonal tiles inside the panel launches below this batch
+constexpr int LAT_FITS_ALLOC = kAbBuild ? 64 : LAT_FITS_F32;  // slabs are sized for min(this, max_batch) fits
+template <typename T> inline int lat_fits() {     // ablation build: CGP_LAT_FITS moves the crossover (measurement)
   if constexpr (kAbBuild) {
     const char *e = getenv("CGP_LAT_FITS");
     if (e) return std::max(0, std::min(atoi(e), LAT_FITS_ALLOC));
   }
-  return LAT_FITS;
+  return sizeof(T) == 8 ? LAT_FITS_F64 : LAT_FITS_F32;
 }
 
 inline size_t alpha_lds_bytes(int NT) { return (size_t)(NT * TS + TS) * sizeof(double); }
@@ -175,7 +177,7 @@ template <typename T> int set_lds_attrs(int device) {
   ok = ok && set(reinterpret_cast<const void *>(&k_tile_sk<T>), tile);
   ok = ok && set(reinterpret_cast<const void *>(&k_trmm_sk<T>), upd);
   ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T>), paneldiag_lds_bytes<T>());
-  if constexpr (sizeof(T) == 4 || kAbBuild) ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true>), paneldiag_lds_bytes<T>());
+  ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true>), paneldiag_lds_bytes<T>());
 #ifdef CGP_AB
   ok = ok && set(reinterpret_cast<const void *>(&k_diag<T>), tile);
 #endif
@@ -288,7 +290,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   if (c->prof || !in_rows) G = 1;  // per-kernel timing wants isolated launches
   // latency schedule: a handful of fits, windows long enough for splitting to pay and short enough for the
   // diagonal tile's pre-update images (N <= 2432); anything else takes the throughput schedule
-  const bool latency = !sw.no_latency && batch <= std::min(lat_fits(), c->lat_cap) && a.NT >= 3 && lat_images(a.NT - 1) <= LAT_IMG_MAX;
+  const bool latency = !sw.no_latency && batch <= std::min(lat_fits<T>(), c->lat_cap) && a.NT >= 3 && lat_images(a.NT - 1) <= LAT_IMG_MAX;
   if (latency) G = 1;
   std::vector<FitArgs> ga(G);
   std::vector<int> gb(G);
@@ -407,10 +409,13 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // while the rest of the chip waits.  -DCGP_AB, CGP_SCHED=splitdiag: one k_diag_lean launch per step.
   // Measured (same box, alternating libraries): fp32 N = 1024 +2.6 % fits/s, fp64 N = 2048 -0.7 % -- in fp64
   // the diagonal launches are already MFMA-bound in their syrk part and two workgroups per CU leave the
-  // finisher's factorisation chain nothing to hide behind -- so fp64 keeps one k_diag_lean launch per step
-  // (CGP_SCHED=fuseddiag in a -DCGP_AB build selects the fused form there too).
-  constexpr bool kFusedBuilt = sizeof(T) == 4 || kAbBuild;
-  const bool split_diag = sw.split_diag || !in_rows || !kFusedBuilt || (sizeof(T) == 8 && !sw.fused_diag);
+  // finisher's factorisation chain nothing to hide behind -- so at the bench batch fp64 keeps one k_diag_lean
+  // launch per step (CGP_SCHED=fuseddiag in a -DCGP_AB build selects the fused form there too).
+  // fp64: a diagonal launch is one workgroup per fit on a latency chain whose length does not depend on the
+  // batch (3.3 ms per N = 2048 schedule), so below FUSED64_BELOW fits per call the fused form wins there too
+  // (batch 32 +26 %, 64 +15 %, 128 +6 %, 256 +0.2 %, 512 -0.7 %).
+  const bool fused64 = sw.fused_diag || batch < FUSED64_BELOW;
+  const bool split_diag = sw.split_diag || !in_rows || (sizeof(T) == 8 && !fused64);
   for (int k = 0; k < a.NT; ++k) {
     const int gx_t = (in_rows ? a.NT - k - 1 : 0) + a.ET;
     for (int g = 0; g < G; ++g) {
@@ -431,8 +436,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       ak.diag_stride = sizeof(T) == 8 ? 2 : 4;  // workgroups per CU of k_panel<T, true> (LDS / VGPR bound)
       const int gx = gx_t + (hasB ? 1 : 0);  // gx_t already counts row tile k + 1 (kind A)
       L[g].begin(0, panel_flops(a.N, a.M, a.d, k, true, gb[g]) + (hasA ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0), k);
-      if constexpr (kFusedBuilt)
-        hipLaunchKernelGGL((k_panel<T, true>), dim3(gx, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ak, k);
+      hipLaunchKernelGGL((k_panel<T, true>), dim3(gx, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ak, k);
       L[g].end();
     }
   }

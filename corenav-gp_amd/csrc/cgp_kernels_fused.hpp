@@ -1,12 +1,13 @@
 // cgp_kernels_fused.hpp -- the schedules the engine runs by default (DESIGN.md sections 2 and 4):
-// throughput (more than 24 fits per call), two launches per block step k
+// throughput (more than 16 fits per call in fp64, 24 in fp32), two launches per block step k
+// (one when the diagonal tile rides in the panel launch: fp32, and fp64 below 512 fits per call)
 //   k_diag_lean(k) / k_diag(k) : one workgroup per fit.  S(k,k) = G(k,k) - sum_j L(k,j) L(k,j)^T on a
 //                triangular MFMA loop, then potf2 + inverse of that tile without leaving the CU (L(k,k),
 //                W_k written).  _lean: packed lower-triangle factorisation in 78 KB of LDS, two per CU.
 //   k_panel(k) : every row tile below k and every extra tile.  S(i,k) as above, kept in the MFMA
 //                accumulators, multiplied by W_k^T IN REGISTERS and stored once as L(i,k): the S
 //                tile never goes to HBM and there is no separate trsm/trmm launch.
-// latency (up to 24 fits per call)
+// latency (up to 16 / 24 fits per call)
 //   k_tile_sk(k) + k_trmm_sk(k) : diagonal and panel tiles of a step in one launch, inner dimension
 //                split over several workgroups with a ticketed, fixed-order reduction.
 // and k_grad (hyper-parameter gradients).
