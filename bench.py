@@ -50,6 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip config.extra (cfg3 / window / look-ahead / end-to-end lines)")
     ap.add_argument("--streams", type=int, default=1, help="worker streams the batch is spread over")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
     return ap.parse_args(argv)
 
 
@@ -210,6 +211,11 @@ def run_rank(args):
                 out["config"]["extra"] = extras(engine, torch, dev, local, W)
             if not args.no_cpu and world == 1:   # rank 0 at N = 1 only: other ranks would wait on the host work
                 out["cpu_baseline"] = cpu_baseline(kid, X, y, Xs, th, args.cpu_sample, W.dmean, W.dvar, W.dlogml, f_fit)
+            if world == 1 and not args.no_pmc and not ablation:
+                live = pmc_traffic_live(args)      # last: everything above is already measured if a pass misbehaves
+                if live is not None:
+                    out["roofline"]["traffic_committed"] = out["roofline"]["traffic"]
+                    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = live
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -321,6 +327,44 @@ def pmc_traffic(B, N, dts):
         except Exception:
             continue
     return None, None
+
+
+def pmc_traffic_live(args):
+    """HBM bytes per k_panel launch of THIS command, measured during this run: two child processes
+    `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --steps 1 ...` (FETCH_SIZE and WRITE_SIZE in separate
+    passes, no other tracing, as MI355X_MICROARCH.md's HBM section prescribes; FETCH doubled for the gfx950
+    half-count, units KB).  Children, not exec: this process keeps its GPU context.  None if rocprofv3 is missing
+    or a pass fails or overruns -- the committed builder-run figure then stays in the line."""
+    import csv, glob, shutil, tempfile
+    if shutil.which("rocprofv3") is None or os.environ.get("CGP_BENCH_CHILD"):
+        return None
+    tmp = tempfile.mkdtemp(prefix="cgp_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu", "--no-extra", "--no-pmc",
+             "--batch", str(args.batch), "--config", str(args.config)] + (["--n", str(args.n)] if args.n else [])
+    env = dict(os.environ, TMPDIR="/tmp", CGP_BENCH_CHILD="1")
+    mean = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if r.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "p_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "k_panel" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            mean[ctr] = sum(vals) / len(vals)
+        bytes_per_launch = 2.0 * mean["FETCH_SIZE"] * 1024 + mean["WRITE_SIZE"] * 1024
+        return bytes_per_launch, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command, run by this process "
+                                  "after the timed region (FETCH x2 gfx950 correction, KB units)")
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def extras(engine, torch, dev, local, W):

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--steps", "2", "--warmup", "1",
-                        "--cpu-sample", "1", "--no-extra"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--cpu-sample", "1", "--no-extra", "--no-pmc"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -37,7 +37,7 @@ def test_bench_extra_lines():
     """config.extra of the same driver command: the PCIe-inclusive rate, BASELINE configs[2] (512 x N=1024
     fp32) on its own schedule, configs[3] (sliding window) and the batched look-ahead."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--steps", "1", "--warmup", "1",
-                        "--no-cpu"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--no-cpu", "--no-pmc"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     ex = j["config"]["extra"]
@@ -45,6 +45,23 @@ def test_bench_extra_lines():
     assert ex["end_to_end_fits_per_s"] > 0 and ex["end_to_end_matches_resident"] is True
     assert ex["cfg3_fits_per_s"] > 0 and 0 < ex["cfg3_roofline_frac"] < 1 and ex["cfg3_max_rel_err_vs_oracle_fit0"] < 1e-3
     assert ex["window_ticks_per_s"] > 0 and 0 < ex["window_hbm_frac"] < 1 and ex["lookahead_traj_per_s"] > 0
+
+
+def test_bench_live_pmc_traffic():
+    """roofline.traffic is measured by the run itself: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) of
+    the same command.  32 fits per call take the throughput schedule, so k_panel launches exist."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on PATH")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "32", "--steps", "1", "--warmup", "1",
+                        "--no-cpu", "--no-extra"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rf = json.loads(lines[0])["roofline"]
+    assert rf["traffic_source"].startswith("rocprofv3 --pmc"), rf
+    # every tile streams its panels at least once: more than the 26 MB per fit of L written once, less than 10x the streaming figure
+    assert 32 * 26e6 / 16 < rf["traffic"] < 32 * 3e9 / 16, rf
 
 
 def test_bench_gpus2_on_one_gpu():
