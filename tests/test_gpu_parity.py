@@ -155,22 +155,47 @@ def test_config2_full_size_fp64(engine):
 
 
 def test_config2_full_size_throughput_schedule(engine):
-    """BASELINE configs[1] shape (N=2048 d=6 ARD fp64, M=599) through the throughput schedule (5 fits):
-    two of them against the numpy oracle, all of them through the variance floor and a permutation
-    property (a fit's outputs do not depend on its slot in the batch)."""
-    kid, X, y, Xs, th, _ = synth.config(2, batch=5)
-    ctx = engine.Context(max_n=2048, max_m=599, max_d=6, max_batch=5)
+    """BASELINE configs[1] shape (N=2048 d=6 ARD fp64, M=599) through the throughput schedule as a mid-size call
+    takes it (18 fits: above the latency crossover, below 512, so the diagonal tiles ride in the panel launches):
+    two fits against the numpy oracle, all of them through the variance floor and a permutation property (a
+    fit's outputs do not depend on its slot in the batch)."""
+    B = 18
+    kid, X, y, Xs, th, _ = synth.config(2, batch=B)
+    ctx = engine.Context(max_n=2048, max_m=599, max_d=6, max_batch=B)
     rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
     assert rc == 0 and not info.any()
-    for b in (0, 4):
+    for b in (0, B - 1):
         f = go.fit(kid, th[b], X[b], y[b])
         omu, ovar = go.predict(f, Xs[b])
         assert relmax(mean[b], omu) < TOL64 and releach(var[b], ovar) < TOL64
         assert abs(logml[b] - f.logml) <= TOL64 * abs(f.logml)
     assert np.all(var >= th[:, -1:])
-    perm = np.array([3, 0, 4, 1, 2])
+    perm = np.random.default_rng(18).permutation(B)
     rc, m2, v2, l2, _ = ctx.fit_predict_batch(X[perm], y[perm], Xs[perm], th[perm], kid)
     assert np.array_equal(m2, mean[perm]) and np.array_equal(v2, var[perm]) and np.array_equal(l2, logml[perm])
+
+
+def test_config2_bench_batch_schedule(engine):
+    """The headline workload exactly as bench.py times it: 512 x (N=2048 d=6 ARD fp64, M=599) in one call (one
+    k_diag_lean launch per block step + k_panel).  Every fit factors, the variance floor holds, a sample of fits
+    meets the oracle, and the first 18 fits agree with the mid-size schedule of the previous test to rounding
+    (same inputs, different summation order inside the diagonal tile)."""
+    B = 512
+    kid, X, y, Xs, th, _ = synth.config(2, batch=B)
+    ctx = engine.Context(max_n=2048, max_m=599, max_d=6, max_batch=B)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not info.any()
+    assert np.all(np.isfinite(mean)) and np.all(np.isfinite(logml)) and np.all(var >= th[:, -1:])
+    for b in (0, 301):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        assert relmax(mean[b], omu) < TOL64 and releach(var[b], ovar) < TOL64
+        assert abs(logml[b] - f.logml) <= TOL64 * abs(f.logml)
+    ctx18 = engine.Context(max_n=2048, max_m=599, max_d=6, max_batch=18)
+    rc, m18, v18, l18, i18 = ctx18.fit_predict_batch(X[:18], y[:18], Xs[:18], th[:18], kid)
+    assert rc == 0 and not i18.any()
+    assert relmax(m18, mean[:18]) < 1e-9 and releach(v18, var[:18]) < 1e-9
+    assert np.max(np.abs(l18 - logml[:18]) / np.abs(logml[:18])) < 1e-11
 
 
 def test_batch_matches_single_and_oracle(engine):
@@ -204,13 +229,14 @@ def test_config3_fp32_batch(engine):
 
 def test_config3_fp32_full_size_throughput_schedule(engine):
     """BASELINE configs[2] at its own size AND on the schedule the 512-fit sweep takes: N=1024 d=6 fp32,
-    M=599, 8 fits (> 4 -> k_diag_lean + k_panel<float>), every fit against the oracle at north_star's
-    fp32 bar (1e-3), per-fit random length-scales as SURVEY.md 8d prescribes for cfg3."""
-    kid, X, y, Xs, th, _ = synth.config(3, batch=8)
-    ctx = engine.Context(max_n=1024, max_m=599, max_d=6, max_batch=8, dtype=engine.F32)
+    M=599, 26 fits (above the fp32 latency crossover of 24 -> k_panel<float> with the diagonal tiles inside),
+    every other fit against the oracle at north_star's fp32 bar (1e-3), per-fit random length-scales as SURVEY.md
+    8d prescribes for cfg3."""
+    kid, X, y, Xs, th, _ = synth.config(3, batch=26)
+    ctx = engine.Context(max_n=1024, max_m=599, max_d=6, max_batch=26, dtype=engine.F32)
     rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
     assert rc == 0 and not info.any()
-    for b in range(8):
+    for b in range(0, 26, 2):
         f = go.fit(kid, th[b], X[b], y[b])
         omu, ovar = go.predict(f, Xs[b])
         assert relmax(mean[b], omu) < TOL32 and releach(var[b], ovar) < TOL32
@@ -439,11 +465,12 @@ def test_batch_jitter_retry_is_per_fit(engine):
 
 def test_stream_groups_do_not_change_results(engine):
     """The batch is cut into worker-stream groups (cgp_set_streams); any grouping gives bitwise the
-    same answers, including an odd batch that does not divide evenly."""
-    kid, X, y, Xs, th, _ = synth.config(2, batch=5, N=300)
+    same answers, including a batch that does not divide evenly (21 fits: the throughput schedule, the only one
+    that uses the groups)."""
+    kid, X, y, Xs, th, _ = synth.config(2, batch=21, N=300)
     ref = None
-    for ns in (1, 2, 3):
-        ctx = engine.Context(max_n=300, max_m=599, max_d=6, max_batch=5)
+    for ns in (1, 2, 4):
+        ctx = engine.Context(max_n=300, max_m=599, max_d=6, max_batch=21)
         ctx.set_streams(ns)
         rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
         assert rc == 0
@@ -498,7 +525,7 @@ def test_sweep_matches_single_context(engine, devices):
     """cgp_sweep_* (the C-ABI multi-device entry of SURVEY.md 8b / 8e): block partition over per-device
     contexts on their own host threads; results bitwise equal to one context running the whole batch,
     summaries in global fit order.  A one-GPU box names device 0 several times (one context each)."""
-    kid, X, y, Xs, th, _ = synth.config(2, batch=16, N=300)   # every shard > 4 fits: throughput schedule
+    kid, X, y, Xs, th, _ = synth.config(2, batch=60, N=300)   # every shard >= 20 fits: throughput schedule, like the whole
     B = X.shape[0]
     ctx = engine.Context(max_n=300, max_m=599, max_d=6, max_batch=B)
     rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
