@@ -211,6 +211,8 @@ def run_rank(args):
                 out["config"]["extra"] = extras(engine, torch, dev, local, W)
             if not args.no_cpu and world == 1:   # rank 0 at N = 1 only: other ranks would wait on the host work
                 out["cpu_baseline"] = cpu_baseline(kid, X, y, Xs, th, args.cpu_sample, W.dmean, W.dvar, W.dlogml, f_fit)
+            if world == 1 and not args.no_extra:
+                out["config"]["extra"].update(extras_cfg3(engine, torch, dev, local, W))
             if world == 1 and not args.no_pmc and not ablation:
                 live = pmc_traffic_live(args)      # last: everything above is already measured if a pass misbehaves
                 if live is not None:
@@ -386,30 +388,6 @@ def extras(engine, torch, dev, local, W):
     except Exception as e:
         ex["end_to_end_error"] = repr(e)
     try:
-        if W.dts == "f64":   # BASELINE configs[2] on its own schedule
-            kid, X, y, Xs, th, dts = synth.config(3, batch=512, M=M_TEST)
-            W3 = Workload(engine, torch, dev, local, kid, X, y, Xs, th, dts, 1)
-            for _ in range(2):
-                W3.step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                W3.step()
-            torch.cuda.synchronize()
-            el = (time.perf_counter() - t0) / 5
-            assert int(W3.dinfo.abs().sum().item()) == 0
-            rf, kms = W3.roofline(FP32_MFMA_PEAK_TFLOPS)
-            ex["cfg3_fits_per_s"] = 512 / el
-            ex["cfg3_ms_per_step"] = el * 1e3
-            ex["cfg3_roofline_frac"] = rf["frac"]
-            ex["cfg3_kernel_ms_per_step"] = kms
-            ex["cfg3_workload"] = "BASELINE configs[2]: 512 x N=1024 d=6 SE-ARD fp32, M=599, one GPU's view of the sweep"
-            f = go_check(kid, X, y, Xs, th, W3, 1e-3)
-            ex["cfg3_max_rel_err_vs_oracle_fit0"] = f
-            del W3
-    except Exception as e:
-        ex["cfg3_error"] = repr(e)
-    try:
         ex.update(window_line(engine, torch, dev, local))
     except Exception as e:
         ex["window_error"] = repr(e)
@@ -431,6 +409,40 @@ def go_check(kid, X, y, Xs, th, W, tol):
               abs(float(W.dlogml[0]) - f.logml) / abs(f.logml))
     assert err < tol, err
     return err
+
+
+def extras_cfg3(engine, torch, dev, local, W):
+    """BASELINE configs[2] (512 x N=1024 fp32) on its own schedule, with its own roofline fraction and an oracle
+    check.  Called AFTER the host-side cpu_baseline leg: measured right behind the fp64 run the part is still at
+    that run's temperature / clock and reads about 8 % low (91 k against 99-101 k fits/s of a cold `--config 3`)."""
+    import corenav_gp_amd.synth as synth
+    ex = {}
+    try:
+        if W.dts == "f64":   # BASELINE configs[2] on its own schedule
+            kid, X, y, Xs, th, dts = synth.config(3, batch=512, M=M_TEST)
+            W3 = Workload(engine, torch, dev, local, kid, X, y, Xs, th, dts, 1)
+            tw = time.perf_counter()
+            while time.perf_counter() - tw < 0.15:   # the part idled through the host leg: back to its working clock first
+                W3.step()
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                W3.step()
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / 5
+            assert int(W3.dinfo.abs().sum().item()) == 0
+            rf, kms = W3.roofline(FP32_MFMA_PEAK_TFLOPS)
+            ex["cfg3_fits_per_s"] = 512 / el
+            ex["cfg3_ms_per_step"] = el * 1e3
+            ex["cfg3_roofline_frac"] = rf["frac"]
+            ex["cfg3_kernel_ms_per_step"] = kms
+            ex["cfg3_workload"] = "BASELINE configs[2]: 512 x N=1024 d=6 SE-ARD fp32, M=599, one GPU's view of the sweep"
+            f = go_check(kid, X, y, Xs, th, W3, 1e-3)
+            ex["cfg3_max_rel_err_vs_oracle_fit0"] = f
+            del W3
+    except Exception as e:
+        ex["cfg3_error"] = repr(e)
+    return ex
 
 
 def window_line(engine, torch, dev, local, W=1024, N=512, d=3, T=200):
