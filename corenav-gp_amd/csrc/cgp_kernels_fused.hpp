@@ -397,7 +397,7 @@ __device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<
                                                 const T *__restrict__ xrT, const T *__restrict__ xcT,
                                                 const T *__restrict__ xraw, const T *__restrict__ craw,
                                                 const T *__restrict__ yc, bool extra, int rowbase, int colbase, T amp,
-                                                T amp_b, T diag_add, int lane, int wave) {
+                                                T amp_b, T diag_add, int lane, int wave, T inv_ell = T(0)) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
   const int N = p.N, M = p.M, l15 = lane & 15, lq = lane >> 4;
@@ -441,6 +441,13 @@ __device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<
           const T x = xrw[j], xp = craw[cl];
           const bool same = !FAST && !extra && grow == gcol;  // GPy forces r^2 = 0 on the auto-covariance diagonal
           T ee = e[r] > T(0) ? T(0) : e[r];                   // r^2 clipped at 0
+          if constexpr (sizeof(T) == 4) {
+            // GPy's r^2 = x^2 + x'^2 - 2 x x' on raw tick counts (what e[] holds, reproduced as is in fp64) loses
+            // the RBF factor itself in single precision (ticks ~ 1e3: 0.06 absolute in r^2, and the window's
+            // conditioning amplifies a 1e-4 perturbation of K to per cent); the difference of two ticks is exact
+            const T df = (x - xp) * inv_ell;
+            ee = T(-0.5) * df * df;
+          }
           ee = same ? T(0) : ee;
           const int sx = (x > T(0)) - (x < T(0)), sp = (xp > T(0)) - (xp < T(0));
           const T ax = x < T(0) ? -x : x, ap = xp < T(0) ? -xp : xp;
@@ -564,11 +571,11 @@ __device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::a
   const int colbase = k * TS;
   const bool fast = (colbase + TS <= N) && (extra ? (rowbase + TS <= M && !p.xid) : (rt != k && rowbase + TS <= N));
   if constexpr (TRI) {  // diagonal tile: never "fast" (it carries the noise diagonal)
-    if (brown) gram_apply_tile<T, true, false, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
+    if (brown) gram_apply_tile<T, true, false, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
     else gram_apply_tile<T, false, false, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
   } else if (brown) {
-    if (fast) gram_apply_tile<T, true, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
-    else gram_apply_tile<T, true, false>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
+    if (fast) gram_apply_tile<T, true, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
+    else gram_apply_tile<T, true, false>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
   } else {
     if (fast) gram_apply_tile<T, false, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
     else gram_apply_tile<T, false, false>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
