@@ -1,0 +1,21 @@
+"""A short prefix of the randomised parity sweep (tools/fuzz_parity.py: window lengths around every tile and
+schedule boundary, horizons around multiples of 128, all three kernels, both precisions, call sizes either side of
+the latency / throughput and fused / split switches) against the oracle.  The seeded case sequence is fixed; the
+time budget only decides how long a prefix of it runs (the builder ran 150 s of this seed clean)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fuzz_prefix():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "20", "7"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("cases ") and " failures 0 " in last, last
+    assert int(last.split()[1]) >= 20, last
