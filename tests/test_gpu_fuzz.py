@@ -19,3 +19,13 @@ def test_fuzz_prefix():
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("cases ") and " failures 0 " in last, last
     assert int(last.split()[1]) >= 20, last
+
+
+def test_fuzz_single_window_api_prefix():
+    """tools/fuzz_single.py: cgp_fit -> cgp_predict (with / without noise) -> cgp_get_alpha -> cgp_get_factor ->
+    cgp_nll_grad on random windows, fp64, against the oracle (the builder ran 120 s of this seed: 2 036 cases clean)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_single.py"), "12", "1"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("cases ") and " failures 0 " in last, last
