@@ -48,6 +48,10 @@ enum {
 /* Allocates every device buffer for up to `max_batch` simultaneous fits of at most max_n training
  * points, max_m test points, max_d input dimensions.  dtype = CGP_F64 | CGP_F32 is the arithmetic
  * type of the device path; host buffers are always fp64 (the messages are float64[]).
+ * CGP_F64 is the reference's arithmetic and meets 1e-6 against it on every kernel.  CGP_F32 is for the SE
+ * kernels on standardised inputs (BASELINE configs[2], 1e-3); a window that is ill-conditioned in single
+ * precision -- dense one-dimensional inputs, the reference's RBF x Brownian kernel on raw tick counts -- is
+ * as accurate as single-precision LAPACK is on it, which can be worse than 1e-3 (tools/fuzz_parity.py).
  * Returns NULL on failure (device index out of range, device is not gfx950 -- the architecture name
  * is checked: the code object holds gfx950 kernels only -- or out of memory): no CPU fallback. */
 cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, int dtype);
