@@ -40,3 +40,13 @@ def test_fuzz_sliding_window_prefix():
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("cases ") and " failures 0 " in last, last
+
+
+def test_fuzz_lookahead_prefix():
+    """tools/fuzz_lookahead.py: the batched GPU look-ahead against the host C++ path of the same ABI on random horizons
+    (0 ... 748 predictions), slip levels, filter snapshots, thresholds, late arrivals, both H packings (the builder
+    ran 60 s of this seed: 1 139 ensembles clean)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_lookahead.py"), "8", "1"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert " failures 0" in r.stdout.strip().splitlines()[-1], r.stdout[-500:]
