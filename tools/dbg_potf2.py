@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Phase cycles of the diagonal-tile kernel (ablation build, CGP_DBG=512): debug helper of round 1."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
