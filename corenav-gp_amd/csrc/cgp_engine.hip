@@ -62,11 +62,11 @@ struct cgp_ctx {
   double *dtheta = nullptr, *djitter = nullptr, *dlogml = nullptr, *dprep = nullptr;
   long long *ddbg = nullptr;
   double *dgpart = nullptr;
-  void *dpart = nullptr;   // latency schedule: partial tiles [LAT_FITS][slots][SK_MAX][128*128]
-  int *dticket = nullptr;  //                   arrival tickets [LAT_FITS][slots]
-  int lat_cap = 0;         //                   fits the latency slabs are sized for: min(LAT_FITS, max_batch)
-  int *dwready = nullptr;  //                   published block steps [LAT_FITS]
-  void *dlatimg = nullptr;  //                  pre-updated diagonal tiles [LAT_FITS][2][LAT_IMG_MAX][DPART]
+  void *dpart = nullptr;   // latency schedule: partial tiles [lat_cap][slots][SK_MAX][128*128]
+  int *dticket = nullptr;  //                   arrival tickets [lat_cap][slots]
+  int lat_cap = 0;         //                   fits the latency slabs are sized for: min(LAT_FITS_F32, max_batch)
+  int *dwready = nullptr;  //                   published block steps [lat_cap]
+  void *dlatimg = nullptr;  //                  pre-updated diagonal tiles [lat_cap][2][LAT_IMG_MAX][DPART]
   double *dmacc = nullptr;  // [max_batch][2][max_m] running predictive sums (throughput schedule, fp64)
   void *ddiagimg = nullptr;  // [max_batch][2][DPART] pre-updated diagonal tiles (throughput schedule, diag_next)
   // cgp_fit_predict_batch staging, grown on demand and kept: pinned host buffers (hipHostMalloc) so the
@@ -231,7 +231,7 @@ template <typename T> FitArgs group_view(const FitArgs &a, int g0) {
 }
 
 // A/B switches of the schedule.  The shipped library has ONE schedule pair (throughput: k_diag_lean +
-// k_panel with running predictive sums; latency: k_tile_sk + k_trmm_sk for <= LAT_FITS fits); the
+// k_panel with running predictive sums; latency: k_tile_sk + k_trmm_sk for <= LAT_FITS_F64 / LAT_FITS_F32 fits); the
 // alternatives measured in DESIGN.md (one diagonal launch per step, two-stream overlap,
 // fat diagonal, finalize without accumulators, fused trmm) exist only in a -DCGP_AB build, where the
 // environment selects them once per process.
