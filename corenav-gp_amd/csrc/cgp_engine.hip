@@ -289,7 +289,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   int G = std::max(1, std::min(std::min(c->nstreams, (int)cgp_ctx::kMaxStreams), batch));
   if (c->prof || !in_rows) G = 1;  // per-kernel timing wants isolated launches
   // latency schedule: a handful of fits, windows long enough for splitting to pay and short enough for the
-  // diagonal tile's pre-update images (N <= 2432); anything else takes the throughput schedule
+  // diagonal tile's pre-update images (N <= 2560); anything else takes the throughput schedule
   const bool latency = !sw.no_latency && batch <= std::min(lat_fits<T>(), c->lat_cap) && a.NT >= 3 && lat_images(a.NT - 1) <= LAT_IMG_MAX;
   if (latency) G = 1;
   std::vector<FitArgs> ga(G);

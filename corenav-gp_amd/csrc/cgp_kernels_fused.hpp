@@ -1205,7 +1205,7 @@ constexpr int SK_MAX = 8;
 // Chunks of one pre-update workgroup of the diagonal tile (latency schedule): 3 block columns, so that it is
 // shorter than the factorisation it hides behind.
 constexpr int LAT_IMG_CHUNKS = 3 * (TS / KT);
-constexpr int LAT_IMG_MAX = 6;  // images per diagonal tile: covers (LAT_IMG_MAX * 3 + 1) * 128 = 2432 columns
+constexpr int LAT_IMG_MAX = 6;  // images per diagonal tile: 3 block columns each, the last one is added by the finisher: N <= (LAT_IMG_MAX * 3 + 2) * 128 = 2560
 __host__ __device__ __forceinline__ constexpr int lat_images(int kn) {  // images of diagonal tile kn: columns < (kn-1)*128
   return kn >= 2 ? ((kn - 1) * (TS / KT) + LAT_IMG_CHUNKS - 1) / LAT_IMG_CHUNKS : 0;
 }

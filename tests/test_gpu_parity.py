@@ -361,11 +361,13 @@ def test_latency_schedule_mid_batch(engine, dtype_name, N):
     assert np.array_equal(ms, mean[sel]) and np.array_equal(vs, var[sel]) and np.array_equal(ls, logml[sel])
 
 
-def test_window_longer_than_the_latency_schedule_covers(engine):
-    """The latency schedule's look-ahead images cover windows up to N = 2432; a single longer window (N = 2500,
-    20 block steps) must fall through to the throughput schedule, not fail -- same parity bar."""
-    rng = np.random.default_rng(2500)
-    N, d, M = 2500, 2, 40
+@pytest.mark.parametrize("N", [2560, 2600])
+def test_window_longer_than_the_latency_schedule_covers(engine, N):
+    """The latency schedule's look-ahead images cover windows up to N = 2560 (20 block steps); a single longer
+    window (N = 2600, 21 block steps) must fall through to the throughput schedule, not fail -- same parity bar on
+    both sides of the limit."""
+    rng = np.random.default_rng(N)
+    d, M = 2, 40
     X, Xs = rng.normal(size=(N, d)), rng.normal(size=(M, d))
     theta = np.array([0.8, 0.9, 1.4, 0.05])
     y = 0.1 * np.sin(np.arange(N) / 7.0) + 0.03 * rng.normal(size=N)
