@@ -349,7 +349,7 @@ def pmc_traffic_live(args):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child
-            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=120, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             if r.returncode != 0:
                 return None
             vals = []
