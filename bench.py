@@ -349,8 +349,18 @@ def pmc_traffic_live(args):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child
-            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=120, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            if r.returncode != 0:
+            # own process group, so that an overrun ends the profiler AND the program it started (exact pgid, not a pattern)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                pr.communicate(timeout=120)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, 9)
+                except OSError:
+                    pass
+                pr.wait()
+                return None
+            if pr.returncode != 0:
                 return None
             vals = []
             for f in glob.glob(os.path.join(d, "**", "p_counter_collection.csv"), recursive=True):
