@@ -6,7 +6,7 @@ not importable here: `core_navigation/script/gp_slip_node.py:3`), and the refere
 golden vector for this path.  What pins this file instead:
   * closed-form known answers (N=1, N=2, noise->inf limit, Brownian prior variance) -- tests/test_oracle.py
   * an independent implementation, scikit-learn GaussianProcessRegressor(optimizer=None), for the
-    SE-iso / SE-ARD kernels at fixed theta -- fixtures in tests/golden/ made by tools/gen_golden.py
+    SE-iso / SE-ARD kernels at fixed theta -- fixtures in tests/golden/ made by tests/golden/gen_golden.py
   * algebraic properties (L L^T = Ky, Ky alpha = y, var >= noise, permutation invariance).
 
 Every function cites the reference file:line whose behaviour it restates.  Paths are relative to

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Parity at window lengths around the latency schedule's upper limit (look-ahead images cover N <= 2560) and beyond
 (test infrastructure: uses oracle/): N = 2047 ... 3000, call sizes either side of the schedule switches, both
-precisions, M = 130.  python tools/check_large_n.py  (about a minute; the builder's run: 0 failures of 100 checks)"""
+precisions, M = 130.  python tests/fuzz/check_large_n.py  (about a minute; the builder's run: 0 failures of 100 checks)"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch

@@ -3,9 +3,9 @@
 path of the same ABI (cgp_predict_stop, itself pinned to the oracle by tests/test_host_abi.py): random horizon
 lengths (0, 1, the reference's 599 / 748), slip means up to the clamp, sigma scales, filter snapshots, thresholds,
 arrival / now offsets (incl. "late"), H packing flag, ensemble sizes.
-   python tools/fuzz_lookahead.py [seconds=30] [seed=0]"""
+   python tests/fuzz/fuzz_lookahead.py [seconds=30] [seed=0]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401

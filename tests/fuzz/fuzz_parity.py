@@ -2,13 +2,13 @@
 """Randomised parity sweep of the batched fit + predict against the oracle (test infrastructure: uses oracle/):
 random window length N (around every tile and schedule boundary), horizon M (0, around multiples of 128), input
 dimension, kernel, precision and call size (either side of the latency / throughput and fused / split switches).
-   python tools/fuzz_parity.py [seconds=120] [seed=0]
+   python tests/fuzz/fuzz_parity.py [seconds=120] [seed=0]
 Prints one line per case that fails its bar and a summary; exit 1 on any.  Bars: fp64 1e-6, fp32 1e-3 (north_star),
 the fp32 one widened to 10x the error LAPACK itself makes in single precision on the same window (spotrf / strtrs on
 the fp64 Gram matrix rounded to fp32) where the window is too ill-conditioned for single precision to hold 1e-3 --
 dense 1-D inputs, the reference's RBF x Brownian kernel on raw tick counts: fp64 paths, as in the reference."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401  (the process's HIP runtime must be torch's)

@@ -2,9 +2,9 @@
 """Randomised sweep of the single-window entry points against the oracle (test infrastructure: uses oracle/):
 cgp_fit -> cgp_predict (with and without the noise term) -> cgp_get_alpha -> cgp_get_factor -> cgp_nll_grad, fp64,
 random N around the tile boundaries, random M, d and kernel.
-   python tools/fuzz_single.py [seconds=60] [seed=0]"""
+   python tests/fuzz/fuzz_single.py [seconds=60] [seed=0]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401

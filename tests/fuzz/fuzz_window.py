@@ -2,9 +2,9 @@
 """Randomised sweep of the sliding-window engine (k_window_ticks) against the refit-per-tick oracle (test
 infrastructure: uses oracle/): random window length N (around the 16-column panel boundaries), input dimension, kernel,
 stream length (several ring compactions), number of independent windows and block cuts of the stream.
-   python tools/fuzz_window.py [seconds=60] [seed=0]"""
+   python tests/fuzz/fuzz_window.py [seconds=60] [seed=0]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401

@@ -37,13 +37,14 @@ def test_bench_extra_lines():
     """config.extra of the same driver command: the PCIe-inclusive rate, BASELINE configs[2] (512 x N=1024
     fp32) on its own schedule, configs[3] (sliding window) and the batched look-ahead."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--steps", "1", "--warmup", "1",
-                        "--no-cpu", "--no-pmc"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--cpu-sample", "1", "--no-pmc"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     ex = j["config"]["extra"]
     assert not [k for k in ex if k.endswith("_error")], ex
     assert ex["end_to_end_fits_per_s"] > 0 and ex["end_to_end_matches_resident"] is True
-    assert ex["cfg3_fits_per_s"] > 0 and 0 < ex["cfg3_roofline_frac"] < 1 and ex["cfg3_max_rel_err_vs_oracle_fit0"] < 1e-3
+    assert ex["cfg3_fits_per_s"] > 0 and 0 < ex["cfg3_roofline_frac"] < 1 and ex["cfg3_max_rel_err_vs_oracle"] < 1e-3
+    assert ex["cfg3_cpu_baseline"]["value"] > 0 and ex["cfg3_cpu_baseline"]["kind"] == "port" and "_cpu_leg" not in ex
     assert ex["window_ticks_per_s"] > 0 and 0 < ex["window_hbm_frac"] < 1 and ex["lookahead_traj_per_s"] > 0
 
 
