@@ -10,6 +10,11 @@ Multi-GPU: one process per GPU, fits sharded across ranks with no data-path coll
 gathers per-fit summaries.  `python bench.py --gpus N` on its own STARTS the N ranks (fresh child
 processes, before this process has touched the GPU) and relays rank 0's line; under
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.
+Default: weak scaling (every rank owns `--batch` fits).  `--scaling strong` fixes the TOTAL: `--batch` fits
+per step cut into contiguous per-rank shards (sharding.shard_range) -- `--scaling strong --config 3` is BASELINE
+configs[2] as written ("Batch=512 independent N=1024 GP fits fp32 sharded across 8 MI355X": 64 fits per GPU
+and call at --gpus 8).  CGP_BENCH_FORCE_DIST=1 runs the RCCL rendezvous / barrier / all_gather / all_reduce
+with a world of ONE rank (the collective path on a one-GPU box).
 
 Prints ONE JSON line on rank 0.
 """
@@ -51,36 +56,60 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="skip config.extra (cfg3 / window / look-ahead / end-to-end lines)")
     ap.add_argument("--streams", type=int, default=1, help="worker streams the batch is spread over")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch fits per GPU and step; strong: --batch fits per step over ALL ranks (contiguous shards)")
     return ap.parse_args(argv)
 
 
 def spawn_ranks(args):
     """`bench.py --gpus N` outside a launcher: start N fresh rank processes (this process has made no
     HIP / torch.cuda call and never will), one per GPU, relay rank 0's JSON line and the worst exit
-    code.  Never re-execs a process that has touched the GPU."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    code.  Never re-execs a process that has touched the GPU.  Rendezvous through a file store (no port to
+    race for); every child is polled, and as soon as one exits non-zero -- or the global deadline passes -- the
+    others are killed (exact PIDs) and that code is returned, so a rank that dies at start-up does not leave the
+    rest waiting in init_process_group."""
+    import tempfile
+    rdzv = tempfile.NamedTemporaryFile(prefix="cgp_rdzv_", dir="/tmp", delete=False)
+    rdzv.close()
+    os.unlink(rdzv.name)        # FileStore creates it
+    deadline = time.time() + float(os.environ.get("CGP_BENCH_SPAWN_TIMEOUT", "1500"))
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   CGP_BENCH_INIT="file://" + rdzv.name)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the pool's driver only supports dmabuf IPC (RCCL needs it)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=600))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
-    bad = [rc for rc in rcs if rc != 0]
-    if bad or not lines:
-        sys.stderr.write(f"bench.py: rank exit codes {rcs}; no result line\n" if not lines else f"bench.py: rank exit codes {rcs}\n")
-        return bad[0] if bad else 1
+    import threading
+    out0 = []
+    t0 = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)   # drain rank 0's pipe while polling
+    t0.start()
+    rcs = [None] * args.gpus
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = rcs[r]
+        if failed is not None or time.time() > deadline:
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.kill()
+                    rcs[r] = p.wait()
+            if failed is None:
+                failed = -9
+            break
+        time.sleep(0.05)
+    t0.join(timeout=10)
+    try:
+        os.unlink(rdzv.name)
+    except OSError:
+        pass
+    lines = [l for l in ("".join(out0)).splitlines() if l.startswith("{")]
+    if failed is not None or not lines:
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}" + ("; no result line\n" if not lines else "\n"))
+        return failed if failed else 1
     print(lines[-1])
     return 0
 
@@ -102,8 +131,13 @@ def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CGP_BENCH_TEST_DIE_RANK") == str(rank):   # launcher self-test: this rank fails before the rendezvous
+        raise SystemExit(17)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: every rank must be started with the same --gpus")
+    # CGP_BENCH_FORCE_DIST=1: the collective path (rendezvous, barrier, all_gather, all_reduce, the summary gather)
+    # with a world of one rank -- RCCL loads and runs on a one-GPU box before an 8-GPU job is the first to try it
+    use_dist = world > 1 or bool(os.environ.get("CGP_BENCH_FORCE_DIST"))
     # CGP_BENCH_BACKEND=gloo + CGP_BENCH_SAME_DEVICE=1: self-test of the N > 1 flow on a 1-GPU box.
     # CGP_BENCH_DRY=1 (CPU test of the launcher / rendezvous / gather only): no engine, no GPU, the
     # "step" is a sleep and the line says "dry_run": true -- never a measurement.
@@ -117,25 +151,46 @@ def run_rank(args):
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     cdev = dev if backend == "nccl" else torch.device("cpu")   # where collective tensors live
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        init = os.environ.get("CGP_BENCH_INIT")       # spawn_ranks: file store
+        if init is None and "MASTER_PORT" not in os.environ:   # forced one-rank world outside any launcher
+            import tempfile
+            f = tempfile.NamedTemporaryFile(prefix="cgp_rdzv_", dir="/tmp", delete=False)
+            f.close()
+            os.unlink(f.name)
+            init = "file://" + f.name
+        if init is not None:
+            dist.init_process_group(backend, init_method=init, rank=rank, world_size=world, **kw)
+        else:                                         # torchrun / the driver's launcher: env:// rendezvous
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend, **kw)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     def sync():
         if not dry:
             torch.cuda.synchronize()
 
-    B = args.batch
-    # every rank owns its own shard of windows (weak scaling: per-GPU work fixed)
-    kid, X, y, Xs, th, dts = synth.config(args.config, batch=B if not dry else min(B, 4), N=args.n if not dry else 64, M=M_TEST)
-    if rank > 0:   # different trajectories per rank, same shapes
-        X = np.roll(X, rank, axis=0) + 0.0
-        rng = np.random.default_rng(synth.SEED_BASE + 7919 * rank)
-        y = y + rng.normal(0, 1e-3, y.shape)
+    strong = args.scaling == "strong"
+    nsyn = (lambda b: min(b, 4)) if dry else (lambda b: b)     # dry run: the windows are never fitted, a few suffice
+    if strong:
+        # the sweep's total is fixed: this rank owns the contiguous shard [b0, b1) of the args.batch windows
+        B_total = args.batch
+        b0, b1 = sharding.shard_range(B_total, rank, world)
+        B = b1 - b0
+        if B < 1:
+            raise SystemExit(f"--scaling strong: {args.batch} fits cannot be cut into {world} non-empty shards")
+        kid, X, y, Xs, th, dts = synth.config(args.config, batch=nsyn(B), N=args.n if not dry else 64, M=M_TEST, first=b0)
+    else:
+        B = args.batch
+        B_total = B * world
+        # every rank owns its own batch of windows (weak scaling: per-GPU work fixed)
+        kid, X, y, Xs, th, dts = synth.config(args.config, batch=nsyn(B), N=args.n if not dry else 64, M=M_TEST)
+        if rank > 0:   # different trajectories per rank, same shapes
+            X = np.roll(X, rank, axis=0) + 0.0
+            rng = np.random.default_rng(synth.SEED_BASE + 7919 * rank)
+            y = y + rng.normal(0, 1e-3, y.shape)
     _, N, d = X.shape
     peak = FP64_MFMA_PEAK_TFLOPS if dts == "f64" else FP32_MFMA_PEAK_TFLOPS
     ablation = False
@@ -148,7 +203,7 @@ def run_rank(args):
             time.sleep(0.002)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         sync()
 
@@ -159,17 +214,19 @@ def run_rank(args):
     for _ in range(args.steps):
         step()
     sync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     sync()
     dt_local = time.perf_counter() - t0
-    tall = torch.tensor([dt_local], device=cdev, dtype=torch.float64)
+    tall = torch.tensor([dt_local, float(B)], device=cdev, dtype=torch.float64)
     per_rank = [tall.clone() for _ in range(world)]
-    if world > 1:
+    if use_dist:
         dist.all_gather(per_rank, tall)
-        dist.all_reduce(tall, op=dist.ReduceOp.MAX)
-    dt = float(tall.item())
-    per_rank_fits = [B * args.steps / float(t.item()) for t in per_rank]
+        tmax = tall[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tall[0] = tmax[0]
+    dt = float(tall[0].item())
+    per_rank_fits = [float(t[1].item()) * args.steps / float(t[0].item()) for t in per_rank]
     if not dry and not ablation:   # timing ablations (-DCGP_ABLATION build + CGP_DBG) produce wrong factors on purpose
         assert int(W.dinfo.abs().sum().item()) == 0, "a fit reported a non-positive pivot"
 
@@ -180,25 +237,27 @@ def run_rank(args):
         summ = torch.stack([W.dlogml, 2.0 * W.dvar.to(torch.float64).max(1).values.sqrt(), W.dinfo.to(torch.float64)], 1)
     else:
         summ = torch.zeros((B, 3), dtype=torch.float64)
-    table = sharding.gather_summaries(summ.to(cdev), B * world)
+    table = sharding.gather_summaries(summ.to(cdev), B_total)
     ens = sharding.ensemble_stats(table)
-    assert table.shape[0] == B * world
+    assert table.shape[0] == B_total
 
     if rank == 0:
-        fits = B * world * args.steps
+        fits = B_total * args.steps
         f_chol, f_fit = fit_flops(N, d, M_TEST)
         value = fits / dt
         out = {
             "metric": "GP-fits/s", "value": value, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": dts, "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": dts, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: batch of independent fixed-theta GP fits, "
                                    f"N={N} d={d} M={M_TEST} kernel={'SE-ARD' if kid == 1 else 'SE-iso'} {dts}",
-                       "fits_per_gpu_per_step": B, "streams": args.streams, "N": N, "d": d, "M": M_TEST,
+                       "fits_per_gpu_per_step": B if not strong else B_total / world, "fits_per_step_all_ranks": B_total,
+                       "streams": args.streams, "N": N, "d": d, "M": M_TEST,
                        "single_fit_latency_ms": single_ms,
                        "fit_tflops": value * f_fit / 1e12, "cholesky_roofline_frac": value * f_chol / 1e12 / world / peak,
                        "inputs": "resident in HBM", "ensemble": ens,
-                       "ranks": world, "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                       "ranks": world, "collective_backend": ("rccl" if backend == "nccl" else backend) if use_dist else None,
+                       "collective_world": dist.get_world_size() if use_dist else None,
                        "per_rank_fits_per_s": per_rank_fits},
         }
         if dry:
@@ -207,11 +266,11 @@ def run_rank(args):
             out["ablation_build"] = True   # CGP_DBG in a -DCGP_ABLATION library: NOT a measurement of the product
         if not dry:
             out["roofline"], out["kernel_ms_per_step"] = W.roofline(peak)
-            if world == 1 and not args.no_extra:
+            if world == 1 and not args.no_extra and not strong:
                 out["config"]["extra"] = extras(engine, torch, dev, local, W)
             if not args.no_cpu and world == 1:   # rank 0 at N = 1 only: other ranks would wait on the host work
                 out["cpu_baseline"] = cpu_baseline(kid, X, y, Xs, th, args.cpu_sample, W.dmean, W.dvar, W.dlogml, f_fit)
-            if world == 1 and not args.no_extra:
+            if world == 1 and not args.no_extra and not strong:
                 ex3 = extras_cfg3(engine, torch, dev, local, W)
                 leg = ex3.pop("_cpu_leg", None)
                 if leg is not None and not args.no_cpu:
@@ -226,7 +285,7 @@ def run_rank(args):
                     out["roofline"]["traffic_committed"] = out["roofline"]["traffic"]
                     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = live
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -308,7 +367,11 @@ class Workload:
         upd = prof["update"]
         achieved = upd["flops"] / (upd["ms"] * 1e-3) / 1e12 if upd["ms"] > 0 else 0.0
         traffic, tsrc = pmc_traffic(self.B, self.N, self.dts)
-        rf = {"bound": "mfma", "kernel": "k_panel (syrk/gemm trailing update + fused Gram + in-register trmm)",
+        fused = self.dts != "f64" or self.B < 512   # the schedule the engine takes (cgp_engine.hip: FUSED64_BELOW)
+        label = ("k_panel (syrk/gemm trailing update + fused Gram + in-register trmm)" if not fused else
+                 "k_panel + diagonal tile (the same launches also finish / pre-update the next diagonal tiles: flops and time of "
+                 "that latency-bound factorisation are inside this figure)")
+        rf = {"bound": "mfma", "kernel": label, "diag_tile_inside_launches": fused,
               "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
               "traffic": traffic, "traffic_source": tsrc,
               "from": "HIP events around every k_panel launch, 2 extra profiled steps after the timed region and "
@@ -338,6 +401,20 @@ def pmc_traffic(B, N, dts):
     return None, None
 
 
+PROFILER_ENV_PREFIXES = ("ROCP_", "ROCPROF", "ROCPROFILER_", "ROCTX_", "ROCTRACER_")
+
+
+def under_profiler():
+    """True when this process was started under rocprofv3 / rocprofiler-sdk (its tool library is preloaded and has
+    initialised the GPU before main): starting ANOTHER profiler from here would inherit the preload, every hop of
+    `rocprofv3 -> env -> python3 -> app` would be an exec out of a GPU-initialised process (the pool forbids it), and
+    the nested passes would pollute the outer counters.  The live PMC passes are skipped then."""
+    pre = os.environ.get("LD_PRELOAD", "") + ":" + os.environ.get("ROCP_TOOL_LIBRARIES", "")
+    if "rocprofiler" in pre or "rocprof" in pre:
+        return True
+    return any(k.startswith(PROFILER_ENV_PREFIXES) for k in os.environ)
+
+
 def pmc_traffic_live(args):
     """HBM bytes per k_panel launch of THIS command, measured during this run: two child processes
     `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --steps 1 ...` (FETCH_SIZE and WRITE_SIZE in separate
@@ -345,17 +422,21 @@ def pmc_traffic_live(args):
     half-count, units KB).  Children, not exec: this process keeps its GPU context.  None if rocprofv3 is missing
     or a pass fails or overruns -- the committed builder-run figure then stays in the line."""
     import csv, glob, shutil, tempfile
-    if shutil.which("rocprofv3") is None or os.environ.get("CGP_BENCH_CHILD"):
+    if shutil.which("rocprofv3") is None or os.environ.get("CGP_BENCH_CHILD") or under_profiler():
         return None
     tmp = tempfile.mkdtemp(prefix="cgp_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu", "--no-extra", "--no-pmc",
              "--batch", str(args.batch), "--config", str(args.config)] + (["--n", str(args.n)] if args.n else [])
-    env = dict(os.environ, TMPDIR="/tmp", CGP_BENCH_CHILD="1")
+    # the children get a clean environment: nothing of a profiler that may be wrapping a parent survives
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(PROFILER_ENV_PREFIXES)}
+    env.update(TMPDIR="/tmp", CGP_BENCH_CHILD="1")
+    rocprof = shutil.which("rocprofv3")
     mean = {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
-            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child
+            # rocprofv3 is a `#!/usr/bin/env python3` script: run it with this interpreter, no `env` hop in between
+            cmd = [sys.executable, rocprof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child
             # own process group, so that an overrun ends the profiler AND the program it started (exact pgid, not a pattern)
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
@@ -518,15 +599,25 @@ def host_description():
         usable = len(os.sched_getaffinity(0))
     except Exception:
         usable = os.cpu_count() or 1
-    return {"cpu_model": model, "governor": gov, "logical_cpus": os.cpu_count(), "usable_cpus": usable}
+    quota = "unavailable"      # cgroup v2 CPU quota of this container: "<quota_us|max> <period_us>"
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+        q, per = quota.split()
+        if q != "max":
+            usable = max(1, min(usable, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return {"cpu_model": model, "governor": gov, "logical_cpus": os.cpu_count(), "usable_cpus": usable, "cgroup_cpu_max": quota}
 
 
 def cpu_baseline(kid, X, y, Xs, th, nsample, dmean, dvar, dlogml, f_fit, context_rows=True):
-    """The C oracle ('port' of the reference arithmetic, single thread like the reference's catkin build)
-    timed on this box's host cores on a bounded sample of the same windows (warm-ups, then
-    the MEDIAN of the per-fit times); its outputs also check the timed GPU outputs.  Context rows (not the
-    baseline): the same port with one window per host thread, and the numpy/scipy restatement on one and
-    on all LAPACK threads."""
+    """The oracle ("port" of the reference arithmetic) timed on this box's host cores, ONE thread like the
+    reference's catkin build, on a bounded sample of the same windows (warm-ups, then the MEDIAN of
+    the per-fit times).  Two single-thread implementations of the same restatement are timed -- oracle/gp_oracle.c
+    (plain C, gcc -O3 -march=native here) and oracle/gp_oracle.py on ONE LAPACK thread (dpotrf / dtrtrs: the
+    Eigen::LLT-class row) -- and the FASTER one is `value`: the honest single-thread denominator.  The C port's
+    outputs also check the timed GPU outputs.  Context row (not the baseline): the C port with one window per host
+    thread over every CPU the container may use (cgroup quota stated)."""
     import ctypes
     import statistics
     import tempfile
@@ -568,57 +659,49 @@ def cpu_baseline(kid, X, y, Xs, th, nsample, dmean, dvar, dlogml, f_fit, context
     med = statistics.median(times)
     tol = 1e-6 if str(dmean.dtype).endswith("float64") else 1e-3   # north_star parity bar
     assert worst < tol, f"timed GPU outputs differ from the oracle: max rel err {worst:.3e} >= {tol}"
-
-    base = {"value": 1.0 / med, "unit": "fits/s", "cores": 1, "kind": "port",
-            "sample": f"median of {reps} of the step's windows after {warm} warm-up(s) through oracle/gp_oracle.c "
-                      f"(gcc -O3 -march=native, 1 thread), {sum(times):.1f} s; {f_fit / med / 1e9:.2f} GFLOP/s",
-            "host": host, "gpu_vs_oracle_max_rel_err": worst}
+    rows = {"c_port_1_thread": {"value": 1.0 / med, "unit": "fits/s", "threads": 1,
+                                "sample": f"median of {reps} of the step's windows after {warm} warm-up(s) through oracle/gp_oracle.c "
+                                          f"(gcc -O3 -march=native), {sum(times):.1f} s; {f_fit / med / 1e9:.2f} GFLOP/s"}}
+    # the same restatement on one LAPACK thread (numpy/scipy: dpotrf, dtrtrs)
+    try:
+        from threadpoolctl import threadpool_limits
+        from oracle import gp_oracle as go
+        nl = 3 if context_rows else 2
+        with threadpool_limits(limits=1):
+            go.predict(go.fit(kid, th[0], X[0], y[0]), Xs[0])   # warm-up
+            ts = []
+            for b in range(nl):
+                t1 = time.perf_counter()
+                go.predict(go.fit(kid, th[b % nwin], X[b % nwin], y[b % nwin]), Xs[b % nwin])
+                ts.append(time.perf_counter() - t1)
+        m1 = statistics.median(ts)
+        rows["lapack_1_thread"] = {"value": 1.0 / m1, "unit": "fits/s", "threads": 1,
+                                   "sample": f"median of {nl} windows after 1 warm-up through oracle/gp_oracle.py, numpy/scipy LAPACK "
+                                             f"limited to ONE thread (threadpoolctl); {f_fit / m1 / 1e9:.2f} GFLOP/s"}
+    except Exception as e:
+        rows["lapack_1_thread"] = {"error": repr(e)}
+    best = max((k for k in rows if "value" in rows[k]), key=lambda k: rows[k]["value"])
+    base = {"value": rows[best]["value"], "unit": "fits/s", "cores": 1, "kind": "port",
+            "sample": f"the faster of two single-thread runs of the oracle: {best} -- " + rows[best]["sample"],
+            "single_thread_rows": rows, "host": host, "gpu_vs_oracle_max_rel_err": worst}
     if not context_rows:
         return base
-    # context row: one window per host thread (ctypes releases the GIL), >= 256 windows
-    allc = None
+    # context row: one window per host thread (ctypes releases the GIL), every CPU the container may use
     try:
         from concurrent.futures import ThreadPoolExecutor
-        ncore = max(1, min(host["usable_cpus"], 64))   # bounded: the visible count can exceed the container's CPU quota
-        nw = max(256, 4 * ncore) if med * 256 / ncore < 20.0 else 4 * ncore   # keep the row under ~20 s on small hosts
+        ncore = max(1, host["usable_cpus"])   # affinity mask capped by the cgroup quota (host["cgroup_cpu_max"])
+        nw = max(256, 2 * ncore) if med * max(256, 2 * ncore) / ncore < 20.0 else 2 * ncore   # keep the row under ~20 s on small hosts
         with ThreadPoolExecutor(max_workers=ncore) as ex:
             list(ex.map(lambda i: run(i)[1], range(ncore)))   # warm-up round
             t2 = time.perf_counter()
             rcs = list(ex.map(lambda i: run(i)[1], range(nw)))
             el2 = time.perf_counter() - t2
         assert not any(rcs)
-        allc = {"value": nw / el2, "unit": "fits/s", "threads": ncore,
-                "kind": "port, one window per host thread (threads over the batch; the container's CPU quota applies)",
-                "sample": f"{nw} windows after a {ncore}-window warm-up, {el2:.1f} s"}
+        base["port_threads_over_batch"] = {"value": nw / el2, "unit": "fits/s", "threads": ncore,
+                                           "kind": "C port, one window per host thread, all usable CPUs of the container",
+                                           "sample": f"{nw} windows after a {ncore}-window warm-up, {el2:.1f} s"}
     except Exception as e:
-        allc = {"error": repr(e)}
-    # context rows: numpy/scipy restatement (LAPACK dpotrf / dtrtrs), 1 thread = the "Eigen-LLT-class" row, and all threads
-    lap1 = lapn = None
-    try:
-        from oracle import gp_oracle as go
-
-        def lap(nrep):
-            go.predict(go.fit(kid, th[0], X[0], y[0]), Xs[0])   # warm-up
-            ts = []
-            for b in range(nrep):
-                t1 = time.perf_counter()
-                go.predict(go.fit(kid, th[b % nwin], X[b % nwin], y[b % nwin]), Xs[b % nwin])
-                ts.append(time.perf_counter() - t1)
-            return statistics.median(ts)
-        try:
-            from threadpoolctl import threadpool_limits
-            with threadpool_limits(limits=1):
-                m1 = lap(3)
-            lap1 = {"value": 1.0 / m1, "unit": "fits/s", "threads": 1, "kind": "numpy/scipy LAPACK restatement, 1 BLAS thread "
-                    "(the Eigen::LLT-class single-thread row)", "sample": "median of 3 windows after 1 warm-up"}
-        except Exception as e:
-            lap1 = {"error": repr(e)}
-        mn = lap(4)
-        lapn = {"value": 1.0 / mn, "unit": "fits/s", "threads": host["usable_cpus"], "kind": "numpy/scipy LAPACK restatement, "
-                "default BLAS threading, one window at a time", "sample": "median of 4 windows after 1 warm-up"}
-    except Exception as e:   # the baseline proper does not depend on it
-        lapn = {"error": repr(e)}
-    base.update({"port_threads_over_batch": allc, "lapack_1_thread": lap1, "lapack_all_threads": lapn})
+        base["port_threads_over_batch"] = {"error": repr(e)}
     return base
 
 

@@ -1,4 +1,4 @@
-"""corenav-gp_amd: MI355X-native engine for the corenav-GP slip-GP hot path.
+"""corenav_gp_amd: MI355X-native engine for the corenav-GP slip-GP hot path.
 
 Host side mirrors the reference's own surface for this path:
   * gp_slip_node  -- drop-in for core_navigation/script/gp_slip_node.py (callback -> GP_Output)

@@ -69,6 +69,8 @@ struct cgp_ctx {
   void *dlatimg = nullptr;  //                  pre-updated diagonal tiles [lat_cap][2][LAT_IMG_MAX][DPART]
   double *dmacc = nullptr;  // [max_batch][2][max_m] running predictive sums (throughput schedule, fp64)
   void *ddiagimg = nullptr;  // [max_batch][2][DPART] pre-updated diagonal tiles (throughput schedule, diag_next)
+  void *dpanimg = nullptr;   // [min(max_batch, mid cap)][2][DPART] pre-updated kind-A panel tiles (k_panel kind C)
+  int mid_cap = 0;
   // cgp_fit_predict_batch staging, grown on demand and kept: pinned host buffers (hipHostMalloc) so the
   // H2D / D2H copies are real asynchronous DMA, and a raw fp64 device buffer the pack kernels read
   void *pin_in = nullptr, *pin_out = nullptr, *draw = nullptr;
@@ -147,6 +149,17 @@ struct Launcher {
 // (tools/lat_crossover.sh) is 16 fits in fp64 and 24 in fp32.
 constexpr int LAT_FITS_F64 = 16, LAT_FITS_F32 = 24;
 constexpr int FUSED64_BELOW = 512;                // fp64 throughput schedule: diagonal tiles inside the panel launches below this batch
+// Calls too small to fill the chip (a launch then lasts as long as its longest workgroup chain): the next launch's
+// kind-A tile is pre-updated by a kind-C workgroup (k_panel), and fp32 takes the deep-prefetch loops (DEEP).
+constexpr int MID_FITS_F64 = 128, MID_FITS_F32 = 192;
+constexpr int MID_FITS_ALLOC = kAbBuild ? 512 : (MID_FITS_F64 > MID_FITS_F32 ? MID_FITS_F64 : MID_FITS_F32);
+template <typename T> inline int mid_fits() {     // ablation build: CGP_MID_FITS moves the crossover (measurement)
+  if constexpr (kAbBuild) {
+    const char *e = getenv("CGP_MID_FITS");
+    if (e) return std::max(0, std::min(atoi(e), MID_FITS_ALLOC));
+  }
+  return sizeof(T) == 8 ? MID_FITS_F64 : MID_FITS_F32;
+}
 constexpr int LAT_FITS_ALLOC = kAbBuild ? 64 : LAT_FITS_F32;  // slabs are sized for min(this, max_batch) fits
 template <typename T> inline int lat_fits() {     // ablation build: CGP_LAT_FITS moves the crossover (measurement)
   if constexpr (kAbBuild) {
@@ -178,6 +191,7 @@ template <typename T> int set_lds_attrs(int device) {
   ok = ok && set(reinterpret_cast<const void *>(&k_trmm_sk<T>), upd);
   ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T>), paneldiag_lds_bytes<T>());
   ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true>), paneldiag_lds_bytes<T>());
+  ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, true>), paneldiag_lds_bytes<T>());
 #ifdef CGP_AB
   ok = ok && set(reinterpret_cast<const void *>(&k_diag<T>), tile);
 #endif
@@ -216,6 +230,7 @@ template <typename T> FitArgs group_view(const FitArgs &a, int g0) {
   v.Lw = const_cast<void *>(adv(a.Lw, (size_t)g0 * a.lw_stride));
   v.Winv = const_cast<void *>(adv(a.Winv, (size_t)g0 * a.winv_stride));
   v.dpart = const_cast<void *>(adv(a.dpart, (size_t)g0 * 2 * DPART));
+  v.pimg = const_cast<void *>(adv(a.pimg, (size_t)g0 * 2 * DPART));
   v.X = adv(a.X, (size_t)g0 * a.d * a.N);
   v.Xs = adv(a.Xs, (size_t)g0 * a.d * a.M);
   v.y = adv(a.y, (size_t)g0 * a.N);
@@ -263,6 +278,13 @@ const SchedSwitches &sched_switches() {
     return w;
   }();
   return sw;
+}
+
+// k_panel<T, true> has two builds: the full-batch one, and the one for calls that leave CUs underfilled (kinds C /
+// image-A compiled in; fp32: deep-prefetch loops)
+template <typename T> void launch_panel_diag(bool mid, dim3 grid, hipStream_t s, const FitArgs &a, int k) {
+  if (mid) hipLaunchKernelGGL((k_panel<T, true, true, true>), grid, dim3(256), paneldiag_lds_bytes<T>(), s, a, k);
+  else hipLaunchKernelGGL((k_panel<T, true>), grid, dim3(256), paneldiag_lds_bytes<T>(), s, a, k);
 }
 
 template <typename T> void launch_diag(const FitArgs &a, int nfits, int k, bool fat, hipStream_t s) {
@@ -415,6 +437,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // batch (3.3 ms per N = 2048 schedule), so below FUSED64_BELOW fits per call the fused form wins there too
   // (batch 32 +26 %, 64 +15 %, 128 +6 %, 256 +0.2 %, 512 -0.7 %).
   const bool fused64 = sw.fused_diag || batch < FUSED64_BELOW;
+  const bool mid = batch <= std::min(mid_fits<T>(), c->mid_cap);  // the whole call (the images are indexed by fit)
   const bool split_diag = sw.split_diag || !in_rows || (sizeof(T) == 8 && !fused64);
   for (int k = 0; k < a.NT; ++k) {
     const int gx_t = (in_rows ? a.NT - k - 1 : 0) + a.ET;
@@ -431,12 +454,21 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
         continue;
       }
       const bool hasA = k + 1 < a.NT, hasB = k + 2 < a.NT && k >= 1;
+      const bool hasC = mid && k + 2 < a.NT, imgA = mid && hasA && k >= 1;  // launch k - 1 had a kind C iff k + 1 < NT
       FitArgs ak = ga[g];
-      ak.diag_slots = (hasA ? 1 : 0) | (hasB ? 2 : 0);
-      ak.diag_stride = sizeof(T) == 8 ? 2 : 4;  // workgroups per CU of k_panel<T, true> (LDS / VGPR bound)
-      const int gx = gx_t + (hasB ? 1 : 0);  // gx_t already counts row tile k + 1 (kind A)
-      L[g].begin(0, panel_flops(a.N, a.M, a.d, k, true, gb[g]) + (hasA ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0), k);
-      hipLaunchKernelGGL((k_panel<T, true>), dim3(gx, gb[g]), dim3(256), paneldiag_lds_bytes<T>(), gs[g], ak, k);
+      ak.diag_slots = (hasA ? 1 : 0) | (hasB ? 2 : 0) | (hasC ? 4 : 0) | (imgA ? 8 : 0);
+      ak.diag_stride = sizeof(T) == 8 || mid ? 2 : 4;  // workgroups per CU of k_panel<T, true> (LDS / VGPR bound)
+      const int gx = gx_t + (hasB ? 1 : 0) + (hasC ? 1 : 0);  // gx_t already counts row tile k + 1 (kind A)
+      // algorithmic flops of THIS launch: kind C does the part of tile (k + 2, k + 1) that kind A of launch k + 1 no longer does
+      double fl = panel_flops(a.N, a.M, a.d, k, true, gb[g]) + (hasA ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0);
+      auto tile_part = [&](int kc, int ncols) {  // Gram + `ncols` inner columns of one 128-row tile of block column kc, all fits
+        const double w = std::min(TS, a.N - kc * TS), rows = std::min(TS, a.N - (kc + 1) * TS);
+        return gb[g] * rows * w * (2.0 * ncols + (3.0 * a.d + 2.0));
+      };
+      if (imgA) fl -= tile_part(k, (k - 1) * TS);
+      if (hasC) fl += tile_part(k + 1, k * TS);
+      L[g].begin(0, fl, k);
+      launch_panel_diag<T>(mid, dim3(gx, gb[g]), gs[g], ak, k);
       L[g].end();
     }
   }
@@ -476,6 +508,7 @@ FitArgs base_args(cgp_ctx *c, int N, int d, int M, int kid, int include_noise) {
   a.alpha_stride = c->alpha_stride;
   a.prep = c->dprep;
   a.dpart = c->ddiagimg;
+  a.pimg = c->dpanimg;
   a.dbgbuf = c->ddbg;
   a.N = N;
   a.d = d;
@@ -581,7 +614,7 @@ int upload_theta(cgp_ctx *c, const double *theta, int theta_stride, int nth, int
 
 extern "C" {
 
-int cgp_abi_version(void) { return 1; }
+int cgp_abi_version(void) { return CGP_ABI_VERSION; }
 
 const char *cgp_strerror(int code) {
   switch (code) {
@@ -651,6 +684,8 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc(&c->dlatimg, (size_t)c->lat_cap * 2 * LAT_IMG_MAX * DPART * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dmacc, sizeof(double) * 2 * B * std::max(c->max_m, 1)) == hipSuccess;
   ok = ok && hipMalloc(&c->ddiagimg, B * 2 * DPART * c->esz) == hipSuccess;
+  c->mid_cap = std::min(MID_FITS_ALLOC, max_batch);
+  ok = ok && hipMalloc(&c->dpanimg, (size_t)c->mid_cap * 2 * DPART * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->ddbg, DBG_SLOTS * sizeof(long long)) == hipSuccess;
   ok = ok && hipMemset(c->ddbg, 0, DBG_SLOTS * sizeof(long long)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dprep, B * PREP_N * sizeof(double)) == hipSuccess;
@@ -672,7 +707,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg, c->dpanimg};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {

@@ -9,11 +9,11 @@
 // whose factor panel Lw holds  L  (rows < N_pad),  V^T = (L^-1 K*)^T  and  z^T = (L^-1 y)^T.
 // Then  mean = V^T z,  var = k** - |V_m|^2,  logML = -0.5 z'z - sum log L_ii - N/2 log 2pi.
 // This replaces GPy's kern.K / jitchol(dpotrf) / dpotrs / dpotri / predict chain that
-// gp_slip_node.py:31-49 reaches with three kernels per 128-column block step:
-//   k_update : S(i,k) = Gram(i,k) - sum_{j<k} L(i,j) L(k,j)^T     fp64/fp32 MFMA 16x16x4, LDS-tiled
-//   k_potf2  : S(k,k) = L(k,k) L(k,k)^T  and  W_k = L(k,k)^-1        one workgroup per fit, LDS-resident
-//   k_trmm   : L(i,k) = S(i,k) W_k^T                                   triangular MFMA product
-// and k_finalize for mean / variance / log marginal likelihood, k_alpha for alpha = L^-T z.
+// gp_slip_node.py:31-49 reaches.  This header holds the shared pieces (precision traits, the
+// 16x16 diagonal-block factorisation, potf2_tile, k_finalize, k_alpha, k_pack_soa); the schedules -- per
+// 128-column block step  S(i,k) = Gram(i,k) - sum_{j<k} L(i,j) L(k,j)^T  kept in MFMA accumulators,
+// L(i,k) = S(i,k) W_k^T in registers, and the diagonal tile's potf2 + inverse W_k = L(k,k)^-1 -- are in
+// cgp_kernels_fused.hpp (k_panel, k_diag_lean, k_tile_sk, k_trmm_sk, k_grad).
 //
 // Storage: Lw is column-major, leading dimension ld (multiple of 128), one slab per fit.
 // Inputs are SoA per fit: X[d][N], Xs[d][M], y[N].
@@ -69,7 +69,9 @@ struct FitArgs {
                          // reads the whole of V
   int tile_off;          // first block-tile index of this launch (split panel launches, A/B overlap schedule)
   void *dpart;           // [batch][2][DPART] register images of pre-updated diagonal tiles (see diag_next)
-  int diag_slots;        // k_panel<T, true>: bit 0 = the launch finishes diagonal tile k+1, bit 1 = pre-updates tile k+2
+  void *pimg;            // [batch][2][DPART] register images of pre-updated kind-A panel tiles (k_panel<T, true>, kind C)
+  int diag_slots;        // k_panel<T, true>: 1 = the launch finishes diagonal tile k+1, 2 = pre-updates tile k+2,
+                         // 4 = pre-updates the next launch's kind-A tile (k+2, k+1), 8 = kind A starts from that image
   int diag_stride;       // k_panel<T, true>: workgroups per CU (one block of 256 ids in `stride` holds the finishers)
   int xid;               // 1: the M (= N) "test rows" are the identity, so the extra block becomes (L^-1)^T (gradient mode)
   double *gpart;         // [batch][pairs][GRAD_N] per-tile-pair partial sums of k_grad
@@ -211,16 +213,6 @@ __device__ __forceinline__ void tile_fit_of_block(int &t, int &b) {
   }
 }
 
-// readlane for scalars of either precision (lane index must be wave-uniform)
-__device__ __forceinline__ float rdlane(float v, int l) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-__device__ __forceinline__ double rdlane(double v, int l) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
-
 // exp(x) for x <= 0 (every covariance exponent is -0.5 r^2): n = rint(x log2 e), r = x - n ln2 in
 // two pieces, degree-13 Horner polynomial on |r| <= ln2/2, v_ldexp for 2^n (denormal-exact).  The
 // argument is clamped at -800 (result 0) instead of being special-cased.  Coefficients live in
@@ -299,64 +291,39 @@ template <typename T>
 __device__ __forceinline__ void factor_block16(T (&a)[DB], T (&w)[DB], int &bad, int pivot_base, int l15) {
   using P = Prec<T>;
   T rinv[DB];
-  if constexpr (true) {
-    static_for<0, DB>([&](auto jc) {
-      constexpr int J = decltype(jc)::value;
-      T dj = mov_bcast<J>(a[J]);
-      const bool ok = dj > T(0);
-      if (!ok && bad == 0) bad = pivot_base + J + 1;
-      dj = ok ? dj : T(1);
-      T rs;
-      if constexpr (sizeof(T) == 8) rs = rsqrt3(dj);
-      else rs = P::rsqrt_(dj);
-      rinv[J] = rs;
-      const T l = (ok ? a[J] : ((l15 == J) ? T(1) : a[J])) * rs;   // lane J's a[J] is the pivot itself
-      a[J] = l;
-      const T nl = -l;
-      static_for<J + 1, DB>([&](auto cc) {
-        constexpr int C = decltype(cc)::value;
-        fmac_bcast<C, C == J + 1>(a[C], l, nl);
-      });
+  static_for<0, DB>([&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    T dj = mov_bcast<J>(a[J]);
+    const bool ok = dj > T(0);
+    if (!ok && bad == 0) bad = pivot_base + J + 1;
+    dj = ok ? dj : T(1);
+    T rs;
+    if constexpr (sizeof(T) == 8) rs = rsqrt3(dj);
+    else rs = P::rsqrt_(dj);
+    rinv[J] = rs;
+    const T l = (ok ? a[J] : ((l15 == J) ? T(1) : a[J])) * rs;   // lane J's a[J] is the pivot itself
+    a[J] = l;
+    const T nl = -l;
+    static_for<J + 1, DB>([&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      fmac_bcast<C, C == J + 1>(a[C], l, nl);
     });
-    // right-looking forward substitution for column l15 of the inverse: independent updates per step
-    T t[DB];
+  });
+  // right-looking forward substitution for column l15 of the inverse: independent updates per step
+  T t[DB];
 #pragma unroll
-    for (int i = 0; i < DB; ++i) t[i] = (i == l15) ? T(1) : T(0);
-    static_for<0, DB>([&](auto qc) {
-      constexpr int Q = decltype(qc)::value;
-      w[Q] = t[Q] * rinv[Q];
-      const T nw = -w[Q];
-      static_for<Q + 1, DB>([&](auto ic) {
-        constexpr int I = decltype(ic)::value;
-        fmac_bcast<I, false>(t[I], a[Q], nw);
-      });
+  for (int i = 0; i < DB; ++i) t[i] = (i == l15) ? T(1) : T(0);
+  static_for<0, DB>([&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    w[Q] = t[Q] * rinv[Q];
+    const T nw = -w[Q];
+    static_for<Q + 1, DB>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      fmac_bcast<I, false>(t[I], a[Q], nw);
     });
+  });
 #pragma unroll
-    for (int i = 0; i < DB; ++i) w[i] = (i < l15) ? T(0) : w[i];
-  } else {
-#pragma unroll
-    for (int j = 0; j < DB; ++j) {
-      T dj = rdlane(a[j], j);
-      if (!(dj > T(0))) {
-        if (bad == 0) bad = pivot_base + j + 1;
-        dj = T(1);
-      }
-      const T rs = P::rsqrt_(dj);
-      rinv[j] = rs;
-      const T l = (l15 == j) ? dj * rs : a[j] * rs;
-      a[j] = l;
-#pragma unroll
-      for (int c = j + 1; c < DB; ++c) a[c] -= l * rdlane(l, c);
-    }
-#pragma unroll
-    for (int i = 0; i < DB; ++i) {
-      T s = 0;
-#pragma unroll
-      for (int q = 0; q < DB; ++q)
-        if (q < i) s += rdlane(a[q], i) * w[q];
-      w[i] = (i < l15) ? T(0) : ((i == l15) ? rinv[i] : -s * rinv[i]);
-    }
-  }
+  for (int i = 0; i < DB; ++i) w[i] = (i < l15) ? T(0) : w[i];
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -294,9 +294,14 @@ __device__ __forceinline__ void mfma_rowpanel_loop_rdirect(typename Prec<T>::acc
 constexpr int TRI_PD = 2;  // chunks in flight ahead of the one being multiplied
 __device__ __forceinline__ constexpr int tri_buf(int i) { return i * KT * LDST; }
 
-template <typename T>
+// DEEP: the chunk goes HBM -> LDS by LDS-DMA (no VGPR staging), which is what lets the loop run TRI_PD chunks
+// ahead.  fp64: one 1 KiB dwordx4 wave-instruction per column; fp32: two 256-byte dword wave-instructions (a
+// 512-byte column does not fill a dwordx4 one and the padded LDS columns are not contiguous).  tri_dma_loads<T>()
+// wave-instructions per wave and chunk.
+template <typename T> constexpr int tri_dma_loads() { return sizeof(T) == 8 ? KT / 4 : KT / 2; }
+template <typename T, bool DEEP = sizeof(T) == 8>
 __device__ __forceinline__ void stage_chunk_tri(const T *gR, size_t ldR, int chunk, T *buf, int tid) {
-  if constexpr (sizeof(T) == 8) {
+  if constexpr (DEEP) {
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void gbl_void;
     const int lane = tid & 63;
@@ -304,8 +309,13 @@ __device__ __forceinline__ void stage_chunk_tri(const T *gR, size_t ldR, int chu
 #pragma unroll
     for (int i = 0; i < KT / 4; ++i) {
       const int col = wave * (KT / 4) + i;
-      __builtin_amdgcn_global_load_lds((gbl_void *)(gR + (size_t)(chunk * KT + col) * ldR + lane * 2),
-                                       (lds_void *)(buf + col * LDST), 16, 0, 0);
+      const T *src = gR + (size_t)(chunk * KT + col) * ldR;
+      if constexpr (sizeof(T) == 8) {
+        __builtin_amdgcn_global_load_lds((gbl_void *)(src + lane * 2), (lds_void *)(buf + col * LDST), 16, 0, 0);
+      } else {
+        __builtin_amdgcn_global_load_lds((gbl_void *)(src + lane), (lds_void *)(buf + col * LDST), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void *)(src + 64 + lane), (lds_void *)(buf + col * LDST + 64), 4, 0, 0);
+      }
     }
   } else {
     // fp32: a 512-byte column does not fill a 1 KiB LDS-DMA wave-instruction; 32 bytes per thread through registers
@@ -316,7 +326,7 @@ __device__ __forceinline__ void stage_chunk_tri(const T *gR, size_t ldR, int chu
 }
 
 // One wavefront's share, W = wave index as a compile-time constant so the MFMA set is static.
-template <typename T, int W>
+template <typename T, int W, bool DEEP>
 __device__ __forceinline__ void syrk_tri_wave(typename Prec<T>::acc_t (&acc)[NCB][2], const T *gR, size_t ldR, int nchunk,
                                               T *smem, int tid) {
   using P = Prec<T>;
@@ -339,14 +349,17 @@ __device__ __forceinline__ void syrk_tri_wave(typename Prec<T>::acc_t (&acc)[NCB
     }
   };
 
-  if constexpr (sizeof(T) == 8) {
+  if constexpr (DEEP) {
     // prefetch distance TRI_PD over a ring of TRI_PD + 1 (LDS-DMA): with one or two workgroups per CU nothing
     // else hides the HBM latency
     for (int c = 0; c < nchunk; ++c) {
-      // chunk c has landed when at most the 4 loads of chunk c + 1 are still in flight
-      if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      if (c + TRI_PD < nchunk) stage_chunk_tri<T>(gR, ldR, c + TRI_PD, smem + tri_buf((c + TRI_PD) % (TRI_PD + 1)), tid);
+      // chunk c has landed when at most the loads of chunk c + 1 (4 fp64 / 8 fp32) are still in flight
+      if (c + 1 < nchunk) {
+        if constexpr (sizeof(T) == 8) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      static_assert(tri_dma_loads<double>() == 4 && tri_dma_loads<float>() == 8, "vmcnt constants");
+      if (c + TRI_PD < nchunk) stage_chunk_tri<T, true>(gR, ldR, c + TRI_PD, smem + tri_buf((c + TRI_PD) % (TRI_PD + 1)), tid);
       compute(smem + tri_buf(c % (TRI_PD + 1)));
     }
   } else {
@@ -366,17 +379,23 @@ __device__ __forceinline__ void syrk_tri_wave(typename Prec<T>::acc_t (&acc)[NCB
   }
 }
 
-// Chunks 0 .. TRI_PD-1 must have been issued with stage_chunk_tri before the call.
-template <typename T>
+// DEEP: chunks 0 .. TRI_PD-1 must have been issued with stage_chunk_tri<T, true> before the call (tri_prologue);
+// otherwise chunk 0 must have been written by stage_chunk_tri<T, false>.
+template <typename T, bool DEEP = sizeof(T) == 8>
 __device__ __forceinline__ void mfma_syrk_tri_loop(typename Prec<T>::acc_t (&acc)[NCB][2], const T *gR, size_t ldR,
                                                    int nchunk, T *smem, int tid) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   switch (wave) {
-    case 0: syrk_tri_wave<T, 0>(acc, gR, ldR, nchunk, smem, tid); break;
-    case 1: syrk_tri_wave<T, 1>(acc, gR, ldR, nchunk, smem, tid); break;
-    case 2: syrk_tri_wave<T, 2>(acc, gR, ldR, nchunk, smem, tid); break;
-    default: syrk_tri_wave<T, 3>(acc, gR, ldR, nchunk, smem, tid); break;
+    case 0: syrk_tri_wave<T, 0, DEEP>(acc, gR, ldR, nchunk, smem, tid); break;
+    case 1: syrk_tri_wave<T, 1, DEEP>(acc, gR, ldR, nchunk, smem, tid); break;
+    case 2: syrk_tri_wave<T, 2, DEEP>(acc, gR, ldR, nchunk, smem, tid); break;
+    default: syrk_tri_wave<T, 3, DEEP>(acc, gR, ldR, nchunk, smem, tid); break;
   }
+}
+template <typename T, bool DEEP = sizeof(T) == 8>
+__device__ __forceinline__ void tri_prologue(const T *gR, size_t ldR, int nchunk, T *smem, int tid) {
+  if (nchunk > 0) stage_chunk_tri<T, DEEP>(gR, ldR, 0, smem + tri_buf(0), tid);
+  if (DEEP && nchunk > 1) stage_chunk_tri<T, DEEP>(gR, ldR, 1, smem + tri_buf(1), tid);
 }
 
 // General exp (|x| small enough not to overflow): the covariance exponent with log(amplitude)
@@ -766,7 +785,7 @@ __device__ __forceinline__ void acc_image(typename Prec<T>::acc_t (&acc)[NCB][2]
     }
 }
 
-template <typename T, int MODE, bool TRI>
+template <typename T, int MODE, bool TRI, bool DEEP = sizeof(T) == 8>
 __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
                                           T *__restrict__ Lw, int b, int kn, int tid) {
   using P = Prec<T>;
@@ -797,14 +816,12 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
   {
     GramPre<T> gp;
     if (!from_image) gram_prefetch<T>(p, b, kn, kn, tid, gp);
-    if constexpr (TRI) {
-      if (nchunk > 0) stage_chunk_tri<T>(gR, (size_t)ld, 0, smem + tri_buf(0), tid);
-      if (sizeof(T) == 8 && nchunk > 1) stage_chunk_tri<T>(gR, (size_t)ld, 1, smem + tri_buf(1), tid);  // fp64: DMA ring, 2 ahead
-    } else if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gR, (size_t)ld, smem, tid);
+    if constexpr (TRI) tri_prologue<T, DEEP>(gR, (size_t)ld, nchunk, smem, tid);  // DEEP: DMA ring, 2 chunks ahead
+    else if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gR, (size_t)ld, smem, tid);
     if (from_image) acc_image<T, TRI, false>(acc, img, tid);
     else gram_apply<T, TRI>(p, acc, smem + CH2, b, kn, kn, tid, gp);
   }
-  if constexpr (TRI) mfma_syrk_tri_loop<T>(acc, gR, (size_t)ld, nchunk, smem, tid);
+  if constexpr (TRI) mfma_syrk_tri_loop<T, DEEP>(acc, gR, (size_t)ld, nchunk, smem, tid);
   else mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gR, (size_t)ld, nchunk, smem, tid);
   if constexpr (MODE == DIAG_PARTIAL) {
     acc_image<T, TRI, true>(acc, img, tid);
@@ -848,7 +865,7 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
 // k_diag_lean: the diagonal tile in the LDS budget of a panel workgroup (two per CU), so that with
 // two or more fits per CU one workgroup's factorisation latency runs under the other's MFMA loop.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void k_diag_lean(FitArgs p, int k) {
+__global__ __launch_bounds__(256, 2) void k_diag_lean(FitArgs p, int k) {  // (k = 0 in the shipped schedules: no update loop, DEEP is moot)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const int b = blockIdx.x;
@@ -947,29 +964,65 @@ __device__ __forceinline__ void load_tile(typename Prec<T>::acc_t (&acc)[NCB][2]
 // both precisions, but fp32 measured 4.5 % slower with it (85.1k vs 89.1k fits/s at N = 1024: 156 VGPRs
 // cost an occupancy step and a 512-byte column needs two 256-byte LDS-DMA instructions), so fp32
 // keeps the register-staged loop.
-constexpr bool RDIRECT = true;
+
+// Kind C of k_panel<T, true, DEEP, MID> in launch k: tile (k + 2, k + 1) -- the NEXT launch's kind-A tile -- with the
+// block columns < k (final since the previous launch): acc = -G + sum_{j<k} L(k+2, j) L(k+1, j)^T, left as a raw
+// register image in p.pimg[(k + 1) & 1].  Same arithmetic, in the same order, as the one-workgroup form.
+template <typename T, bool DEEP>
+__device__ __forceinline__ void panel_partial(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem, int b,
+                                              int k, int tid) {
+  constexpr int CH2 = 2 * KT * LDST;
+  const int kc = k + 1, rt = k + 2, ld = p.ld, nchunk = k * (TS / KT);
+  const T *Lw = reinterpret_cast<const T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const T *gR = Lw + (size_t)rt * TS, *gC = Lw + (size_t)kc * TS;
+  GramPre<T> gp;
+  gram_prefetch<T>(p, b, kc, rt, tid, gp);
+  if constexpr (DEEP) {
+    RowFrag<T> rf;
+    T *zs = smem + 4 * KT * LDST;  // the loop folds its newest block column into running sums nobody reads here
+    if (tid < TS) zs[tid] = T(0);
+    T ms[4] = {T(0), T(0), T(0), T(0)};
+    rdirect_prologue<T>(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+    gram_apply<T>(p, acc, smem + CH2, b, kc, rt, tid, gp);
+    mfma_rowpanel_loop_rdirect<T>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
+  } else {
+    if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
+    gram_apply<T>(p, acc, smem + CH2, b, kc, rt, tid, gp);
+    mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+  }
+  acc_image<T, false, true>(acc, reinterpret_cast<T *>(p.pimg) + ((size_t)b * 2 + (kc & 1)) * DPART, tid);
+}
 
 // DIAGNEXT (throughput schedule, fit launches): besides the row tiles below the diagonal and the extra
 // tiles the launch carries, per fit, the workgroup that finishes the next diagonal tile (kind A: row tile
-// k + 1, then DIAG_FINISH of tile k + 1) and the one that pre-updates the one after (kind B: DIAG_PARTIAL of
-// tile k + 2); both kinds get the lowest linear block ids, i.e. are dispatched first, so their longer
-// chains end inside the launch.  grid.x = A + B + other tiles; p.diag_slots = {has A, has B}.
-template <typename T, bool DIAGNEXT = false>
-__global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p, int k) {
+// k + 1, then DIAG_FINISH of tile k + 1), the one that pre-updates the one after (kind B: DIAG_PARTIAL of
+// tile k + 2) and -- calls too small to fill the chip, where a launch lasts as long as its kind-A chain -- the
+// one that pre-updates the NEXT launch's kind-A tile (kind C: tile (k + 2, k + 1) with the block columns < k,
+// left as a register image in p.pimg; the next launch's kind A then only adds block column k, so the chain of
+// a block step no longer grows with k).  Kinds A, B, C get the lowest linear block ids, i.e. are dispatched
+// first, so their longer chains end inside the launch.  grid.x = A + B + C + other tiles;
+// p.diag_slots = {1: has A, 2: has B, 4: has C, 8: kind A starts from the image of the previous launch's C}.
+// DEEP: row panel straight to registers + LDS-DMA column panel two chunks ahead (fp64 always; fp32 for calls
+// that leave most CUs with one or two workgroups, where nothing else hides the memory latency -- with four
+// workgroups per CU the register-staged loop is 4.5 % faster: 128 instead of 156 VGPRs).
+// MID: kinds C / image-A compiled in (their branches cost registers the full-batch build cannot spare).
+template <typename T, bool DIAGNEXT = false, bool DEEP = sizeof(T) == 8, bool MID = false>
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? (DEEP ? (MID ? 2 : 3) : 4) : 2) void k_panel(FitArgs p, int k) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const int tid = threadIdx.x;
   int bt, b, rt;
-  bool finish_next = false;
+  int c_first = 0;             // first 16-column chunk of the inner dimension this workgroup applies
+  bool finish_next = false, from_image = false;
   acc_t acc[NCB][2];
   SpanClock sc;
   sc.enter(p, k, tid);
   if constexpr (DIAGNEXT) {
     const int Tg = gridDim.x, B = gridDim.y;
     const int lin = blockIdx.y * Tg + blockIdx.x;
-    const int nA = (p.diag_slots & 1) ? B : 0, nB = (p.diag_slots & 2) ? B : 0;
+    const int nA = (p.diag_slots & 1) ? B : 0, nB = (p.diag_slots & 2) ? B : 0, nC = (MID && (p.diag_slots & 4)) ? B : 0;
     // Dispatch follows the linear block id and an XCD hands consecutive workgroups to different CUs, so ids
     // are dealt in blocks of 256 (8 XCDs x 32 CUs): every `stride`-th block (stride = workgroups per CU)
     // is a block of kind-A workgroups and the blocks between hold the other tiles.  A CU then hosts one
@@ -983,21 +1036,29 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
       else io = (j - before) * 256 + r;
     } else if (lin < nA) ia = lin;
     else io = lin - nA;
-    if (CGP_DBG_ON(p, 65536) && (ia >= 0 || io < nB) && !(ia >= 0 && false)) {  // timing probe: no diagonal work in the launch
+    if (CGP_DBG_ON(p, 65536) && (ia >= 0 || io < nB)) {  // timing probe: no diagonal work in the launch
       if (ia < 0) return;
     }
     if (ia >= 0) {
       b = ia;
       rt = k + 1;
       finish_next = !CGP_DBG_ON(p, 65536);
+      if (MID && (p.diag_slots & 8)) {  // tile (k + 1, k) minus block column k - 1 is waiting in the image
+        from_image = true;
+        c_first = (k - 1) * (TS / KT);
+      }
     } else if (io < nB) {
       b = io;
       T *LwB = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
-      diag_next<T, DIAG_PARTIAL, kTriDiag>(p, acc, smem, LwB, b, k + 2, tid);
+      diag_next<T, DIAG_PARTIAL, kTriDiag, DEEP>(p, acc, smem, LwB, b, k + 2, tid);
+      sc.leave(p, k, tid);
+      return;
+    } else if (MID && io < nB + nC) {
+      panel_partial<T, DEEP>(p, acc, smem, io - nB, k, tid);  // kind C (a path of its own, as kind B: the main path keeps its registers)
       sc.leave(p, k, tid);
       return;
     } else {
-      const int l2 = io - nB, To = Tg - (nA ? 1 : 0) - (nB ? 1 : 0);  // the other tiles, XCD-steered
+      const int l2 = io - nB - nC, To = Tg - (nA ? 1 : 0) - (nB ? 1 : 0) - (nC ? 1 : 0);  // the other tiles, XCD-steered
       if ((B & 7) == 0) {
         const int xcd = l2 & 7, slot = l2 >> 3;
         bt = slot % To;
@@ -1020,35 +1081,37 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
   pc.start(p, tid);
   const int ps = 64 + 8 * (k & 31);  // debug slots of this step
 
-  // Gram first: acc = -G(rt, k) while nothing else is live in the register file, with chunk 0 of the
+  // Gram first: acc = -G(rt, kc) while nothing else is live in the register file, with chunk 0 of the
   // panels already in flight into LDS buffer 0 (the Gram inputs are staged in buffer 1's space).
   constexpr int CH2 = 2 * KT * LDST;
-  const T *gR = Lw + (size_t)rt * TS, *gC = Lw + (size_t)k * TS;
+  const T *gR = Lw + (size_t)rt * TS + (size_t)(c_first * KT) * ld, *gC = Lw + (size_t)k * TS + (size_t)(c_first * KT) * ld;
   // timing probes (wrong results): 4096 = every tile reads fit (b & 7)'s first row panel (L2-resident row
   // panels), 8192 = the same for the column panel
   if (CGP_DBG_ON(p, 4096)) gR = reinterpret_cast<const T *>(p.Lw) + (size_t)(b & 7) * p.lw_stride + (size_t)p.NT * TS;
   if (CGP_DBG_ON(p, 8192)) gC = reinterpret_cast<const T *>(p.Lw) + (size_t)(b & 7) * p.lw_stride + (size_t)k * TS;
-  const int nchunk = (k * TS) / KT;
+  const int nchunk = k * (TS / KT) - c_first;
+  const T *pimg = reinterpret_cast<const T *>(p.pimg) + ((size_t)b * 2 + (k & 1)) * DPART;  // image of tile (k + 1, k)
   // running predictive sums (extra tiles, throughput schedule): z of the newest block column
   // (k - 1) goes to LDS behind the chunk ring; zeros when nothing is to be accumulated
   const bool accm = p.macc != nullptr && rt >= p.NT && k > 0;
   T *zs = smem + 4 * KT * LDST;
   if (tid < TS) zs[tid] = accm ? Lw[(size_t)((k - 1) * TS + tid) * ld + (size_t)p.NT * TS + p.M] : T(0);
   T ms[4] = {T(0), T(0), T(0), T(0)};
-  if constexpr (RDIRECT && sizeof(T) == 8) {
+  if constexpr (DEEP) {
     RowFrag<T> rf;
     {
       GramPre<T> gp;
-      gram_prefetch<T>(p, b, k, rt, tid, gp);
+      if (!(MID && from_image)) gram_prefetch<T>(p, b, k, rt, tid, gp);
       rdirect_prologue<T>(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
-      gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
+      if (MID && from_image) acc_image<T, false, false>(acc, const_cast<T *>(pimg), tid);
+      else gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
     }
     pc.lap(p, ps + 0);
     mfma_rowpanel_loop_rdirect<T>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
   } else {
     {
       GramPre<T> gp;
-      gram_prefetch<T>(p, b, k, rt, tid, gp);
+      if (!(MID && from_image)) gram_prefetch<T>(p, b, k, rt, tid, gp);
       if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
       if (CGP_DBG_ON(p, 16384)) {  // timing probe: no Gram tile
 #pragma unroll
@@ -1057,8 +1120,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[cb][j][r] = gp.v[0];
-      } else
-      gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
+      } else if (MID && from_image) acc_image<T, false, false>(acc, const_cast<T *>(pimg), tid);
+      else gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
     }
     pc.lap(p, ps + 0);
     mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, accm ? zs : nullptr, ms);
@@ -1094,7 +1157,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_panel(FitArgs p
   pc.lap(p, ps + 5);
   pc.count(p, ps + 7);
   if constexpr (DIAGNEXT) {
-    if (finish_next) diag_next<T, DIAG_FINISH, kTriDiag>(p, acc, smem, Lw, b, k + 1, tid);
+    if (finish_next) diag_next<T, DIAG_FINISH, kTriDiag, DEEP>(p, acc, smem, Lw, b, k + 1, tid);
   }
   sc.leave(p, k, tid);
 }

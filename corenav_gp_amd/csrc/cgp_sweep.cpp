@@ -3,7 +3,7 @@
 //
 // The path shards across fits only: a batch of windows (one per Monte-Carlo trajectory / terrain
 // segment) is cut into contiguous per-device blocks -- the same partition as
-// corenav-gp_amd/sharding.py::shard_range -- every device runs its block through its own engine context
+// corenav_gp_amd/sharding.py::shard_range -- every device runs its block through its own engine context
 // on its own host thread, and the only exchange is the per-fit summary table gathered on the host
 // (a few KB; there is no data-path collective, so no RCCL call is needed inside one process).  This is
 // what lets the C++ ROS host of the reference (gp_predictor) shard an ensemble without Python / torch.

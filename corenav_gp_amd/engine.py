@@ -20,6 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # `make ab` writes next to the shipped one); there is still no CPU fallback.
 LIB_PATH = os.environ.get("CGP_LIB") or os.path.join(_HERE, "libcorenav_gp.so")
 DEBUG_SLOTS = 512
+ABI_VERSION = 2   # include/corenav_gp.h CGP_ABI_VERSION: load() refuses a library of another revision
 BUILD_ABLATION, BUILD_AB = 1, 2
 STREAM_CTX = ctypes.c_void_p(-1).value   # CGP_STREAM_CTX: the context's private stream
 
@@ -87,7 +88,9 @@ _lib = None
 
 
 def load():
-    """Loads libcorenav_gp.so and binds every symbol of include/corenav_gp.h (raises if missing)."""
+    """Loads libcorenav_gp.so and binds every symbol of include/corenav_gp.h (raises if missing).
+    Load order in a process that also uses torch.cuda: `import torch` FIRST -- torch bundles its own libamdhip64,
+    and if this library has already pulled in /opt/rocm's copy, torch.cuda later reports "No HIP GPUs"."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
@@ -97,6 +100,8 @@ def load():
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.cgp_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} has ABI revision {lib.cgp_abi_version()}, this binding is for {ABI_VERSION}: rebuild it")
         _lib = lib
     return _lib
 

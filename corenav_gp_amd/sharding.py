@@ -27,8 +27,8 @@ def gather_summaries(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """local: (n_local, len(SUMMARY_FIELDS)) float64 on this rank's device.  Returns the (n_total, F)
     table in global fit order on every rank.  Shards may differ by one row, so rows are padded to the
     largest shard for the all_gather and trimmed afterwards."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return local
+    if not (dist.is_available() and dist.is_initialized()):
+        return local          # no process group: one rank owns everything (a world of ONE rank still runs the collective)
     world = dist.get_world_size()
     sizes = [shard_range(n_total, r, world) for r in range(world)]
     nmax = max(b - a for a, b in sizes)

@@ -58,8 +58,9 @@ def theta_for(kernel_id, d, y, rng=None):
     raise ValueError(kernel_id)
 
 
-def config(cfg, batch=1, N=None, M=599):
-    """BASELINE.json configs -> (kernel_id, X[b,N,d], y[b,N], Xs[b,M,d], theta[b,nt], dtype)."""
+def config(cfg, batch=1, N=None, M=599, first=0):
+    """BASELINE.json configs -> (kernel_id, X[b,N,d], y[b,N], Xs[b,M,d], theta[b,nt], dtype); windows
+    first .. first + batch - 1 of the config's sequence (a rank's shard of a sweep)."""
     if cfg == 1:
         kid, d, n, dt = KERNEL_SE_ISO, 3, N or 256, "f64"
     elif cfg == 2:
@@ -69,7 +70,7 @@ def config(cfg, batch=1, N=None, M=599):
     else:
         raise ValueError(cfg)
     Xs_, ys_, Xt_, th_ = [], [], [], []
-    for b in range(batch):
+    for b in range(first, first + batch):
         seed = SEED_BASE + cfg + 1000 * b
         X, y, Xt = window(n, d, M, seed)
         rng = np.random.default_rng(seed + 7) if (cfg == 3 or b > 0) else None

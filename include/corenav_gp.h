@@ -59,6 +59,10 @@ void cgp_destroy(cgp_ctx *ctx);
 const char *cgp_strerror(int code);
 /* Text of the last HIP error seen by this context ("" if none). */
 const char *cgp_last_error(const cgp_ctx *ctx);
+/* ABI revision of the library that is loaded; compare with CGP_ABI_VERSION of the header a client was built
+ * against.  2 (this header): cgp_debug_read writes CGP_DEBUG_SLOTS = 512 slots (version 1: 64), and a NULL
+ * `hip_stream` is the legacy default stream (version 1: the context's private stream, now CGP_STREAM_CTX). */
+#define CGP_ABI_VERSION 2
 int cgp_abi_version(void);
 /* How the library was built: 0 for the shipped library.  CGP_BUILD_ABLATION (-DCGP_ABLATION): env
  * CGP_DBG is read and can skip parts of the arithmetic for timing ablations -- outputs are WRONG by
@@ -162,7 +166,7 @@ int cgp_fit_predict_batch_device(cgp_ctx *ctx, int batch, int N, int d, int M, i
  * on the host in global fit order (`summary` is (batch, 3), may be NULL).  No data-path collective:
  * the path shards across fits only, a single fit is never split.  This is the entry point that lets
  * the reference's C++ ROS host (gp_predictor) shard a Monte-Carlo ensemble without Python; the
- * one-process-per-GPU form over RCCL is corenav-gp_amd/sharding.py + bench.py --gpus N.  `devices` may
+ * one-process-per-GPU form over RCCL is corenav_gp_amd/sharding.py + bench.py --gpus N.  `devices` may
  * name a device more than once (several contexts on one GPU: the self-test of a one-GPU box).
  * Argument meaning, outputs and return value as cgp_fit_predict_batch; max_batch_total = the largest
  * batch a call will carry.  Returns NULL / CGP_ECAPACITY like cgp_create / cgp_fit_predict_batch. */

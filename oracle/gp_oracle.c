@@ -1,6 +1,6 @@
 /* ORACLE (test infrastructure, NOT product code) -- plain-C fp64 restatement of the corenav-GP
  * slip-GP fit/predict at fixed hyper-parameters.  It is the checker for the HIP path and the
- * "port" CPU baseline that bench.py times beside it; nothing under corenav-gp_amd/ links it.
+ * "port" CPU baseline that bench.py times beside it; nothing under corenav_gp_amd/ links it.
  *
  * PARITY UNPINNED at the GPy boundary (the reference's arithmetic is inside un-vendored GPy,
  * /root/reference/core_navigation/script/gp_slip_node.py:3,31-36,45-49; no reference test pins a

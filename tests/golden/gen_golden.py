@@ -6,6 +6,13 @@ Sources of the expected values, per fixture `source` field:
   sklearn  -- scikit-learn GaussianProcessRegressor(optimizer=None): an implementation independent
               of oracle/ (the reference cites scikit-learn kernels, `Kernel Selection/README.md:9`)
   closed   -- closed-form N=1 / N=2 answers evaluated with python floats
+  kalman   -- the reference's kernel in its pure-Brownian limit (RBF length-scale 1e12: the RBF factor is 1 to
+              1e-18) at the reference's operating size (N = 134, M = 599): Brownian motion observed in white noise
+              is a scalar state-space model, so posterior mean / variance / log marginal likelihood come from a
+              Kalman filter + RTS smoother recursion in python floats -- O(N), no Gram matrix, no Cholesky, nothing
+              shared with oracle/ -- itself checked here against the textbook noise-free forms (linear
+              interpolation between samples, constant beyond the last one, bridge variance s2 (x-a)(b-x)/(b-a),
+              s2 (x - x_N) beyond)
   restated -- oracle/gp_oracle.py outputs (regression vectors for the GPy-only RBF x Brownian kernel
               and for the GpPredictor look-ahead; PARITY UNPINNED vs GPy itself)
 """
@@ -78,6 +85,97 @@ def closed_forms():
                         Xs=np.array([[xs]]), mean=np.array([mu]), var_latent=np.array([var]), logml=lml)
 
 
+def brownian_kalman(x, y, xs, s2, tau2):
+    """Posterior of B(x*) for Brownian motion B (B(0) = 0, Var[B(b) - B(a)] = s2 (b - a)) observed as
+    y_i = B(x_i) + N(0, tau2) at increasing x_i > 0.  Python floats only.  Returns mean[], latent var[], logML."""
+    n = len(x)
+    m, P, xp = 0.0, 0.0, 0.0
+    fm, fP, pP = [], [], []          # filtered mean / variance, predicted variance at x_i
+    lml = 0.0
+    for i in range(n):
+        Pm = P + s2 * (x[i] - xp)
+        S = Pm + tau2
+        K = Pm / S
+        r = y[i] - m
+        lml += -0.5 * (math.log(2.0 * math.pi * S) + r * r / S)
+        m = m + K * r
+        P = Pm * (1.0 - K)
+        xp = x[i]
+        fm.append(m); fP.append(P); pP.append(Pm)
+    sm, sP = fm[:], fP[:]            # RTS smoother
+    for i in range(n - 2, -1, -1):
+        G = fP[i] / pP[i + 1]
+        sm[i] = fm[i] + G * (sm[i + 1] - fm[i])
+        sP[i] = fP[i] + G * G * (sP[i + 1] - pP[i + 1])
+    mean, var = [], []
+    for q in xs:
+        if q >= x[-1]:
+            mean.append(fm[-1]); var.append(fP[-1] + s2 * (q - x[-1]))
+            continue
+        j = 0
+        while x[j] <= q:             # x[j] = first sample beyond q
+            j += 1
+        if j == 0:
+            m0, P0, x0 = 0.0, 0.0, 0.0
+        else:
+            m0, P0, x0 = fm[j - 1], fP[j - 1], x[j - 1]
+        Ps = P0 + s2 * (q - x0)      # filtered = predicted at the unobserved point q
+        G = Ps / pP[j]
+        mean.append(m0 + G * (sm[j] - m0))
+        var.append(Ps + G * G * (sP[j] - pP[j]))
+    return mean, var, lml
+
+
+def brownian_cases():
+    """The reference kernel `GPy.kern.RBF(1) * GPy.kern.Brownian(1)` (gp_slip_node.py:31) pinned without the oracle at
+    the reference's operating size: first 134 ticks of the slipVal window as training set (gp_slip_node.py:27-29),
+    (a) the 599 published prediction ticks (:45,:59 -- all beyond the window), (b) 599 points inside / before the
+    window (bridge), (c) the prior-variance law: one sample, variance growing ~ x*."""
+    raw = np.loadtxt(REF_CSV, delimiter=",")
+    ticks = [float(round(t * 10.0)) for t in raw[:149, 0]]
+    slip = [float(v) for v in raw[:149, 1]]
+    ntr = int(0.9 * len(ticks))
+    x, y = ticks[:ntr], slip[:ntr]
+    sr, ell, sb, sn = 0.5, 1.0e12, 0.02, 0.002
+    s2, tau2 = sr * sb, sn + go.GPY_DIAG_EPS
+    # textbook check of the recursion itself (noise 1e-12 of the signal variance)
+    xin = [x[0] * 0.5] + [x[i] + f for i in range(0, ntr - 1, 7) for f in (0.25, 0.5)] + [x[-1] + 40.0]
+    km, kv, _ = brownian_kalman(x, y, xin, s2, 1e-14)
+    for q, mq, vq in zip(xin, km, kv):
+        if q < x[0]:
+            em, ev = y[0] * q / x[0], s2 * q * (x[0] - q) / x[0]
+        elif q > x[-1]:
+            em, ev = y[-1], s2 * (q - x[-1])
+        else:
+            j = max(i for i in range(ntr) if x[i] <= q)
+            a, b = x[j], x[j + 1]
+            em = y[j] + (y[j + 1] - y[j]) * (q - a) / (b - a)
+            ev = s2 * (q - a) * (b - q) / (b - a)
+        assert abs(mq - em) < 1e-9 and abs(vq - ev) < 1e-9 * max(ev, 1e-3), (q, mq, em, vq, ev)
+    theta = np.array([sr, ell, sb, sn])
+    X = np.array(x)[:, None]
+    cases = {
+        "closed_brownian_kalman_n134": [ticks[0] + len(ticks) + m for m in range(599)],          # gp_slip_node.py:45,59
+        "closed_brownian_bridge_n134": [x[0] * (0.1 + 0.8 * (m % 10) / 10.0) if m < 10 else
+                                       x[(m * 7) % (ntr - 1)] + ((m * 37) % 100 + 1) / 101.0 for m in range(599)],
+    }
+    for name, xs in cases.items():
+        mean, var, lml = brownian_kalman(x, y, xs, s2, tau2)
+        f = go.fit(go.KERNEL_RBF_BROWNIAN, theta, X, np.array(y))
+        omu, ovar = go.predict(f, np.array(xs)[:, None], include_noise=False)
+        e_mu = np.max(np.abs(omu - mean)) / np.max(np.abs(mean))
+        e_var = np.max(np.abs(ovar - var) / np.array(var))
+        print(f"{name}: oracle vs Kalman/RTS  mean {e_mu:.2e}  var {e_var:.2e}  logml {abs(f.logml - lml) / abs(lml):.2e}")
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), source="kalman", kernel_id=2, theta=theta, X=X,
+                            y=np.array(y), Xs=np.array(xs)[:, None], mean=np.array(mean), var_latent=np.array(var), logml=lml)
+    # (c) one sample at x = 1: var(x*) = P_1 + s2 (x* - 1), prior-like growth ~ x* up to tick 6000
+    xs = [1.0 + 10.0 * m for m in range(1, 600)]
+    mean, var, lml = brownian_kalman([1.0], [0.05], xs, s2, tau2)
+    np.savez_compressed(os.path.join(OUT, "closed_brownian_prior_n1.npz"), source="kalman", kernel_id=2, theta=theta,
+                        X=np.array([[1.0]]), y=np.array([0.05]), Xs=np.array(xs)[:, None], mean=np.array(mean),
+                        var_latent=np.array(var), logml=lml)
+
+
 def slipval_window():
     """The only real slip series in the reference (core_navigation/script/slipVal.csv, 199 rows
     time_s, slip @ 0.1 s).  Stored as data: tick = round(10 t), the first 149 rows form one
@@ -143,6 +241,7 @@ def main():
     # independent implementation
     kid, X, y, Xs, th, _ = synth.config(2)
     sklearn_case("sk_se_ard_n2048_d6", kid, X[0], y[0], Xs[0], th[0])
+    brownian_cases()
     slipval_window()
     restated_cases()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

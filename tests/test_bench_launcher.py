@@ -44,3 +44,37 @@ def test_single_rank_dry_line():
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["config"]["ranks"] == 1 and j["config"]["collective_backend"] is None
+
+
+def test_strong_scaling_shards_the_total():
+    """--scaling strong: --batch is the sweep's TOTAL (BASELINE configs[2]: 512 fits over the ranks); two ranks own
+    contiguous shards of 5 and 4 of 9 fits, the gathered table has 9 rows, value counts 9 fits per step."""
+    r = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "9", "--scaling", "strong", "--config", "3")
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["config"]["ensemble"]["n"] == 9
+    assert j["config"]["fits_per_step_all_ranks"] == 9 and j["config"]["fits_per_gpu_per_step"] == 4.5
+    # per-rank rates are in the ratio of the shard sizes (5 : 4) up to timing noise, and sum to about the whole-job value
+    a, b = j["config"]["per_rank_fits_per_s"]
+    assert 1.0 < a / b < 1.6
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 9) < 1e-6
+
+
+def test_forced_one_rank_world_runs_the_collectives():
+    """CGP_BENCH_FORCE_DIST=1: a world of ONE rank still initialises the process group and runs barrier / all_gather /
+    all_reduce / the summary gather (gloo here; RCCL in tests/test_gpu_bench_contract.py)."""
+    r = run_bench("--steps", "2", "--warmup", "0", "--batch", "4", CGP_BENCH_FORCE_DIST="1")
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["config"]["collective_backend"] == "gloo" and j["config"]["collective_world"] == 1
+    assert j["config"]["ensemble"]["n"] == 4
+
+
+def test_a_rank_that_dies_ends_the_job_quickly():
+    """One rank failing at start-up must not leave the others waiting in the rendezvous: the launcher kills them and
+    returns the failing code."""
+    import time
+    t0 = time.time()
+    r = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "4", CGP_BENCH_TEST_DIE_RANK="1")
+    assert r.returncode != 0
+    assert time.time() - t0 < 60

@@ -47,7 +47,10 @@ def check_fit_predict(engine, kid, theta, X, y, Xs, dtype, tol, include_noise=Tr
 
 SK = ["sk_se_iso_n256_d3", "sk_se_ard_n2_d1", "sk_se_ard_n15_d3", "sk_se_ard_n134_d6", "sk_se_ard_n256_d6",
       "sk_se_ard_n2048_d6",
-      "closed_n1_se", "closed_n2_rbfbrownian"]
+      "closed_n1_se", "closed_n2_rbfbrownian",
+      # the reference's kernel in its pure-Brownian limit at the reference's operating size, expected values from a
+      # Kalman filter / RTS smoother recursion (tests/golden/gen_golden.py: brownian_cases) -- independent of oracle/
+      "closed_brownian_kalman_n134", "closed_brownian_bridge_n134", "closed_brownian_prior_n1"]
 
 
 @pytest.mark.parametrize("name", SK)
@@ -266,6 +269,50 @@ def test_config3_fp32_batch512_properties(engine):
     assert np.array_equal(m2, mean[perm]) and np.array_equal(v2, var[perm]) and np.array_equal(l2, logml[perm])
 
 
+def test_config3_as_sharded_64_fits_fp32(engine):
+    """BASELINE configs[2] as written: 512 x (N=1024 d=6 fp32) "sharded across 8 MI355X" = 64 fits per GPU per call.
+    Exactly that call (64 fits, N=1024, fp32, M=599) -- which takes the mid-size schedule (kind-C pre-update of the
+    next launch's chain tile, deep-prefetch loops) -- against the oracle at north_star's fp32 bar on every fourth fit,
+    the variance floor on all, and slot-permutation invariance bitwise."""
+    B = 64
+    kid, X, y, Xs, th, _ = synth.config(3, batch=B)
+    ctx = engine.Context(max_n=1024, max_m=599, max_d=6, max_batch=B, dtype=engine.F32)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not info.any()
+    assert np.all(var >= th[:, -1:] * (1 - 1e-6))
+    for b in range(0, B, 4):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        assert relmax(mean[b], omu) < TOL32 and releach(var[b], ovar) < TOL32
+        assert abs(logml[b] - f.logml) <= TOL32 * abs(f.logml)
+    perm = np.random.default_rng(64).permutation(B)
+    rc, m2, v2, l2, i2 = ctx.fit_predict_batch(X[perm], y[perm], Xs[perm], th[perm], kid)
+    assert rc == 0 and not i2.any()
+    assert np.array_equal(m2, mean[perm]) and np.array_equal(v2, var[perm]) and np.array_equal(l2, logml[perm])
+
+
+@pytest.mark.parametrize("dtype_name,N,small,large", [("F32", 640, 64, 200), ("F32", 1024, 40, 196), ("F64", 640, 48, 136)])
+def test_mid_size_schedule_is_bitwise_the_full_schedule(engine, dtype_name, N, small, large):
+    """A mid-size call (<= 192 fits fp32 / 128 fp64) splits the chain tile of every block step over two launches
+    (kind C leaves a register image, kind A of the next launch adds the newest block column) and, in fp32, runs the
+    deep-prefetch loops; a larger call computes every tile in one workgroup with the register-staged loop.  Same
+    arithmetic in the same order: the first `small` fits of a `large`-fit call equal a `small`-fit call BITWISE."""
+    dtype = getattr(engine, dtype_name)
+    kid, X, y, Xs, th, _ = synth.config(3 if dtype_name == "F32" else 2, batch=large, N=N, M=130)
+    big = engine.Context(max_n=N, max_m=130, max_d=6, max_batch=large, dtype=dtype)
+    rc, mean, var, logml, info = big.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not info.any()
+    sm = engine.Context(max_n=N, max_m=130, max_d=6, max_batch=small, dtype=dtype)
+    rc, m2, v2, l2, i2 = sm.fit_predict_batch(X[:small], y[:small], Xs[:small], th[:small], kid)
+    assert rc == 0 and not i2.any()
+    assert np.array_equal(m2, mean[:small]) and np.array_equal(v2, var[:small]) and np.array_equal(l2, logml[:small])
+    tol = TOL32 if dtype_name == "F32" else TOL64
+    for b in (0, small - 1):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        assert relmax(m2[b], omu) < tol and releach(v2[b], ovar) < tol and abs(l2[b] - f.logml) <= tol * abs(f.logml)
+
+
 def test_jitter_policy_and_failure(engine):
     """GPy jitchol: a matrix that is not PD gets mean(diag)*1e-6*10^k; hopeless input returns info."""
     X = np.zeros((40, 1))
@@ -398,9 +445,9 @@ def test_alternate_schedules_match_oracle(env):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # the alternatives are not in the shipped library: `make ab` builds them into libcorenav_gp_ab.so
-    ab = os.path.join(root, "corenav-gp_amd", "libcorenav_gp_ab.so")
+    ab = os.path.join(root, "corenav_gp_amd", "libcorenav_gp_ab.so")
     if not os.path.exists(ab):
-        pytest.skip("libcorenav_gp_ab.so not built (make -C corenav-gp_amd/csrc ab)")
+        pytest.skip("libcorenav_gp_ab.so not built (make -C corenav_gp_amd/csrc ab)")
     env = dict(env, CGP_LIB=ab)
     code = (
         "import sys; sys.path.insert(0, %r)\n"

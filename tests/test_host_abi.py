@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in corenav_gp.h but not exported"
     assert declared == set(engine.EXPORTS), declared ^ set(engine.EXPORTS)
-    assert lib.cgp_abi_version() == 1
+    assert lib.cgp_abi_version() == 2
 
 
 def test_no_device_fails_loudly():
@@ -132,7 +132,7 @@ def test_gppredictor_header_offers_the_reference_signature():
     checks the surface is spelled out and that the ROS-free configuration, which the library ships, builds."""
     import re
     import subprocess
-    csrc = os.path.join(ROOT, "corenav-gp_amd", "csrc")
+    csrc = os.path.join(ROOT, "corenav_gp_amd", "csrc")
     h = open(os.path.join(csrc, "gp_predictor.h")).read()
     for needle in ("typedef ros::NodeHandle NodeHandle;", "GpPredictor(corenav_types::NodeHandle &);",
                    "typedef Eigen::MatrixXd Matrix;", "ros::Subscriber gp_sub_;", "ros::Publisher stop_cmd_pub_;",
@@ -144,7 +144,7 @@ def test_gppredictor_header_offers_the_reference_signature():
                    'serviceClient<core_nav::SetStopping>("/core_nav/core_nav/stopping_service")',
                    'advertise<std_msgs::Float64>("/core_nav/core_nav/stop_cmd", 1)'):
         assert needle in cpp, needle
-    node = open(os.path.join(ROOT, "corenav-gp_amd", "ros", "gp_predictor_node.cpp")).read()
+    node = open(os.path.join(ROOT, "corenav_gp_amd", "ros", "gp_predictor_node.cpp")).read()
     body = re.sub(r"\s+", " ", node[node.index("int main"):])
     assert 'ros::init(argc, argv, "gp_predictor"); ros::NodeHandle nh(""); GpPredictor gp_predictor(nh); ros::spin();' in body
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-DCORENAV_NO_ROS", "-DCORENAV_NO_EIGEN",

@@ -12,6 +12,10 @@ from oracle import gp_oracle as go
 SK = ["sk_se_iso_n256_d3", "sk_se_ard_n2_d1", "sk_se_ard_n15_d3", "sk_se_ard_n134_d6", "sk_se_ard_n256_d6",
       "sk_se_ard_n2048_d6"]
 CLOSED = ["closed_n1_se", "closed_n2_rbfbrownian"]
+# RBF x Brownian (the reference's kernel, gp_slip_node.py:31) with the RBF factor switched off (ell = 1e12), at the
+# reference's operating size: expected values from a Kalman filter / RTS smoother recursion in python floats
+# (tests/golden/gen_golden.py: brownian_cases), nothing shared with oracle/
+KALMAN = ["closed_brownian_kalman_n134", "closed_brownian_bridge_n134", "closed_brownian_prior_n1"]
 
 
 def rel(a, b, floor=1e-300):
@@ -19,7 +23,7 @@ def rel(a, b, floor=1e-300):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
 
 
-@pytest.mark.parametrize("name", SK + CLOSED)
+@pytest.mark.parametrize("name", SK + CLOSED + KALMAN)
 def test_numpy_oracle_vs_golden(name):
     g = load_golden(name)
     f = go.fit(int(g["kernel_id"]), g["theta"], g["X"], g["y"])
@@ -32,7 +36,7 @@ def test_numpy_oracle_vs_golden(name):
         assert np.max(np.abs(f.alpha - g["alpha"])) / np.max(np.abs(g["alpha"])) < 1e-7
 
 
-@pytest.mark.parametrize("name", SK + CLOSED)
+@pytest.mark.parametrize("name", SK + CLOSED + KALMAN)
 def test_c_oracle_vs_golden(name, oracle_c):
     g = load_golden(name)
     rc, mu, var, logml, alpha, jit = oracle_c(int(g["kernel_id"]), g["theta"], g["X"], g["y"], g["Xs"], False)

@@ -14,7 +14,7 @@ import pytest
 from conftest import load_golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "corenav-gp_amd", "csrc")
+CSRC = os.path.join(ROOT, "corenav_gp_amd", "csrc")
 DOUBLES = os.path.join(ROOT, "tests", "ros_api_doubles")
 
 
@@ -31,7 +31,7 @@ def driver(tmp_path_factory):
     assert r.returncode == 0, r.stderr[-3000:]
     # the node's translation unit (reference main: gp_predictor.cpp:180-190) compiles in the same configuration
     r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", DOUBLES, "-I", CSRC, "-c", "-o", str(out / "node.o"),
-                        os.path.join(ROOT, "corenav-gp_amd", "ros", "gp_predictor_node.cpp")], capture_output=True, text=True)
+                        os.path.join(ROOT, "corenav_gp_amd", "ros", "gp_predictor_node.cpp")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     syms = subprocess.run(["nm", "-C", str(out / "node.o")], capture_output=True, text=True).stdout
     assert " T main" in syms and "GpPredictor::GpPredictor(ros::NodeHandle&)" in syms

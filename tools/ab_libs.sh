@@ -2,7 +2,7 @@
 # A/B of two builds of libcorenav_gp.so on the same box: tools/ab_libs.sh <old.so> <bench args...>
 # (alternates new/old three times; prints fits/s and ms per step)
 old=$1; shift
-lib=corenav-gp_amd/libcorenav_gp.so
+lib=corenav_gp_amd/libcorenav_gp.so
 cp $lib /tmp/new.so
 for i in 1 2 3; do
   for v in new old; do

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the host-buffer batch call spends its time (ablation build: CGP_LIB=corenav-gp_amd/libcorenav_gp_ab.so
+"""Where the host-buffer batch call spends its time (ablation build: CGP_LIB=corenav_gp_amd/libcorenav_gp_ab.so
 CGP_TRACE_E2E=1 prints stage / queue / device / D2H / copy-out laps of cgp_fit_predict_batch to stderr)."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())

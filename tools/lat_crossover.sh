@@ -3,7 +3,7 @@
 # (ablation build, CGP_LAT_FITS): tools/lat_crossover.sh <tag> <bench args...>
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-export CGP_LIB=$R/corenav-gp_amd/libcorenav_gp_ab.so
+export CGP_LIB=$R/corenav_gp_amd/libcorenav_gp_ab.so
 for b in 4 8 12 16 24 32 48 64; do
   for lf in 0 64; do
     echo -n "batch $b lat_fits $lf: "

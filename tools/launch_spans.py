@@ -3,7 +3,7 @@
   a) in-kernel real-time stamps (CGP_DBG=2048: earliest workgroup entry .. latest exit per block step), no events;
   b) HIP events around every launch (cgp_profile_enable(1)) -- what bench.py's roofline used in round 1;
   c) HIP events around ONE launch per step, the others back to back (cgp_profile_enable(2 + k)).
-   CGP_LIB=corenav-gp_amd/libcorenav_gp_ab.so CGP_DBG=2048 python tools/launch_spans.py [--config 3] [--batch 512]"""
+   CGP_LIB=corenav_gp_amd/libcorenav_gp_ab.so CGP_DBG=2048 python tools/launch_spans.py [--config 3] [--batch 512]"""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase cycle sums of k_panel (PhaseClock, CGP_DBG & 1024) from the -DCGP_ABLATION library:
-   CGP_LIB=corenav-gp_amd/libcorenav_gp_ab.so CGP_DBG=1024 python tools/phase_clock.py [--config 3] [--batch 512]
+   CGP_LIB=corenav_gp_amd/libcorenav_gp_ab.so CGP_DBG=1024 python tools/phase_clock.py [--config 3] [--batch 512]
 prints, per block step k, the mean s_memtime ticks per workgroup of: gram (prefetch + prologue loads + Gram tile),
 loop (MFMA update), fold (accumulator fold + barrier), wstage (W_k -> LDS), trmm, store."""
 import argparse, json, os, sys

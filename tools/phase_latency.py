@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase cycle sums of the latency schedule's diagonal-tile workgroup (k_tile_sk, CGP_DBG & 1024):
-   CGP_LIB=corenav-gp_amd/libcorenav_gp_ab.so CGP_DBG=1024 python tools/phase_latency.py"""
+   CGP_LIB=corenav_gp_amd/libcorenav_gp_ab.so CGP_DBG=1024 python tools/phase_latency.py"""
 import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch

@@ -1,6 +1,6 @@
 // Microbenchmark of the 16x16 diagonal-block factor + inverse that sits on the serial critical path
 // of potf2 (csrc/cgp_kernels.hpp, factor_block16): one wavefront, block in LDS, s_memtime per call.
-//   hipcc --offload-arch=gfx950 -O3 -I corenav-gp_amd/csrc tools/potf2_block_bench.hip -o tools/potf2_block_bench
+//   hipcc --offload-arch=gfx950 -O3 -I corenav_gp_amd/csrc tools/potf2_block_bench.hip -o tools/potf2_block_bench
 #include "cgp_kernels.hpp"
 #include <cstdio>
 #include <vector>

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Monte-Carlo closed-loop replay sharded over the GPUs of a node (stand-in for BASELINE configs[4]):
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/replay_ensemble.py --traj 64
-Each rank replays its block of trajectories (corenav-gp_amd/replay.py); the only collective is the
+Each rank replays its block of trajectories (corenav_gp_amd/replay.py); the only collective is the
 all-gather of per-trajectory summaries (first stop time, number of windows / stops)."""
 import argparse, json, os, sys, time
 import numpy as np
