@@ -522,6 +522,26 @@ def extras_cfg3(engine, torch, dev, local, W):
             ex["cfg3_roofline_frac"] = rf["frac"]
             ex["cfg3_kernel_ms_per_step"] = kms
             ex["cfg3_workload"] = "BASELINE configs[2]: 512 x N=1024 d=6 SE-ARD fp32, M=599, one GPU's view of the sweep"
+            # configs[2] AS WRITTEN shards the 512 fits over 8 GPUs: 64 fits per GPU and call.  The same engine on the
+            # first 64 windows (its mid-size schedule), and what 8 such GPUs would make of the 1-GPU rate above -- a
+            # projection from this GPU's two rates (no collective on the data path), not a measurement of 8 GPUs.
+            W64 = Workload(engine, torch, dev, local, kid, X[:64], y[:64], Xs[:64], th[:64], dts, 1)
+            tw = time.perf_counter()
+            while time.perf_counter() - tw < 0.1:
+                W64.step()
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                W64.step()
+            torch.cuda.synchronize()
+            el64 = (time.perf_counter() - t0) / 20
+            assert int(W64.dinfo.abs().sum().item()) == 0
+            ex["cfg3_fits_per_s_at_64"] = 64 / el64
+            ex["cfg3_ms_per_call_at_64"] = el64 * 1e3
+            ex["cfg3_strong_scaling_projection_8gpu"] = 8 * (64 / el64) / (512 / el)
+            ex["cfg3_strong_scaling_note"] = ("8 x (64-fit call rate) / (512-fit call rate) on this one GPU; measure it with "
+                                              "`bench.py --scaling strong --config 3 --gpus 8`")
+            del W64
             # for the CPU leg (the only place of this program that may run the oracle): inputs and the timed outputs
             ex["_cpu_leg"] = (kid, X, y, Xs, th, W3.dmean, W3.dvar, W3.dlogml, fit_flops(1024, 6, M_TEST)[1])
             del W3
@@ -559,7 +579,19 @@ def window_line(engine, torch, dev, local, W=1024, N=512, d=3, T=200):
     el = time.perf_counter() - t0
     assert ctx.window_state(0)[1] == 0
     gbps = W * T * (N * N / 2 * 8 * 2) / el / 1e9
-    return {"window_ticks_per_s": W * T / el, "window_hbm_frac": gbps / HBM_PEAK_GBPS,
+    # the per-tick host entry (cgp_window_push, T = 1, ONE window, host buffers in and out: what a node that receives one
+    # sample per IMU tick calls): pinned staging kept in the context, one H2D, the launch, two D2H, one synchronisation
+    c1 = engine.Context(device=local, max_n=8, max_m=8, max_d=d)
+    c1.window_init(1, N, d, 1, theta)
+    c1.window_push(X[:1, :N], y[:1, :N])                 # fill
+    for i in range(5):
+        c1.window_push(X[:1, N + i:N + i + 1], y[:1, N + i:N + i + 1])
+    nt = 50
+    t1 = time.perf_counter()
+    for i in range(5, 5 + nt):
+        c1.window_push(X[:1, N + i:N + i + 1], y[:1, N + i:N + i + 1])
+    host_tick_us = (time.perf_counter() - t1) / nt * 1e6
+    return {"window_ticks_per_s": W * T / el, "window_hbm_frac": gbps / HBM_PEAK_GBPS, "window_host_tick_us": host_tick_us,
             "window_workload": f"BASELINE configs[3]: {W} windows x N={N} d={d} fp64, {T} ticks, algorithmic {gbps:.0f} GB/s of {HBM_PEAK_GBPS:.0f}"}
 
 

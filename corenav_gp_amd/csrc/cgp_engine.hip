@@ -83,6 +83,9 @@ struct cgp_ctx {
   WindowArgs win{};
   int nwin = 0;
   void *winbuf[8] = {nullptr};
+  // cgp_window_push staging, grown on demand and kept: one pinned host block and one device block per direction
+  void *win_pin = nullptr, *win_dev = nullptr;
+  size_t win_pin_cap = 0, win_dev_cap = 0;
   int *dinfo = nullptr;
   size_t lw_stride = 0, winv_stride = 0, alpha_stride = 0;
   // state of the last single fit (cgp_fit -> cgp_predict)
@@ -151,7 +154,9 @@ constexpr int LAT_FITS_F64 = 16, LAT_FITS_F32 = 24;
 constexpr int FUSED64_BELOW = 512;                // fp64 throughput schedule: diagonal tiles inside the panel launches below this batch
 // Calls too small to fill the chip (a launch then lasts as long as its longest workgroup chain): the next launch's
 // kind-A tile is pre-updated by a kind-C workgroup (k_panel), and fp32 takes the deep-prefetch loops (DEEP).
-constexpr int MID_FITS_F64 = 128, MID_FITS_F32 = 192;
+// Measured crossover (tools/r3_mid2.sh, same box, CGP_MID_FITS either side): fp32 N = 1024: 32 fits +14 %, 48 +13 %,
+// 64 +9 %, 96 +2 %, 128 -4 %; fp64 N = 2048: 24 fits +18 %, 32 +11 %, 48 +4 %, 64 -2 %.
+constexpr int MID_FITS_F64 = 48, MID_FITS_F32 = 96;
 constexpr int MID_FITS_ALLOC = kAbBuild ? 512 : (MID_FITS_F64 > MID_FITS_F32 ? MID_FITS_F64 : MID_FITS_F32);
 template <typename T> inline int mid_fits() {     // ablation build: CGP_MID_FITS moves the crossover (measurement)
   if constexpr (kAbBuild) {
@@ -457,7 +462,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       const bool hasC = mid && k + 2 < a.NT, imgA = mid && hasA && k >= 1;  // launch k - 1 had a kind C iff k + 1 < NT
       FitArgs ak = ga[g];
       ak.diag_slots = (hasA ? 1 : 0) | (hasB ? 2 : 0) | (hasC ? 4 : 0) | (imgA ? 8 : 0);
-      ak.diag_stride = sizeof(T) == 8 || mid ? 2 : 4;  // workgroups per CU of k_panel<T, true> (LDS / VGPR bound)
+      ak.diag_stride = sizeof(T) == 8 ? 2 : (mid ? 3 : 4);  // workgroups per CU of k_panel<T, true> (LDS / VGPR bound)
       const int gx = gx_t + (hasB ? 1 : 0) + (hasC ? 1 : 0);  // gx_t already counts row tile k + 1 (kind A)
       // algorithmic flops of THIS launch: kind C does the part of tile (k + 2, k + 1) that kind A of launch k + 1 no longer does
       double fl = panel_flops(a.N, a.M, a.d, k, true, gb[g]) + (hasA ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0);
@@ -722,6 +727,8 @@ void cgp_destroy(cgp_ctx *c) {
     if (e) (void)hipEventDestroy(e);
   for (void *wb : c->winbuf)
     if (wb) (void)hipFree(wb);
+  if (c->win_pin) (void)hipHostFree(c->win_pin);
+  if (c->win_dev) (void)hipFree(c->win_dev);
   if (c->pin_in) (void)hipHostFree(c->pin_in);
   if (c->pin_out) (void)hipHostFree(c->pin_out);
   if (c->draw) (void)hipFree(c->draw);
@@ -1357,27 +1364,28 @@ extern "C" int cgp_window_push(cgp_ctx *c, int T, const double *xs, const double
   if (!c || c->nwin < 1) return CGP_ESTATE;
   if (T < 1 || !xs || !ys || !pm || !pv || !logml) return CGP_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
+  // The per-tick host entry (configs[3] is "streamed per IMU tick": T = 1 is the common call): no allocation and no
+  // pageable copy on the path.  One pinned block [xs | ys | pm pv logml | state] and its device twin live in the
+  // context; per call: stage in, ONE H2D, the launch, TWO D2H (outputs, window states), one synchronisation.
   const size_t W = c->nwin, nx = W * T * c->win.d, ny = W * T;
-  double *buf = nullptr;
-  HIP_TRY(c, hipMalloc((void **)&buf, (nx + 4 * ny) * 8));
+  const size_t ndbl = nx + 4 * ny, bytes = ndbl * 8 + W * 4 * sizeof(int);
+  if (!grow_pinned(c->win_pin, c->win_pin_cap, bytes) || !grow_device(c->win_dev, c->win_dev_cap, ndbl * 8)) return CGP_ENOMEM;
+  double *h = static_cast<double *>(c->win_pin), *d = static_cast<double *>(c->win_dev);
+  int *hst = reinterpret_cast<int *>(h + ndbl);
+  memcpy(h, xs, nx * 8);
+  memcpy(h + nx, ys, ny * 8);
   hipStream_t s = c->stream;
-  int rc = CGP_OK;
-  do {
-    if (!hip_ok(c, hipMemcpyAsync(buf, xs, nx * 8, hipMemcpyHostToDevice, s), "H2D xs")) { rc = CGP_EHIP; break; }
-    if (!hip_ok(c, hipMemcpyAsync(buf + nx, ys, ny * 8, hipMemcpyHostToDevice, s), "H2D ys")) { rc = CGP_EHIP; break; }
-    rc = cgp_window_push_device(c, T, buf, buf + nx, include_noise, buf + nx + ny, buf + nx + 2 * ny, buf + nx + 3 * ny, s);
-    if (rc != CGP_OK) break;
-    if (!hip_ok(c, hipMemcpyAsync(pm, buf + nx + ny, ny * 8, hipMemcpyDeviceToHost, s), "D2H")) { rc = CGP_EHIP; break; }
-    if (!hip_ok(c, hipMemcpyAsync(pv, buf + nx + 2 * ny, ny * 8, hipMemcpyDeviceToHost, s), "D2H")) { rc = CGP_EHIP; break; }
-    if (!hip_ok(c, hipMemcpyAsync(logml, buf + nx + 3 * ny, ny * 8, hipMemcpyDeviceToHost, s), "D2H")) { rc = CGP_EHIP; break; }
-    if (!hip_ok(c, hipStreamSynchronize(s), "sync")) { rc = CGP_EHIP; break; }
-  } while (false);
-  (void)hipFree(buf);
+  HIP_TRY(c, hipMemcpyAsync(d, h, (nx + ny) * 8, hipMemcpyHostToDevice, s));
+  int rc = cgp_window_push_device(c, T, d, d + nx, include_noise, d + nx + ny, d + nx + 2 * ny, d + nx + 3 * ny, s);
   if (rc != CGP_OK) return rc;
-  std::vector<int> st(W * 4);
-  HIP_TRY(c, hipMemcpy(st.data(), c->win.state, st.size() * sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpyAsync(h + nx + ny, d + nx + ny, 3 * ny * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(hst, c->win.state, W * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  memcpy(pm, h + nx + ny, ny * 8);
+  memcpy(pv, h + nx + 2 * ny, ny * 8);
+  memcpy(logml, h + nx + 3 * ny, ny * 8);
   for (size_t w = 0; w < W; ++w)
-    if (st[w * 4 + 2] != 0) return st[w * 4 + 2];
+    if (hst[w * 4 + 2] != 0) return hst[w * 4 + 2];
   return CGP_OK;
 }
 

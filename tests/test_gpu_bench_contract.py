@@ -29,6 +29,9 @@ def test_bench_line_contract():
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["gpu_vs_oracle_max_rel_err"] < 1e-6
     assert cb["host"]["cpu_model"] and "governor" in cb["host"] and cb["port_threads_over_batch"]["value"] > 0
+    assert "cgroup_cpu_max" in cb["host"] and "lapack_all_threads" not in cb
+    rows = cb["single_thread_rows"]      # the baseline is the FASTER of the two single-thread runs of the oracle
+    assert cb["value"] == max(r["value"] for r in rows.values() if "value" in r)
     assert "ablation_build" not in j and "dry_run" not in j
     assert j["value"] > 0 and j["config"]["single_fit_latency_ms"] > 0
 
@@ -46,6 +49,9 @@ def test_bench_extra_lines():
     assert ex["cfg3_fits_per_s"] > 0 and 0 < ex["cfg3_roofline_frac"] < 1 and ex["cfg3_max_rel_err_vs_oracle"] < 1e-3
     assert ex["cfg3_cpu_baseline"]["value"] > 0 and ex["cfg3_cpu_baseline"]["kind"] == "port" and "_cpu_leg" not in ex
     assert ex["window_ticks_per_s"] > 0 and 0 < ex["window_hbm_frac"] < 1 and ex["lookahead_traj_per_s"] > 0
+    assert 0 < ex["window_host_tick_us"] < 2000
+    # configs[2] as written (64 fits per GPU at 8 GPUs): the 64-fit call rate and the projection from this GPU's two rates
+    assert ex["cfg3_fits_per_s_at_64"] > 0 and 0 < ex["cfg3_strong_scaling_projection_8gpu"] <= 8.5
 
 
 def test_bench_live_pmc_traffic():
@@ -80,3 +86,36 @@ def test_bench_gpus2_on_one_gpu():
     assert j["n_gpus"] == 2 and j["config"]["ranks"] == 2 and len(j["config"]["per_rank_fits_per_s"]) == 2
     assert j["config"]["ensemble"]["n"] == 32 and j["config"]["ensemble"]["n_failed"] == 0
     assert "cpu_baseline" not in j and j["roofline"]["frac"] > 0
+
+
+def test_bench_strong_scaling_two_ranks_on_one_gpu():
+    """BASELINE configs[2] as written, two ranks: `--scaling strong --config 3 --batch 64` cuts the 64 fits into two
+    contiguous shards of 32 (one engine context each, both on device 0 here), the gathered table has 64 rows and
+    `value` counts 64 fits per step."""
+    env = dict(os.environ, CGP_BENCH_SAME_DEVICE="1", CGP_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "strong", "--config", "3",
+                        "--batch", "64", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["dtype"] == "f32"
+    assert j["config"]["fits_per_step_all_ranks"] == 64 and j["config"]["fits_per_gpu_per_step"] == 32
+    assert j["config"]["ensemble"]["n"] == 64 and j["config"]["ensemble"]["n_failed"] == 0
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 64) < 1e-6
+
+
+def test_bench_rccl_collectives_with_one_rank():
+    """CGP_BENCH_FORCE_DIST=1: `bench.py --gpus 1` initialises the `nccl` backend (= RCCL on ROCm) with a world of one
+    rank and runs the barrier, the all_gather / all_reduce of the timings and sharding.gather_summaries ON THE DEVICE:
+    librccl loads, HSA_ENABLE_IPC_MODE_LEGACY handling and the gather are exercised on an MI355X before an 8-GPU job
+    is the first to try them."""
+    env = dict(os.environ, CGP_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "CGP_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "3", "--batch", "64", "--steps", "3",
+                        "--warmup", "1", "--no-cpu", "--no-extra", "--no-pmc"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["config"]["collective_backend"] == "rccl" and j["config"]["collective_world"] == 1
+    assert j["n_gpus"] == 1 and j["config"]["ensemble"]["n"] == 64 and j["config"]["ensemble"]["n_failed"] == 0
