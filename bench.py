@@ -56,6 +56,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="skip config.extra (cfg3 / window / look-ahead / end-to-end lines)")
     ap.add_argument("--streams", type=int, default=1, help="worker streams the batch is spread over")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="contexts (slab sets) the steps are dealt over, one HIP stream each, so that successive calls too small "
+                         "to fill the chip overlap on the GPU; 0 = auto: 2 for --scaling strong with <= 128 fits per rank, else 1")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch fits per GPU and step; strong: --batch fits per step over ALL ranks (contiguous shards)")
     return ap.parse_args(argv)
@@ -194,10 +197,26 @@ def run_rank(args):
     _, N, d = X.shape
     peak = FP64_MFMA_PEAK_TFLOPS if dts == "f64" else FP32_MFMA_PEAK_TFLOPS
     ablation = False
+    depth = args.pipeline if args.pipeline > 0 else (2 if strong and B <= 128 else 1)
     if not dry:
         W = Workload(engine, torch, dev, local, kid, X, y, Xs, th, dts, args.streams)
         ablation = bool(engine.load().cgp_build_flags() & engine.BUILD_ABLATION) and bool(os.environ.get("CGP_DBG"))
         step = W.step
+        if depth > 1:
+            # Successive calls of a sweep are independent; a call of a few dozen fits leaves most CUs idle in its
+            # chain-bound early block steps.  `depth` contexts (own slabs, own outputs), one HIP stream each, take
+            # the steps round-robin: step i + 1's early launches run beside step i's MFMA-bound late ones.  Every
+            # step still does all of its work; the timed region is bracketed as before.
+            lanes = [W] + [Workload(engine, torch, dev, local, kid, X, y, Xs, th, dts, args.streams) for _ in range(depth - 1)]
+            for ln in lanes:
+                ln.torch_stream = torch.cuda.Stream(dev)
+                ln.stream = ln.torch_stream.cuda_stream
+            torch.cuda.synchronize()
+            turn = [0]
+
+            def step():
+                lanes[turn[0] % depth].step()
+                turn[0] += 1
     else:
         def step():
             time.sleep(0.002)
@@ -232,6 +251,10 @@ def run_rank(args):
 
     single_ms = None
     if not dry:
+        if depth > 1:
+            assert all(int(ln.dinfo.abs().sum().item()) == 0 for ln in lanes)
+            W.stream = torch.cuda.current_stream().cuda_stream   # what follows is lane 0 alone, on the default stream
+            torch.cuda.synchronize()
         single_ms = W.single_fit_latency_ms()
         # per-fit summaries gathered over RCCL (the only collective on the path: SURVEY.md 8e)
         summ = torch.stack([W.dlogml, 2.0 * W.dvar.to(torch.float64).max(1).values.sqrt(), W.dinfo.to(torch.float64)], 1)
@@ -252,7 +275,7 @@ def run_rank(args):
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: batch of independent fixed-theta GP fits, "
                                    f"N={N} d={d} M={M_TEST} kernel={'SE-ARD' if kid == 1 else 'SE-iso'} {dts}",
                        "fits_per_gpu_per_step": B if not strong else B_total / world, "fits_per_step_all_ranks": B_total,
-                       "streams": args.streams, "N": N, "d": d, "M": M_TEST,
+                       "streams": args.streams, "pipeline_depth": depth, "N": N, "d": d, "M": M_TEST,
                        "single_fit_latency_ms": single_ms,
                        "fit_tflops": value * f_fit / 1e12, "cholesky_roofline_frac": value * f_chol / 1e12 / world / peak,
                        "inputs": "resident in HBM", "ensemble": ens,
@@ -541,7 +564,27 @@ def extras_cfg3(engine, torch, dev, local, W):
             ex["cfg3_strong_scaling_projection_8gpu"] = 8 * (64 / el64) / (512 / el)
             ex["cfg3_strong_scaling_note"] = ("8 x (64-fit call rate) / (512-fit call rate) on this one GPU; measure it with "
                                               "`bench.py --scaling strong --config 3 --gpus 8`")
-            del W64
+            # the same 64-fit calls dealt over TWO contexts on two HIP streams (what --scaling strong does by default):
+            # successive calls overlap, the chain-bound early block steps of one beside the MFMA-bound late ones of the other
+            W64b = Workload(engine, torch, dev, local, kid, X[:64], y[:64], Xs[:64], th[:64], dts, 1)
+            lanes = [W64, W64b]
+            for ln in lanes:
+                ln.torch_stream = torch.cuda.Stream(dev)
+                ln.stream = ln.torch_stream.cuda_stream
+            torch.cuda.synchronize()
+            for i in range(8):
+                lanes[i % 2].step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(40):
+                lanes[i % 2].step()
+            torch.cuda.synchronize()
+            el64p = (time.perf_counter() - t0) / 40
+            assert int(W64.dinfo.abs().sum().item()) == 0 and int(W64b.dinfo.abs().sum().item()) == 0
+            assert torch.equal(W64.dmean, W64b.dmean) and torch.equal(W64.dlogml, W64b.dlogml)
+            ex["cfg3_fits_per_s_at_64_pipelined2"] = 64 / el64p
+            ex["cfg3_strong_scaling_projection_8gpu_pipelined2"] = 8 * (64 / el64p) / (512 / el)
+            del W64, W64b
             # for the CPU leg (the only place of this program that may run the oracle): inputs and the timed outputs
             ex["_cpu_leg"] = (kid, X, y, Xs, th, W3.dmean, W3.dvar, W3.dlogml, fit_flops(1024, 6, M_TEST)[1])
             del W3

@@ -148,9 +148,10 @@ struct Launcher {
   }
 };
 
-// Batches up to this size take the latency schedule: the measured crossover against the throughput schedule
-// (tools/lat_crossover.sh) is 16 fits in fp64 and 24 in fp32.
-constexpr int LAT_FITS_F64 = 16, LAT_FITS_F32 = 24;
+// Batches up to this size take the latency schedule: the measured crossover against the (mid-size) throughput
+// schedule (tools/lat_crossover.sh, round 3: N = 2048 fp64 8 fits 1.87 vs 2.64 ms, 12 fits 2.72 vs 2.66; N = 1024 fp32
+// 20 fits 0.641 vs 0.672 ms, 24 fits 0.769 vs 0.712) is 11 fits in fp64 and 20 in fp32 (16 / 24 before the mid-size form).
+constexpr int LAT_FITS_F64 = 11, LAT_FITS_F32 = 20;
 constexpr int FUSED64_BELOW = 512;                // fp64 throughput schedule: diagonal tiles inside the panel launches below this batch
 // Calls too small to fill the chip (a launch then lasts as long as its longest workgroup chain): the next launch's
 // kind-A tile is pre-updated by a kind-C workgroup (k_panel), and fp32 takes the deep-prefetch loops (DEEP).
@@ -182,6 +183,9 @@ template <typename T> constexpr int potf2_lds_bytes() {
   return (TS * LDP + 8 * DB * DB + 4 * DB * DB) * (int)sizeof(T) + 16;
 }
 
+#ifndef CGP_F32_FULL_DEEP
+#define CGP_F32_FULL_DEEP 0   // `make variant` A/B: the deep-prefetch fp32 loops at full batch too (measured slower: 128 -> 168 VGPRs)
+#endif
 // hipFuncSetAttribute applies to the CURRENT device's function object: called from cgp_create after
 // hipSetDevice, once per (device, dtype).
 template <typename T> int set_lds_attrs(int device) {
@@ -197,6 +201,7 @@ template <typename T> int set_lds_attrs(int device) {
   ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T>), paneldiag_lds_bytes<T>());
   ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true>), paneldiag_lds_bytes<T>());
   ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, true>), paneldiag_lds_bytes<T>());
+  if (CGP_F32_FULL_DEEP && sizeof(T) == 4) ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, false>), paneldiag_lds_bytes<T>());
 #ifdef CGP_AB
   ok = ok && set(reinterpret_cast<const void *>(&k_diag<T>), tile);
 #endif
@@ -289,6 +294,7 @@ const SchedSwitches &sched_switches() {
 // image-A compiled in; fp32: deep-prefetch loops)
 template <typename T> void launch_panel_diag(bool mid, dim3 grid, hipStream_t s, const FitArgs &a, int k) {
   if (mid) hipLaunchKernelGGL((k_panel<T, true, true, true>), grid, dim3(256), paneldiag_lds_bytes<T>(), s, a, k);
+  else if (CGP_F32_FULL_DEEP && sizeof(T) == 4) hipLaunchKernelGGL((k_panel<T, true, true, false>), grid, dim3(256), paneldiag_lds_bytes<T>(), s, a, k);
   else hipLaunchKernelGGL((k_panel<T, true>), grid, dim3(256), paneldiag_lds_bytes<T>(), s, a, k);
 }
 
@@ -462,7 +468,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       const bool hasC = mid && k + 2 < a.NT, imgA = mid && hasA && k >= 1;  // launch k - 1 had a kind C iff k + 1 < NT
       FitArgs ak = ga[g];
       ak.diag_slots = (hasA ? 1 : 0) | (hasB ? 2 : 0) | (hasC ? 4 : 0) | (imgA ? 8 : 0);
-      ak.diag_stride = sizeof(T) == 8 ? 2 : (mid ? 3 : 4);  // workgroups per CU of k_panel<T, true> (LDS / VGPR bound)
+      ak.diag_stride = sizeof(T) == 8 ? 2 : (mid || CGP_F32_FULL_DEEP ? 3 : F32_FULL_OCC);  // workgroups per CU of k_panel<T, true> (LDS / VGPR bound)
       const int gx = gx_t + (hasB ? 1 : 0) + (hasC ? 1 : 0);  // gx_t already counts row tile k + 1 (kind A)
       // algorithmic flops of THIS launch: kind C does the part of tile (k + 2, k + 1) that kind A of launch k + 1 no longer does
       double fl = panel_flops(a.N, a.M, a.d, k, true, gb[g]) + (hasA ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0);

@@ -1006,8 +1006,12 @@ __device__ __forceinline__ void panel_partial(const FitArgs &p, typename Prec<T>
 // that leave most CUs with one or two workgroups, where nothing else hides the memory latency -- with four
 // workgroups per CU the register-staged loop is 4.5 % faster: 128 instead of 156 VGPRs).
 // MID: kinds C / image-A compiled in (their branches cost registers the full-batch build cannot spare).
+#ifndef CGP_F32_FULL_OCC
+#define CGP_F32_FULL_OCC 4   // workgroups per CU the register-staged fp32 build is compiled for (`make variant` A/B: 3)
+#endif
+constexpr int F32_FULL_OCC = CGP_F32_FULL_OCC;
 template <typename T, bool DIAGNEXT = false, bool DEEP = sizeof(T) == 8, bool MID = false>
-__global__ __launch_bounds__(256, sizeof(T) == 4 ? (DEEP ? 3 : 4) : 2) void k_panel(FitArgs p, int k) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? (DEEP ? 3 : F32_FULL_OCC) : 2) void k_panel(FitArgs p, int k) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the batched fit + predict against the oracle (test infrastructure: uses oracle/):
 random window length N (around every tile and schedule boundary), horizon M (0, around multiples of 128), input
-dimension, kernel, precision and call size (either side of the latency / throughput and fused / split switches).
+dimension, kernel, precision and call size (either side of the latency / mid-size / full-batch switches).
    python tests/fuzz/fuzz_parity.py [seconds=120] [seed=0]
 Prints one line per case that fails its bar and a summary; exit 1 on any.  Bars: fp64 1e-6, fp32 1e-3 (north_star),
 the fp32 one widened to 10x the error LAPACK itself makes in single precision on the same window (spotrf / strtrs on
 the fp64 Gram matrix rounded to fp32) where the window is too ill-conditioned for single precision to hold 1e-3 --
 dense 1-D inputs.  The reference's RBF x Brownian kernel on raw tick counts (cond ~ 1e6) is an fp64 path, as in the
-reference: its fp32 cases are run (no crash, finite results) and reported, not judged."""
+reference; in fp32 its contract (include/corenav_gp.h) is 3x that widened bar -- max(3e-3, 30x single-precision
+LAPACK's own error on the window) -- and it IS judged here (worst seen in 17 000 cases of round 2: 2.0x)."""
+BROWN32_FACTOR = 3.0
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -47,7 +49,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 NS = [3, 15, 16, 17, 127, 128, 129, 134, 255, 256, 257, 300, 383, 384, 385, 511, 512, 513, 640, 700, 1000, 1024, 1100]
 MS = [0, 1, 5, 126, 127, 128, 129, 255, 256, 300, 599]
-BS = [1, 2, 4, 5, 15, 16, 17, 23, 24, 25, 33]
+BS = [1, 2, 4, 5, 10, 11, 12, 19, 20, 21, 33, 48, 49, 96, 97]   # either side of the latency (11 / 20), mid-size (48 / 96) switches
 t_end, cases, bad, marginal, brown32, worst = time.time() + budget, 0, 0, 0, 0.0, {"f64": 0.0, "f32": 0.0}
 while time.time() < t_end:
     N, M, B = int(rng.choice(NS)), int(rng.choice(MS)), int(rng.choice(BS))
@@ -96,8 +98,10 @@ while time.time() < t_end:
             mscale = max(float(np.max(np.abs(omu))), 0.1 * float(np.max(np.abs(y[b]))))
             e = max(e, float(np.max(np.abs(mean[b] - omu)) / mscale), float(np.max(np.abs(var[b] - ovar) / np.abs(ovar))))
         if f32 and kid == synth.KERNEL_RBF_BROWNIAN:
-            # outside what CGP_F32 promises (include/corenav_gp.h): raw tick counts give cond(Ky) ~ 1e6; reported, not judged
+            # raw tick counts give cond(Ky) ~ 1e6: CGP_F32's contract for this kernel is BROWN32_FACTOR x the widened bar
             brown32 = max(brown32, e / tol_b)
+            if not (e < BROWN32_FACTOR * tol_b):
+                print("FAIL", tag, "fit", b, "err", e, "bar", BROWN32_FACTOR * tol_b); bad += 1
             continue
         worst["f32" if f32 else "f64"] = max(worst["f32" if f32 else "f64"], e / tol_b)
         if not (e < tol_b):
@@ -106,5 +110,5 @@ while time.time() < t_end:
             else:
                 print("FAIL", tag, "fit", b, "err", e, "bar", tol_b); bad += 1
 print(f"cases {cases} failures {bad} fp32-marginal {marginal} worst error / bar: fp64 {worst['f64']:.3g} fp32 {worst['f32']:.3g} "
-      f"(fp32 RBF x Brownian, not judged: {brown32:.3g})")
+      f"(fp32 RBF x Brownian, judged at {BROWN32_FACTOR:g}x: {brown32:.3g})")
 sys.exit(1 if bad else 0)

@@ -232,7 +232,7 @@ def test_config3_fp32_batch(engine):
 
 def test_config3_fp32_full_size_throughput_schedule(engine):
     """BASELINE configs[2] at its own size AND on the schedule the 512-fit sweep takes: N=1024 d=6 fp32,
-    M=599, 26 fits (above the fp32 latency crossover of 24 -> k_panel<float> with the diagonal tiles inside),
+    M=599, 26 fits (above the fp32 latency crossover of 20 -> k_panel<float> with the diagonal tiles inside, mid-size form),
     every other fit against the oracle at north_star's fp32 bar (1e-3), per-fit random length-scales as SURVEY.md
     8d prescribes for cfg3."""
     kid, X, y, Xs, th, _ = synth.config(3, batch=26)
@@ -366,7 +366,7 @@ def test_multi_tile_single_fit(engine):
 
 @pytest.mark.parametrize("dtype_name,N", [("F64", 700), ("F32", 300)])
 def test_throughput_schedule_matches_oracle(engine, dtype_name, N):
-    """Batches above 16 (fp64) / 24 (fp32) fits take the throughput schedule (k_diag_lean + k_panel, what bench.py times);
+    """Batches above 11 (fp64) / 20 (fp32) fits take the throughput schedule (k_diag_lean + k_panel, what bench.py times);
     smaller ones the latency schedule (k_tile_sk / k_trmm_sk; crossover measured with tools/lat_crossover.sh).
     Same parity bar for both, and a fit's result must not depend on which other fits share the batch (bitwise,
     within a schedule)."""
@@ -389,10 +389,10 @@ def test_throughput_schedule_matches_oracle(engine, dtype_name, N):
 
 @pytest.mark.parametrize("dtype_name,N", [("F64", 700), ("F32", 520)])
 def test_latency_schedule_mid_batch(engine, dtype_name, N):
-    """The latency schedule at the top of its range (16 fits per call in fp64, 24 in fp32): oracle parity, and a
+    """The latency schedule at the top of its range (11 fits per call in fp64, 20 in fp32): oracle parity, and a
     fit's result does not depend on its companions or on its slot in the call (bitwise)."""
     dtype, tol = getattr(engine, dtype_name), (TOL64 if dtype_name == "F64" else TOL32)
-    B = 16 if dtype_name == "F64" else 24
+    B = 11 if dtype_name == "F64" else 20
     kid, X, y, Xs, th, _ = synth.config(2, batch=B, N=N)
     ctx = engine.Context(max_n=N, max_m=Xs.shape[1], max_d=X.shape[2], max_batch=B, dtype=dtype)
     rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
@@ -402,7 +402,7 @@ def test_latency_schedule_mid_batch(engine, dtype_name, N):
         omu, ovar = go.predict(f, Xs[b])
         assert relmax(mean[b], omu) < tol and releach(var[b], ovar) < tol
         assert abs(logml[b] - f.logml) <= tol * abs(f.logml)
-    sel = [B - 1, 5, 11, 0, 13]
+    sel = [B - 1, 5, 9, 0, 3]
     rc, ms, vs, ls, _ = ctx.fit_predict_batch(X[sel], y[sel], Xs[sel], th[sel], kid)
     assert rc == 0
     assert np.array_equal(ms, mean[sel]) and np.array_equal(vs, var[sel]) and np.array_equal(ls, logml[sel])

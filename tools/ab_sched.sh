@@ -5,7 +5,7 @@ tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 AB=$R/corenav_gp_amd/libcorenav_gp_ab.so
-run() { name=$1; shift; env "$@" CGP_LIB=$AB python3 $R/bench.py --no-cpu --no-extra "${ARGS[@]}" 2>/dev/null | tail -1 | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('$name', round(j['value'],1), round(j['ms_per_step'],3), j['kernel_ms_per_step'])"; }
+run() { name=$1; shift; env "$@" CGP_LIB=$AB python3 $R/bench.py --no-pmc --no-cpu --no-extra "${ARGS[@]}" 2>/dev/null | tail -1 | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('$name', round(j['value'],1), round(j['ms_per_step'],3), j['kernel_ms_per_step'])"; }
 ARGS=("$@")
 for rep in 1 2; do
   run default CGP_X=0

@@ -9,11 +9,11 @@ tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --no-cpu --no-extra "$@" > $O/${tag}_bench.json 2> $O/${tag}_bench.err
-CGP_PROF_DUMP=1 python3 $R/bench.py --no-cpu --no-extra --steps 2 --warmup 1 "$@" > $O/${tag}_dump.json 2> $O/${tag}_dump.err
+python3 $R/bench.py --no-pmc --no-cpu --no-extra "$@" > $O/${tag}_bench.json 2> $O/${tag}_bench.err
+CGP_PROF_DUMP=1 python3 $R/bench.py --no-pmc --no-cpu --no-extra --steps 2 --warmup 1 "$@" > $O/${tag}_dump.json 2> $O/${tag}_dump.err
 AB=$R/corenav_gp_amd/libcorenav_gp_ab.so
 for dbg in 64 128 192; do
-  CGP_LIB=$AB CGP_DBG=$dbg python3 $R/bench.py --no-cpu --no-extra "$@" > $O/${tag}_dbg$dbg.json 2> $O/${tag}_dbg$dbg.err
+  CGP_LIB=$AB CGP_DBG=$dbg python3 $R/bench.py --no-pmc --no-cpu --no-extra "$@" > $O/${tag}_dbg$dbg.json 2> $O/${tag}_dbg$dbg.err
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats -o $tag -- python3 $R/bench.py --no-pmc --no-cpu --no-extra --steps 5 --warmup 2 "$@" > $O/${tag}_stats.log 2>&1
 for f in $O/${tag}_bench.json $O/${tag}_dbg64.json $O/${tag}_dbg128.json $O/${tag}_dbg192.json; do tail -1 $f | cut -c1-200; done

@@ -5,5 +5,5 @@ tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for v in new prev; do
   if [ $v = new ]; then lib=$R/corenav_gp_amd/libcorenav_gp.so; else lib=$R/corenav_gp_amd/libcorenav_gp_prev.so; fi
-  CGP_LIB=$lib CGP_PROF_DUMP=1 python3 $R/bench.py --no-cpu --no-extra --steps 2 --warmup 1 "$@" 2>&1 >/dev/null | grep "cgp prof" > $R/gpurun_out/${tag}_dump_$v.txt
+  CGP_LIB=$lib CGP_PROF_DUMP=1 python3 $R/bench.py --no-pmc --no-cpu --no-extra --steps 2 --warmup 1 "$@" 2>&1 >/dev/null | grep "cgp prof" > $R/gpurun_out/${tag}_dump_$v.txt
 done
