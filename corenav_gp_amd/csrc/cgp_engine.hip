@@ -55,7 +55,7 @@ struct cgp_ctx {
   hipStream_t wstream[kMaxStreams] = {nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr};
   hipEvent_t ev_look[3 * 64] = {nullptr};  // look-ahead schedule: diag / P1 / P2 completion per step
-  int nstreams = 4;
+  int nstreams = 1;   // cgp_set_streams: worker streams a LARGE batch is cut over (measured: no gain since the diagonal tiles ride in the panel launches)
   // device buffers
   void *Lw = nullptr, *Winv = nullptr, *dX = nullptr, *dXs = nullptr, *dy = nullptr;
   void *dmean = nullptr, *dvar = nullptr, *dalpha = nullptr;
@@ -158,6 +158,10 @@ constexpr int FUSED64_BELOW = 512;                // fp64 throughput schedule: d
 // Measured crossover (tools/r3_mid2.sh, same box, CGP_MID_FITS either side): fp32 N = 1024: 32 fits +14 %, 48 +13 %,
 // 64 +9 %, 96 +2 %, 128 -4 %; fp64 N = 2048: 24 fits +18 %, 32 +11 %, 48 +4 %, 64 -2 %.
 constexpr int MID_FITS_F64 = 48, MID_FITS_F32 = 96;
+#ifndef CGP_NO_EXTRA_SPLIT
+#define CGP_NO_EXTRA_SPLIT 0   // `make variant` A/B: mid-size calls keep the extra rows inside the factorisation launches
+#endif
+constexpr bool kNoExtraSplit = CGP_NO_EXTRA_SPLIT != 0;
 constexpr int MID_FITS_ALLOC = kAbBuild ? 512 : (MID_FITS_F64 > MID_FITS_F32 ? MID_FITS_F64 : MID_FITS_F32);
 template <typename T> inline int mid_fits() {     // ablation build: CGP_MID_FITS moves the crossover (measurement)
   if constexpr (kAbBuild) {
@@ -201,6 +205,7 @@ template <typename T> int set_lds_attrs(int device) {
   ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T>), paneldiag_lds_bytes<T>());
   ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true>), paneldiag_lds_bytes<T>());
   ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, true>), paneldiag_lds_bytes<T>());
+  ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, false, true, false>), panel_lds_bytes<T>());
   if (CGP_F32_FULL_DEEP && sizeof(T) == 4) ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, false>), paneldiag_lds_bytes<T>());
 #ifdef CGP_AB
   ok = ok && set(reinterpret_cast<const void *>(&k_diag<T>), tile);
@@ -298,6 +303,11 @@ template <typename T> void launch_panel_diag(bool mid, dim3 grid, hipStream_t s,
   else hipLaunchKernelGGL((k_panel<T, true>), grid, dim3(256), paneldiag_lds_bytes<T>(), s, a, k);
 }
 
+// The extra-row tiles of block step k alone (rows_from_extra), in the loop flavour of the mid-size build
+template <typename T> void launch_panel_rows(dim3 grid, hipStream_t s, const FitArgs &a, int k) {
+  hipLaunchKernelGGL((k_panel<T, false, true, false>), grid, dim3(256), panel_lds_bytes<T>(), s, a, k);
+}
+
 template <typename T> void launch_diag(const FitArgs &a, int nfits, int k, bool fat, hipStream_t s) {
 #ifdef CGP_AB
   if (fat) {
@@ -324,7 +334,8 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // latency schedule: a handful of fits, windows long enough for splitting to pay and short enough for the
   // diagonal tile's pre-update images (N <= 2560); anything else takes the throughput schedule
   const bool latency = !sw.no_latency && batch <= std::min(lat_fits<T>(), c->lat_cap) && a.NT >= 3 && lat_images(a.NT - 1) <= LAT_IMG_MAX;
-  if (latency) G = 1;
+  const bool mid = batch <= std::min(mid_fits<T>(), c->mid_cap);  // the whole call (the images are indexed by fit)
+  if (latency || mid) G = 1;  // a mid-size call has its own concurrency (factorisation || extra rows, below)
   std::vector<FitArgs> ga(G);
   std::vector<int> gb(G);
   std::vector<hipStream_t> gs(G);
@@ -448,15 +459,33 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // batch (3.3 ms per N = 2048 schedule), so below FUSED64_BELOW fits per call the fused form wins there too
   // (batch 32 +26 %, 64 +15 %, 128 +6 %, 256 +0.2 %, 512 -0.7 %).
   const bool fused64 = sw.fused_diag || batch < FUSED64_BELOW;
-  const bool mid = batch <= std::min(mid_fits<T>(), c->mid_cap);  // the whole call (the images are indexed by fit)
   const bool split_diag = sw.split_diag || !in_rows || (sizeof(T) == 8 && !fused64);
+  // Mid-size calls: the extra rows (test points and y: M + 1 of them against N - 128 (k + 1) matrix rows, i.e. most of
+  // the update work) do not feed the factorisation, only their own next block column.  They get launches of their own on
+  // a second stream -- E(k), after the launch that finished diagonal tile k -- so the chain-bound factorisation launches
+  // A(k) (few workgroups, long chains) run beside the MFMA-bound extra-row launches instead of in lock-step with them:
+  //     s :  diag(0)  A(0)  A(1)  A(2) ...            A(k): matrix tiles of step k + kinds A / B / C
+  //     sE:           E(0)  E(1)  E(2) ...            E(k) waits for A(k - 1) (W_k, row panel k) and follows E(k - 1)
+  const bool xsplit = mid && in_rows && !split_diag && G == 1 && a.ET > 0 && !kNoExtraSplit;
+  hipStream_t sE = c->wstream[0];
+  Launcher LE{c, sE};
   for (int k = 0; k < a.NT; ++k) {
-    const int gx_t = (in_rows ? a.NT - k - 1 : 0) + a.ET;
+    const int gx_t = (in_rows ? a.NT - k - 1 : 0) + (xsplit ? 0 : a.ET);
     for (int g = 0; g < G; ++g) {
       if (in_rows && (split_diag || k == 0)) {
         L[g].begin(1, diag_flops(a.N, a.d, k, gb[g]));
         launch_diag<T>(ga[g], gb[g], k, sw.fat_diag, gs[g]);
         L[g].end();
+      }
+      if (xsplit) {
+        // E(k) needs W_k and the row panel k: diag(0) for k = 0, else everything up to A(k - 1), the last thing queued on s
+        HIP_TRY(c, hipEventRecord(c->ev_look[k], s));
+        HIP_TRY(c, hipStreamWaitEvent(sE, c->ev_look[k], 0));
+        FitArgs ae = ga[g];
+        ae.rows_from_extra = 1;
+        LE.begin(0, panel_flops(a.N, a.M, a.d, k, false, gb[g]), k);
+        launch_panel_rows<T>(dim3(a.ET, gb[g]), sE, ae, k);
+        LE.end();
       }
       if (split_diag) {
         L[g].begin(0, panel_flops(a.N, a.M, a.d, k, in_rows, gb[g]), k);
@@ -472,16 +501,22 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       const int gx = gx_t + (hasB ? 1 : 0) + (hasC ? 1 : 0);  // gx_t already counts row tile k + 1 (kind A)
       // algorithmic flops of THIS launch: kind C does the part of tile (k + 2, k + 1) that kind A of launch k + 1 no longer does
       double fl = panel_flops(a.N, a.M, a.d, k, true, gb[g]) + (hasA ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0);
+      if (xsplit) fl -= panel_flops(a.N, a.M, a.d, k, false, gb[g]);
       auto tile_part = [&](int kc, int ncols) {  // Gram + `ncols` inner columns of one 128-row tile of block column kc, all fits
         const double w = std::min(TS, a.N - kc * TS), rows = std::min(TS, a.N - (kc + 1) * TS);
         return gb[g] * rows * w * (2.0 * ncols + (3.0 * a.d + 2.0));
       };
       if (imgA) fl -= tile_part(k, (k - 1) * TS);
       if (hasC) fl += tile_part(k + 1, k * TS);
+      if (gx < 1) continue;  // (mid-size call, last block step: the extra rows are all that is left)
       L[g].begin(0, fl, k);
       launch_panel_diag<T>(mid, dim3(gx, gb[g]), gs[g], ak, k);
       L[g].end();
     }
+  }
+  if (xsplit) {  // join: k_finalize reads the extra rows
+    HIP_TRY(c, hipEventRecord(c->ev_join[0], sE));
+    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[0], 0));
   }
   for (int g = 0; g < G; ++g) {
     L[g].begin(3, gb[g] * (4.0 * a.M * a.N + 2.0 * a.N));

@@ -183,7 +183,7 @@ int cgp_sweep_fit_predict(cgp_sweep *sweep, int batch, int N, int d, int M, int 
                           int include_noise, double *mean, double *var, double *logml, int *info,
                           double *summary);
 
-/* Number of worker streams a batch is spread over (1..8, default 4): the batch is cut into that
+/* Number of worker streams a LARGE batch is spread over (1..8, default 1): the batch is cut into that
  * many groups whose launch schedules run concurrently (HIP streams + events, forked from and
  * joined to the caller's stream), so latency-bound launches of one group overlap MFMA-bound
  * launches of another. */
