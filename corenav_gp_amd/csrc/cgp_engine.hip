@@ -162,6 +162,7 @@ constexpr int MID_FITS_F64 = 48, MID_FITS_F32 = 96;
 #define CGP_NO_EXTRA_SPLIT 0   // `make variant` A/B: mid-size calls keep the extra rows inside the factorisation launches
 #endif
 constexpr bool kNoExtraSplit = CGP_NO_EXTRA_SPLIT != 0;
+constexpr int XSPLIT64_FROM = 28;   // fp64 mid-size calls of at least this many fits put their extra rows on a second stream
 constexpr int MID_FITS_ALLOC = kAbBuild ? 512 : (MID_FITS_F64 > MID_FITS_F32 ? MID_FITS_F64 : MID_FITS_F32);
 template <typename T> inline int mid_fits() {     // ablation build: CGP_MID_FITS moves the crossover (measurement)
   if constexpr (kAbBuild) {
@@ -183,6 +184,10 @@ inline size_t alpha_lds_bytes(int NT) { return (size_t)(NT * TS + TS) * sizeof(d
 template <typename T> constexpr int upd_lds_bytes() { return 4 * KT * LDST * (int)sizeof(T); }
 template <typename T> constexpr int panel_lds_bytes() { return upd_lds_bytes<T>() + TS * (int)sizeof(T); }  // + z of one block column
 template <typename T> constexpr int paneldiag_lds_bytes() { return std::max(panel_lds_bytes<T>(), diag_lds_elems<T>() * (int)sizeof(T)); }
+// mid-size build: fp32 factors the diagonal tile in the fat form (potf2_tile), see mid_fat
+template <typename T> constexpr int paneldiag_mid_lds_bytes() {
+  return mid_fat<T, true>() ? std::max(paneldiag_lds_bytes<T>(), potf2_lds_elems<T>() * (int)sizeof(T)) : paneldiag_lds_bytes<T>();
+}
 template <typename T> constexpr int potf2_lds_bytes() {
   return (TS * LDP + 8 * DB * DB + 4 * DB * DB) * (int)sizeof(T) + 16;
 }
@@ -204,9 +209,9 @@ template <typename T> int set_lds_attrs(int device) {
   ok = ok && set(reinterpret_cast<const void *>(&k_trmm_sk<T>), upd);
   ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T>), paneldiag_lds_bytes<T>());
   ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true>), paneldiag_lds_bytes<T>());
-  ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, true>), paneldiag_lds_bytes<T>());
-  ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, false, true, false>), panel_lds_bytes<T>());
-  if (CGP_F32_FULL_DEEP && sizeof(T) == 4) ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, false>), paneldiag_lds_bytes<T>());
+  ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, true>), paneldiag_mid_lds_bytes<T>());
+  if constexpr (mid_fat<T, true>()) ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T, true>), paneldiag_mid_lds_bytes<T>());
+  if constexpr (CGP_F32_FULL_DEEP && sizeof(T) == 4) ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, false>), paneldiag_lds_bytes<T>());
 #ifdef CGP_AB
   ok = ok && set(reinterpret_cast<const void *>(&k_diag<T>), tile);
 #endif
@@ -298,8 +303,11 @@ const SchedSwitches &sched_switches() {
 // k_panel<T, true> has two builds: the full-batch one, and the one for calls that leave CUs underfilled (kinds C /
 // image-A compiled in; fp32: deep-prefetch loops)
 template <typename T> void launch_panel_diag(bool mid, dim3 grid, hipStream_t s, const FitArgs &a, int k) {
-  if (mid) hipLaunchKernelGGL((k_panel<T, true, true, true>), grid, dim3(256), paneldiag_lds_bytes<T>(), s, a, k);
-  else if (CGP_F32_FULL_DEEP && sizeof(T) == 4) hipLaunchKernelGGL((k_panel<T, true, true, false>), grid, dim3(256), paneldiag_lds_bytes<T>(), s, a, k);
+  if (mid) {
+    hipLaunchKernelGGL((k_panel<T, true, true, true>), grid, dim3(256), paneldiag_mid_lds_bytes<T>(), s, a, k);
+    return;
+  }
+  if constexpr (CGP_F32_FULL_DEEP && sizeof(T) == 4) hipLaunchKernelGGL((k_panel<T, true, true, false>), grid, dim3(256), paneldiag_lds_bytes<T>(), s, a, k);
   else hipLaunchKernelGGL((k_panel<T, true>), grid, dim3(256), paneldiag_lds_bytes<T>(), s, a, k);
 }
 
@@ -308,7 +316,13 @@ template <typename T> void launch_panel_rows(dim3 grid, hipStream_t s, const Fit
   hipLaunchKernelGGL((k_panel<T, false, true, false>), grid, dim3(256), panel_lds_bytes<T>(), s, a, k);
 }
 
-template <typename T> void launch_diag(const FitArgs &a, int nfits, int k, bool fat, hipStream_t s) {
+template <typename T> void launch_diag(const FitArgs &a, int nfits, int k, bool fat, hipStream_t s, bool mid = false) {
+  if constexpr (mid_fat<T, true>()) {
+    if (mid) {
+      hipLaunchKernelGGL((k_diag_lean<T, true>), dim3(nfits), dim3(256), paneldiag_mid_lds_bytes<T>(), s, a, k);
+      return;
+    }
+  }
 #ifdef CGP_AB
   if (fat) {
     hipLaunchKernelGGL(k_diag<T>, dim3(nfits), dim3(256), potf2_lds_bytes<T>(), s, a, k);
@@ -466,7 +480,11 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // A(k) (few workgroups, long chains) run beside the MFMA-bound extra-row launches instead of in lock-step with them:
   //     s :  diag(0)  A(0)  A(1)  A(2) ...            A(k): matrix tiles of step k + kinds A / B / C
   //     sE:           E(0)  E(1)  E(2) ...            E(k) waits for A(k - 1) (W_k, row panel k) and follows E(k - 1)
-  const bool xsplit = mid && in_rows && !split_diag && G == 1 && a.ET > 0 && !kNoExtraSplit;
+  // Measured (tools/r3_xsplit.sh, same box, variant without the split): fp64 N = 2048 48 fits 5.58 -> 4.99 ms, 32 fits 4.03 ->
+  // 3.92, 24 fits 3.48 -> 3.51, 12 fits 2.62 -> 3.45 (the call is one chain then: nothing to run beside it); fp32 N = 1024
+  // 64 fits 0.99 -> 1.01, 32 fits 0.69 -> 0.76: its launches last as long as kind A's chain at every k, so the extra rows'
+  // last launches only queue up behind it, and two contexts overlap worse (0.76 -> 0.96 ms per call).  fp64 from 28 fits.
+  const bool xsplit = mid && sizeof(T) == 8 && batch >= XSPLIT64_FROM && in_rows && !split_diag && G == 1 && a.ET > 0 && !kNoExtraSplit;
   hipStream_t sE = c->wstream[0];
   Launcher LE{c, sE};
   for (int k = 0; k < a.NT; ++k) {
@@ -474,7 +492,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     for (int g = 0; g < G; ++g) {
       if (in_rows && (split_diag || k == 0)) {
         L[g].begin(1, diag_flops(a.N, a.d, k, gb[g]));
-        launch_diag<T>(ga[g], gb[g], k, sw.fat_diag, gs[g]);
+        launch_diag<T>(ga[g], gb[g], k, sw.fat_diag, gs[g], mid && !split_diag);
         L[g].end();
       }
       if (xsplit) {
@@ -484,7 +502,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
         FitArgs ae = ga[g];
         ae.rows_from_extra = 1;
         LE.begin(0, panel_flops(a.N, a.M, a.d, k, false, gb[g]), k);
-        launch_panel_rows<T>(dim3(a.ET, gb[g]), sE, ae, k);
+        if constexpr (sizeof(T) == 8) launch_panel_rows<T>(dim3(a.ET, gb[g]), sE, ae, k);
         LE.end();
       }
       if (split_diag) {
@@ -497,7 +515,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       const bool hasC = mid && k + 2 < a.NT, imgA = mid && hasA && k >= 1;  // launch k - 1 had a kind C iff k + 1 < NT
       FitArgs ak = ga[g];
       ak.diag_slots = (hasA ? 1 : 0) | (hasB ? 2 : 0) | (hasC ? 4 : 0) | (imgA ? 8 : 0);
-      ak.diag_stride = sizeof(T) == 8 ? 2 : (mid || CGP_F32_FULL_DEEP ? 3 : F32_FULL_OCC);  // workgroups per CU of k_panel<T, true> (LDS / VGPR bound)
+      ak.diag_stride = sizeof(T) == 8 || mid ? 2 : (CGP_F32_FULL_DEEP ? 3 : F32_FULL_OCC);  // workgroups per CU of k_panel<T, true> (LDS / VGPR bound)
       const int gx = gx_t + (hasB ? 1 : 0) + (hasC ? 1 : 0);  // gx_t already counts row tile k + 1 (kind A)
       // algorithmic flops of THIS launch: kind C does the part of tile (k + 2, k + 1) that kind A of launch k + 1 no longer does
       double fl = panel_flops(a.N, a.M, a.d, k, true, gb[g]) + (hasA ? diag_flops(a.N, a.d, k + 1, gb[g]) : 0.0);

@@ -785,9 +785,13 @@ __device__ __forceinline__ void acc_image(typename Prec<T>::acc_t (&acc)[NCB][2]
     }
 }
 
-template <typename T, int MODE, bool TRI, bool DEEP = sizeof(T) == 8>
+// FAT: the launch carries potf2_lds_elems<T>() of LDS, so the tile is factored by potf2_tile (factor chain on wave 0 beside
+// the trailing updates and the inverse on waves 1-3; in-kernel clocks, fp32, lone workgroup: 67 k ticks against the packed
+// form's 89 k, 76 k against 124 k with 64 fits on the chip) -- the packed form exists to fit TWO diagonal workgroups on a CU.
+template <typename T> constexpr int potf2_lds_elems() { return TS * LDP + 8 * DB * DB + 4 * DB * DB + 8; }
+template <typename T, int MODE, bool TRI, bool DEEP = sizeof(T) == 8, bool FAT = false>
 __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
-                                          T *__restrict__ Lw, int b, int kn, int tid) {
+                                          T *__restrict__ Lw, int b, int kn, int tid, PhaseClock *pc = nullptr) {
   using P = Prec<T>;
   using vec2 = T __attribute__((ext_vector_type(2)));
   const int ld = p.ld;
@@ -821,14 +825,42 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
     if (from_image) acc_image<T, TRI, false>(acc, img, tid);
     else gram_apply<T, TRI>(p, acc, smem + CH2, b, kn, kn, tid, gp);
   }
+  if (pc) pc->lap(p, 344);  // finisher: fence + image / Gram tile (measurement build; slots 344.. = all steps summed)
   if constexpr (TRI) mfma_syrk_tri_loop<T, DEEP>(acc, gR, (size_t)ld, nchunk, smem, tid);
   else mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gR, (size_t)ld, nchunk, smem, tid);
+  if (pc) pc->lap(p, 345);  // the two newest block columns
   if constexpr (MODE == DIAG_PARTIAL) {
     acc_image<T, TRI, true>(acc, img, tid);
     return;
   }
   __syncthreads();
   T *tile = Lw + (size_t)(kn * TS) * ld + (size_t)kn * TS;
+  if constexpr (FAT) {
+    static_assert(!FAT || TRI, "the fat form takes the triangular accumulator layout");
+    T *At = smem;  // element (r, c) at At[c * LDP + r]; lower 16x16 blocks only (wave w: block rows w and 7 - w)
+    T *Dv = At + TS * LDP;
+    T *Ts = Dv + 8 * DB * DB;
+    int *flag = reinterpret_cast<int *>(Ts + 4 * DB * DB);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rb = j ? NCB - 1 - wave : wave;
+        if (cb <= rb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) At[(cb * DB + P::drow(lane, r)) * LDP + rb * DB + l15] = -acc[cb][j][r];
+        }
+      }
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    if (pc) pc->lap(p, 346);  // tile into LDS
+    potf2_tile<T>(p, At, Dv, Ts, flag, tile, ld, b, kn, tid);
+    if (pc) {
+      pc->lap(p, 347);        // factorisation + inverse + stores
+      pc->count(p, 351);
+    }
+    return;
+  }
   // S = -acc -> the 36 lower blocks
   if constexpr (TRI) {
 #pragma unroll
@@ -859,19 +891,24 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
   // (the strictly upper 16x16 blocks of the tile in HBM are never read by anybody and are left alone)
   __syncthreads();
   T *Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)kn * WIMG;
+  if (pc) pc->lap(p, 346);  // tile into LDS
   diag_factor_packed<T>(p, smem, tile, ld, Wk, b, kn, tid);
+  if (pc) {
+    pc->lap(p, 347);        // packed factorisation + inverse + stores
+    pc->count(p, 351);
+  }
 }
 
 // k_diag_lean: the diagonal tile in the LDS budget of a panel workgroup (two per CU), so that with
 // two or more fits per CU one workgroup's factorisation latency runs under the other's MFMA loop.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_diag_lean(FitArgs p, int k) {  // (k = 0 in the shipped schedules: no update loop, DEEP is moot)
+template <typename T, bool FAT = false>
+__global__ __launch_bounds__(256, 2) void k_diag_lean(FitArgs p, int k) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const int b = blockIdx.x;
   T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
   typename Prec<T>::acc_t acc[NCB][2];
-  diag_next<T, DIAG_FULL, kTriDiag>(p, acc, smem, Lw, b, k, threadIdx.x);
+  diag_next<T, DIAG_FULL, kTriDiag, sizeof(T) == 8 || FAT, FAT>(p, acc, smem, Lw, b, k, threadIdx.x);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1005,7 +1042,10 @@ __device__ __forceinline__ void panel_partial(const FitArgs &p, typename Prec<T>
 // DEEP: row panel straight to registers + LDS-DMA column panel two chunks ahead (fp64 always; fp32 for calls
 // that leave most CUs with one or two workgroups, where nothing else hides the memory latency -- with four
 // workgroups per CU the register-staged loop is 4.5 % faster: 128 instead of 156 VGPRs).
-// MID: kinds C / image-A compiled in (their branches cost registers the full-batch build cannot spare).
+// MID: kinds C / image-A compiled in (their branches cost registers the full-batch build cannot spare).  In fp32 the
+// mid-size build also takes the fat form of the diagonal tile (79 KB of LDS: two workgroups per CU, which these calls do
+// not fill anyway); fp64 would need 147 KB, one workgroup per CU, and keeps the packed form.
+template <typename T, bool MID> constexpr bool mid_fat() { return MID && sizeof(T) == 4; }
 #ifndef CGP_F32_FULL_OCC
 #define CGP_F32_FULL_OCC 4   // workgroups per CU the register-staged fp32 build is compiled for (`make variant` A/B: 3)
 #endif
@@ -1083,7 +1123,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (DEEP ? 3 : F32_FULL_OCC) : 2
   const int ld = p.ld;
   PhaseClock pc;
   pc.start(p, tid);
-  const int ps = 64 + 8 * (k & 31);  // debug slots of this step
+  const int ps = finish_next ? 336 : 64 + 8 * (k & 31);  // debug slots of this step (kind A: its own group, all steps summed)
 
   // Gram first: acc = -G(rt, kc) while nothing else is live in the register file, with chunk 0 of the
   // panels already in flight into LDS buffer 0 (the Gram inputs are staged in buffer 1's space).
@@ -1161,7 +1201,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (DEEP ? 3 : F32_FULL_OCC) : 2
   pc.lap(p, ps + 5);
   pc.count(p, ps + 7);
   if constexpr (DIAGNEXT) {
-    if (finish_next) diag_next<T, DIAG_FINISH, kTriDiag, DEEP>(p, acc, smem, Lw, b, k + 1, tid);
+    if (finish_next) diag_next<T, DIAG_FINISH, kTriDiag, DEEP, mid_fat<T, MID>()>(p, acc, smem, Lw, b, k + 1, tid, &pc);
   }
   sc.leave(p, k, tid);
 }

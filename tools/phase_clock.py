@@ -29,4 +29,18 @@ for k in range(32):
     if s[7] == 0:
         continue
     rows.append({"k": k, "wgs": int(s[7]), **{n: float(s[i]) / s[7] for i, n in enumerate(names)}})
-print(json.dumps({"config": a.config, "batch": a.batch, "step_ms": t0.elapsed_time(t1), "ticks_per_wg": rows}))
+ka = out[336:344]   # kind-A workgroups (the chain tile), all block steps summed; 344.. = their diagonal-tile finish
+fin = out[344:352]
+extra = {}
+if ka[7]:
+    extra["kind_A_tile_ticks_per_wg"] = {n: float(ka[i]) / ka[7] for i, n in enumerate(names)}
+    extra["kind_A_wgs"] = int(ka[7])
+if fin[7]:
+    extra["diag_finish_ticks_per_wg"] = {n: float(fin[i]) / fin[7] for i, n in enumerate(["fence_image_or_gram", "newest_two_block_columns", "tile_to_lds", "packed_factor_inverse_stores"])}
+pf = out[32:42]      # potf2_tile (fat diagonal tile): per tile F / P / U phase sums, tail, count, wave-0 factor, helper side, inverse, trailing
+if pf[4]:
+    n = float(pf[4])
+    extra["potf2_tile_ticks_per_tile"] = {"F_phases": pf[0] / n, "P_phases": pf[1] / n, "U_phases": pf[2] / n, "tail": pf[3] / n,
+                                          "wave0_factor_in_F": pf[5] / n, "helpers_in_F": pf[6] / n, "helpers_inverse": pf[8] / n,
+                                          "helpers_trailing": pf[9] / n, "tiles": int(pf[4])}
+print(json.dumps({"config": a.config, "batch": a.batch, "step_ms": t0.elapsed_time(t1), "ticks_per_wg": rows, **extra}))
