@@ -7,6 +7,13 @@
 #include <cmath>
 using namespace cgp;
 
+// readlane of a double (lane index wave-uniform): what the DPP form replaced (variants 1, 2, 5 keep it for the record)
+__device__ __forceinline__ double rdlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 template <int V> __device__ __forceinline__ void variant(double (&a)[DB], double (&w)[DB], int &bad, int l15);
 
 template <> __device__ __forceinline__ void variant<0>(double (&a)[DB], double (&w)[DB], int &bad, int l15) {
@@ -167,6 +174,47 @@ template <> __device__ __forceinline__ void variant<4>(double (&a)[DB], double (
   for (int i = 0; i < DB; ++i) w[i] = (i < l15) ? 0.0 : w[i];
 }
 
+
+// V6: V4 rescheduled, same arithmetic in the same order per register (bitwise V4's results):
+//  * the trailing updates of step J-1 to the columns >= J+1 are issued AFTER the broadcast of pivot J, i.e. under the
+//    rsqrt chain of step J instead of in front of it (only column J had to be current for that pivot);
+//  * the inverse's forward-substitution step J (independent of the factor chain once column J is final) is issued inside
+//    the factor loop too, so its 120 fmacs fill the chain's issue bubbles instead of forming a second serial phase.
+template <> __device__ __forceinline__ void variant<6>(double (&a)[DB], double (&w)[DB], int &bad, int l15) {
+  double t[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i) t[i] = (i == l15) ? 1.0 : 0.0;
+  double lp = 0.0, nlp = 0.0;
+  static_for<0, DB>([&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    double dj = mov_bcast<J>(a[J]);
+    if constexpr (J > 0) {
+      static_for<J + 1, DB>([&](auto cc) {
+        constexpr int C = decltype(cc)::value;
+        fmac_bcast<C, false>(a[C], lp, nlp);
+      });
+    }
+    const bool ok = dj > 0.0;
+    if (!ok && bad == 0) bad = J + 1;
+    dj = ok ? dj : 1.0;
+    const double rs = rsqrt3(dj);
+    const double l = (ok ? a[J] : ((l15 == J) ? 1.0 : a[J])) * rs;
+    a[J] = l;
+    const double nl = -l;
+    if constexpr (J + 1 < DB) fmac_bcast<J + 1, true>(a[J + 1], l, nl);
+    w[J] = t[J] * rs;
+    const double nw = -w[J];
+    static_for<J + 1, DB>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      fmac_bcast<I, false>(t[I], a[J], nw);
+    });
+    lp = l;
+    nlp = nl;
+  });
+#pragma unroll
+  for (int i = 0; i < DB; ++i) w[i] = (i < l15) ? 0.0 : w[i];
+}
+
 template <int V> __global__ __launch_bounds__(64) void kbench(const double *A, double *Lout, double *Wout, long long *cyc, int iters) {
   __shared__ double blk[DB * DB];
   const int lane = threadIdx.x, l15 = lane & 15;
@@ -216,6 +264,15 @@ template <int V> void run(const double *dA, double *dL, double *dW, long long *d
     e2 = fmax(e2, fabs(s2 - (r == c2 ? 1.0 : 0.0)));
   }
   printf("variant %d: %.1f ns per block (s_memtime 100 MHz)   |LL^T-A| %.2e   |WL-I| %.2e\n", V, c * 10.0 / iters, e1, e2);
+  // one wave per CU (the latency schedule's situation: the factor chain is alone on its SIMD)
+  kbench<V><<<256, 64>>>(dA, dL, dW, dc, iters);
+  hipDeviceSynchronize();
+  hipEventRecord(ev0);
+  kbench<V><<<256, 64>>>(dA, dL, dW, dc, iters);
+  hipEventRecord(ev1);
+  hipEventSynchronize(ev1);
+  hipEventElapsedTime(&ms, ev0, ev1);
+  printf("variant %d: lone wave per CU: %.1f ns per block wall\n", V, ms * 1e6 / iters);
 }
 
 int main() {
@@ -230,5 +287,6 @@ int main() {
   run<3>(dA, dL, dW, dc, A);
   run<4>(dA, dL, dW, dc, A);
   run<5>(dA, dL, dW, dc, A);
+  run<6>(dA, dL, dW, dc, A);
   return 0;
 }
