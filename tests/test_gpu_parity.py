@@ -522,12 +522,12 @@ def test_batch_jitter_retry_is_per_fit(engine):
 
 def test_stream_groups_do_not_change_results(engine):
     """The batch is cut into worker-stream groups (cgp_set_streams); any grouping gives bitwise the
-    same answers, including a batch that does not divide evenly (21 fits: the throughput schedule, the only one
-    that uses the groups)."""
-    kid, X, y, Xs, th, _ = synth.config(2, batch=21, N=300)
+    same answers, including a batch that does not divide evenly (53 fits: the full-batch form of the throughput schedule,
+    the only one that uses the groups -- latency and mid-size calls run as one group)."""
+    kid, X, y, Xs, th, _ = synth.config(2, batch=53, N=300)
     ref = None
     for ns in (1, 2, 4):
-        ctx = engine.Context(max_n=300, max_m=599, max_d=6, max_batch=21)
+        ctx = engine.Context(max_n=300, max_m=599, max_d=6, max_batch=53)
         ctx.set_streams(ns)
         rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
         assert rc == 0
