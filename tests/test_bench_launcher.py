@@ -78,3 +78,33 @@ def test_a_rank_that_dies_ends_the_job_quickly():
     r = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "4", CGP_BENCH_TEST_DIE_RANK="1")
     assert r.returncode != 0
     assert time.time() - t0 < 60
+
+
+def test_live_pmc_passes_are_skipped_under_a_profiler(monkeypatch):
+    """bench.py started under rocprofv3 / rocprofiler-sdk (tool library preloaded, ROCP_* / ROCPROF* set) must not start
+    profilers of its own: the nested start-up would exec out of a GPU-initialised process and pollute the outer counters."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    for k in list(os.environ):
+        if k == "LD_PRELOAD" or k.startswith(bench.PROFILER_ENV_PREFIXES):
+            monkeypatch.delenv(k, raising=False)
+    assert bench.under_profiler() is False
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert bench.under_profiler() is True
+    monkeypatch.delenv("LD_PRELOAD")
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert bench.under_profiler() is True
+    called = []
+    monkeypatch.setattr(bench.subprocess, "Popen", lambda *a, **k: called.append(a) or (_ for _ in ()).throw(AssertionError("spawned")))
+    assert bench.pmc_traffic_live(bench.parse_args([])) is None and not called
+
+
+def test_tools_never_profile_bench_with_live_pmc():
+    """Every tools/*.sh that wraps bench.py in rocprofv3 passes --no-pmc."""
+    import glob
+    import re
+    for f in glob.glob(os.path.join(ROOT, "tools", "*.sh")):
+        for line in open(f):
+            if "rocprofv3" in line and "bench.py" in line:
+                assert re.search(r"bench\.py\s+--no-pmc", line), (f, line)
