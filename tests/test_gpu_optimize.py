@@ -128,3 +128,27 @@ def test_optimize_batch_climbs_the_jitter_ladder(engine):
         th1, lml1, nev1 = ctx1.optimize(X[b], y[b], 0, th0[b].copy(), max_evals=60)
         assert np.isfinite(lml[b]) and lml[b] == pytest.approx(lml1, rel=1e-6)
         np.testing.assert_allclose(th[b], th1, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B", [14, 32])
+def test_gradient_mode_on_the_mid_size_schedule(engine, B):
+    """A batched gradient evaluation (gradient mode: the M = N "test rows" are the identity) of 14 / 32 fp64 windows of three
+    block steps takes the mid-size throughput schedule -- kind C pre-update, and from 28 fits the extra rows on a second
+    stream: value and gradient of every window equal the single-window call (latency schedule) to rounding."""
+    N, d = 300, 3
+    rng = np.random.default_rng(B)
+    X = rng.normal(size=(B, N, d))
+    y = 0.2 * np.sin(np.arange(N) / 5.0)[None] + 0.05 * rng.normal(size=(B, N))
+    th = np.stack([np.concatenate([[0.9], rng.uniform(0.6, 1.8, d), [0.08]]) for _ in range(B)])
+    ctx = engine.Context(max_n=N, max_m=N, max_d=d, max_batch=B)
+    th_b, lml_b, nev = ctx.optimize_batch(X, y, 1, th, max_evals=1)     # one evaluation: logML at the start point
+    one = engine.Context(max_n=N, max_m=N, max_d=d)
+    for b in (0, B // 2, B - 1):
+        nll, g = one.nll_grad(X[b], y[b], 1, th[b])
+        onll, og = go.nll_and_grad(1, th[b], X[b], y[b])
+        assert abs(nll - onll) <= 1e-6 * abs(onll) and np.max(np.abs(g - og)) <= 1e-6 * np.max(np.abs(og))
+    # the batched optimiser's own first evaluations, through a few real rounds
+    th2, lml2, nev2 = ctx.optimize_batch(X, y, 1, th, max_evals=6)
+    for b in (0, B - 1):
+        t1, l1, n1 = one.optimize(X[b], y[b], 1, th[b], max_evals=6)
+        assert lml2[b] == pytest.approx(l1, rel=1e-8) and np.allclose(th2[b], t1, rtol=1e-6)
