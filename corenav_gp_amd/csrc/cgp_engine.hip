@@ -82,6 +82,7 @@ struct cgp_ctx {
   // sliding windows (cgp_window_*)
   WindowArgs win{};
   int nwin = 0;
+  int win_o = 0, win_n = 0;   // origin / size of the windows (they advance in lock-step), mirrored on the host to cut a push into launches
   void *winbuf[8] = {nullptr};
   // cgp_window_push staging, grown on demand and kept: one pinned host block and one device block per direction
   void *win_pin = nullptr, *win_dev = nullptr;
@@ -162,6 +163,10 @@ constexpr int MID_FITS_F64 = 48, MID_FITS_F32 = 96;
 #define CGP_NO_EXTRA_SPLIT 0   // `make variant` A/B: mid-size calls keep the extra rows inside the factorisation launches
 #endif
 constexpr bool kNoExtraSplit = CGP_NO_EXTRA_SPLIT != 0;
+#ifndef CGP_WIN_PAIRS
+#define CGP_WIN_PAIRS 1   // sliding window: steady-state ticks two per pass over the factor (`make variant`: 0 = every tick on its own)
+#endif
+constexpr bool kWinPairs = CGP_WIN_PAIRS != 0;
 constexpr int XSPLIT64_FROM = 28;   // fp64 mid-size calls of at least this many fits put their extra rows on a second stream
 constexpr int MID_FITS_ALLOC = kAbBuild ? 512 : (MID_FITS_F64 > MID_FITS_F32 ? MID_FITS_F64 : MID_FITS_F32);
 template <typename T> inline int mid_fits() {     // ablation build: CGP_MID_FITS moves the crossover (measurement)
@@ -1346,6 +1351,9 @@ extern "C" int cgp_window_init(cgp_ctx *c, int nwin, int N, int d, int kid, cons
   const int nth = ntheta(kid, d);
   if (theta_stride < nth) return CGP_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
+  // the two-ticks-per-pass kernel keeps six window-length vectors in LDS: 98 KB at N = 2048
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_window_pairs), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+    return CGP_EHIP;
   // the old windows are gone from here on: a failure below must leave the context without windows,
   // not with stale pointers (cgp_window_push checks nwin)
   c->nwin = 0;
@@ -1396,6 +1404,7 @@ extern "C" int cgp_window_init(cgp_ctx *c, int nwin, int N, int d, int kid, cons
   }
   c->win = wa;  // published only when every allocation and copy has succeeded
   c->nwin = nwin;
+  c->win_o = c->win_n = 0;
   return CGP_OK;
 }
 
@@ -1412,8 +1421,44 @@ extern "C" int cgp_window_push_device(cgp_ctx *c, int T, const double *dxs, cons
   a.logml = dl;
   a.T = T;
   a.include_noise = include_noise;
-  const size_t lds = (size_t)(3 * a.N + 4 * WPB + MAXD + 8) * sizeof(double);
-  hipLaunchKernelGGL(k_window_ticks, dim3(c->nwin), dim3(256), lds, pick_stream(c, hip_stream), a);
+  // The T ticks are cut into launches: runs of steady-state ticks (full windows, no ring compaction inside) go two per
+  // pass over the factor (k_window_pairs), everything else -- filling, the tick that compacts the ring, an odd one out --
+  // through the single-tick kernel.  Origin and size of the windows are deterministic and identical for every window of
+  // the context, so the host mirrors them instead of reading them back.
+  const size_t lds1 = (size_t)(3 * a.N + 4 * WPB + MAXD + 8) * sizeof(double);
+  const size_t lds2 = (size_t)(6 * ((a.N + 3) & ~1) + 8 * WPB + 2 * MAXD + 16) * sizeof(double);
+  hipStream_t ws = pick_stream(c, hip_stream);
+  const int N = a.N, CAP = a.CAP;
+  int o = c->win_o, n = c->win_n;
+  auto one_tick = [&](int &oo, int &nn) {   // k_window_ticks, one tick
+    if (oo + nn >= CAP) oo = 0;
+    const bool drop = nn >= N;
+    oo = drop ? oo + 1 : oo;
+    nn = (drop ? nn - 1 : nn) + 1;
+  };
+  auto pair_ok = [&](int oo, int nn, int left) { return kWinPairs && N >= 2 * WPB && nn == N && left >= 2 && oo + N + 1 < CAP; };
+  for (int t = 0; t < T;) {
+    a.t0 = t;
+    int np = 0;
+    for (int oo = o; pair_ok(oo, n, T - t - 2 * np); oo += 2) ++np;
+    if (np > 0) {
+      a.nt = 2 * np;
+      hipLaunchKernelGGL(k_window_pairs, dim3(c->nwin), dim3(256), lds2, ws, a);
+      o += 2 * np;
+      t += 2 * np;
+      continue;
+    }
+    int ns = 0;
+    do {
+      one_tick(o, n);
+      ++ns;
+    } while (t + ns < T && !pair_ok(o, n, T - t - ns));
+    a.nt = ns;
+    hipLaunchKernelGGL(k_window_ticks, dim3(c->nwin), dim3(256), lds1, ws, a);
+    t += ns;
+  }
+  c->win_o = o;
+  c->win_n = n;
   HIP_TRY(c, hipGetLastError());
   return CGP_OK;
 }

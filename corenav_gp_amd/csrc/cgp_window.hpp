@@ -47,6 +47,7 @@ struct WindowArgs {
   const double *ys;     // [nwin][T]
   double *pred_mean, *pred_var, *logml;  // [nwin][T]
   int N, CAP, d, kernel_id, T, include_noise;
+  int t0, nt;       // this launch handles ticks [t0, t0 + nt) of the block (k_window_pairs: nt even)
 };
 
 // Covariance of two points (raw coordinates), direct formulas.
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
   const double noise = th[nth - 1];
   int o = st[0], n = st[1], bad = st[2];
 
-  for (int t = 0; t < p.T; ++t) {
+  for (int t = p.t0; t < p.t0 + p.nt; ++t) {
     // ---- make room: move the window back to the origin when it reached the end of the buffer
     if (o + n >= CAP) {
       for (int c = 0; c < n; ++c)
@@ -324,7 +325,346 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
     st[0] = o;
     st[1] = n;
     st[2] = bad;
-    st[3] += p.T;
+    st[3] += p.nt;
+  }
+}
+
+
+// --------------------------------------------------------------------------------------------------
+// k_window_pairs: TWO ticks per pass over the factor.  Under load the single-tick kernel is bound by its factor traffic
+// (every entry read once and written once per tick, 4.1-4.2 TB/s whatever the chain does), so the
+// steady-state ticks (full window, no ring compaction inside the pair) are taken two at a time: a panel's rows are loaded
+// once, take tick t's rotations and substitution update, then tick t + 1's, and are stored once.
+// With o1 = o + 1 the origin after the first drop, m = N - 1 and rows / columns counted from o1:
+//   tick t    : v1 = column -1 (the dropped one), window [0, m), new row m = (l1, d1)
+//   tick t + 1: v2 = column 0 AFTER tick t's update (row m contributes l1[0]), window [1, m], new row m + 1 = (l2, d2)
+// Both ticks share the panel grid (16 columns from o1): per panel wave 0 runs A1 (tick t: rotations + substitution of the
+// diagonal block) and then A2 (tick t + 1) on the block it still holds; in panel 0 lane 0 (row 0, dropped by tick t + 1) is
+// inert for A2 and every row's v2 is its freshly rotated column-0 entry.  Tick t's new row m is born panel by panel (l1 of a
+// panel is final after A1): until it reaches the diagonal block in the last panel it is swept like any other row -- by
+// tick t + 1's rotations only -- with its entries taken from LDS instead of memory.  Same arithmetic as two single ticks
+// (up to the order in which a row's two rotation sets are interleaved with other rows').
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int N = p.N, CAP = p.CAP, d = p.d, kid = p.kernel_id;
+  const int NS = (N + 2 + 1) & ~1;                       // per-vector LDS stride (rows 0 .. m + 1)
+  double *vv1 = reinterpret_cast<double *>(smem_raw);   // rank-1 vector of tick t
+  double *kk1 = vv1 + NS, *ll1 = kk1 + NS;               // its append right-hand side / solution
+  double *vv2 = ll1 + NS, *kk2 = vv2 + NS, *ll2 = kk2 + NS;   // the same for tick t + 1
+  double *cs1 = ll2 + NS;                                // [2][2 WPB] (c, s) of a panel, double-buffered, tick t
+  double *cs2 = cs1 + 4 * WPB;                           // tick t + 1
+  double *xn = cs2 + 4 * WPB;                            // [2][MAXD] the incoming points
+  double *red = xn + 2 * MAXD;                           // [16] scalars handed from wave 0 to the block
+  const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double *L = p.L + (size_t)w * CAP * CAP;
+  double *z = p.z + (size_t)w * CAP;
+  double *xw = p.xw + (size_t)w * d * CAP;
+  double *yw = p.yw + (size_t)w * CAP;
+  int *st = p.state + w * 4;
+  const double *pr = p.prep + (size_t)w * PREP_N;
+  const double *th = p.theta + (size_t)w * MAX_THETA;
+  const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
+  const double noise = th[nth - 1];
+  int o = st[0], bad = st[2];
+  const int m = N - 1;
+  const int npan = (m + 1 + WPB - 1) / WPB;   // panels of tick t + 1 (columns 1 .. m); tick t uses columns 0 .. m - 1
+  const int i = lane & (WPB - 1);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(L, 0, (int)((size_t)CAP * CAP * sizeof(double)), 0x00020000);
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  auto ld64 = [&](unsigned off, int soff) {
+    const u2 q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, soff, 0);
+    return __hiloint2double((int)q[1], (int)q[0]);
+  };
+  auto st64 = [&](double x, unsigned off, int soff) {
+    u2 q;
+    q[0] = (unsigned)__double2loint(x);
+    q[1] = (unsigned)__double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(q, rsrc, off, soff, 0);
+  };
+  const int colb = CAP * (int)sizeof(double);
+
+  for (int t = p.t0; t < p.t0 + p.nt; t += 2) {
+    const int o1 = o + 1;
+    if (tid < 2 * d) {
+      const int tk = tid / d, q = tid - tk * d;
+      xn[tk * MAXD + q] = p.xs[((size_t)w * p.T + t + tk) * d + q];
+    }
+    __syncthreads();
+    for (int rr = tid; rr <= m; rr += 256) {
+      if (rr < m) {
+        vv1[rr] = L[(size_t)o * CAP + o1 + rr];
+        kk1[rr] = win_cov(kid, d, pr, xw + o1 + rr, CAP, xn, 1, false);
+        kk2[rr] = win_cov(kid, d, pr, xw + o1 + rr, CAP, xn + MAXD, 1, false);
+      } else {
+        kk2[m] = win_cov(kid, d, pr, xn, 1, xn + MAXD, 1, false);   // the two incoming points
+        vv1[m] = 0.0;
+        kk1[m] = 0.0;
+        ll1[m] = 0.0;
+      }
+    }
+    double vz1 = z[o], vz2 = 0.0;   // the dropped samples' components of z
+    double sl2a = 0, slza = 0, szza = 0, sl2b = 0, slzb = 0, szzb = 0;
+    double pma = 1.0, pmb = 1.0;    // running products of the diagonals (mantissa, exponent), one per tick
+    int pea = 0, peb = 0;
+    double d1 = 1.0, znew1 = 0.0;
+    __syncthreads();
+
+    // element (row rr, column cc) of the factor, both counted from o1
+    auto eoff = [&](int rr, int cc) { return (unsigned)(((o1 + cc) * CAP + o1 + rr) * (int)sizeof(double)); };
+    // rotations of one diagonal block (lane = row), branch-free, (c, s) to csb; skip0: step 0 is not part of this tick
+    auto rotate_block = [&](double (&a)[WPB], double &vi, double &zi, double &vz, double &szz, double &idg, double *csb, bool skip0) {
+      static_for<0, WPB>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        if (J == 0 && skip0) {
+          csb[0] = 1.0;
+          csb[WPB] = 0.0;
+        } else {
+          const double ljj = mov_bcast<J>(a[J]), vj = mov_bcast<J>(vi), zj = mov_bcast<J>(zi);
+          const double r2 = __builtin_fma(vj, vj, ljj * ljj);
+          const double ri = rsqrt3(r2);
+          const double c = ljj * ri, sn = vj * ri;
+          const double aj = a[J];
+          a[J] = __builtin_fma(sn, vi, c * aj);
+          vi = __builtin_fma(c, vi, -(sn * aj));
+          const bool me = i == J;
+          idg = me ? ri : idg;
+          const double zn = __builtin_fma(sn, vz, c * zj);
+          vz = __builtin_fma(c, vz, -(sn * zj));
+          zi = me ? zn : zi;
+          szz += zn * zn;
+          csb[J] = c;
+          csb[WPB + J] = sn;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    // forward substitution of the incoming point inside the block; lane q keeps l_q
+    auto substitute_block = [&](const double (&a)[WPB], double &ki, const double &zi, const double &idg, double &sl2, double &slz, double &mine) {
+      static_for<0, WPB>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        const double lq = mov_bcast<Q>(ki * idg);
+        ki = __builtin_fma(-a[Q], lq, ki);
+        sl2 = __builtin_fma(lq, lq, sl2);
+        fmac_bcast<Q, true>(slz, zi, lq);
+        mine = (i == Q) ? lq : mine;
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    auto diag_product = [&](const double (&a)[WPB], double &pm, int &pe) {
+      double dg = 1.0;
+#pragma unroll
+      for (int j = 0; j < WPB; ++j) dg = (i == j) ? a[j] : dg;
+      pm *= dg;
+      pe += __builtin_amdgcn_frexp_exp(pm);
+      pm = __builtin_amdgcn_frexp_mant(pm);
+    };
+    // one row of the sweep with one tick's rotations
+    auto sweep_row = [&](double (&a)[WPB], double &v, double &k, const double *csb, const double *lp) {
+#pragma unroll
+      for (int j = 0; j < WPB; ++j) {
+        const double c = csb[j], sn = csb[WPB + j], aj = a[j];
+        const double tv = __builtin_fma(sn, v, c * aj);
+        v = __builtin_fma(c, v, -(sn * aj));
+        a[j] = tv;
+        k = __builtin_fma(-tv, lp[j], k);
+      }
+    };
+    // a row below the diagonal block of panel pi through both ticks: tick t (rows < m), then tick t + 1
+    auto both_ticks = [&](double (&a)[WPB], int rr, int pi, double &v1, double &k1, double &v2, double &k2) {
+      const int p0 = pi * WPB, cso = (pi & 1) * 2 * WPB;
+      if (rr < m) sweep_row(a, v1, k1, cs1 + cso, ll1 + p0);
+      if (pi == 0) v2 = a[0];   // column 0 after tick t: this row's entry of tick t + 1's rank-1 vector
+      sweep_row(a, v2, k2, cs2 + cso, ll2 + p0);
+    };
+    // the 16 panel entries of row rr: memory, or -- tick t's new row m, which exists only as l1 so far -- LDS
+    auto load_row = [&](double (&a)[WPB], int rr, int p0, bool live) {
+      const unsigned off = eoff(live ? rr : 0, p0);
+#pragma unroll
+      for (int j = 0; j < WPB; ++j) {
+        const double x = ld64(off, j * colb);
+        a[j] = !live ? 0.0 : (rr == m ? ll1[p0 + j] : x);
+      }
+    };
+
+    // ---- wave 0 state: the diagonal block's rows of v, k, z for both ticks (registers across panels)
+    double v1i = 0, k1i = 0, v2i = 0, k2i = 0, zi = 0;
+    auto block_ab = [&](int pi, double (&a)[WPB]) {   // A1 then A2 on the diagonal block of panel pi (a[], zi, v1i .. k2i loaded)
+      const int p0 = pi * WPB;
+      const int nb1 = max(0, min(WPB, m - p0));        // rows / columns of tick t in this block
+      const int nb2 = min(WPB, m + 1 - p0);            // of tick t + 1 (the block's last row may be row m)
+      double *c1 = cs1 + (pi & 1) * 2 * WPB, *c2 = cs2 + (pi & 1) * 2 * WPB;
+      // ---- A1
+      {
+        double idg = 1.0, mine = 0.0;
+        rotate_block(a, v1i, zi, vz1, szza, idg, c1, false);
+        if (lane < nb1) diag_product(a, pma, pea);
+        substitute_block(a, k1i, zi, idg, sl2a, slza, mine);
+        if (lane < nb1) ll1[p0 + i] = mine;
+      }
+      if (p0 + WPB > m) {
+        // the last panel: tick t's new row m = (l1, d1) joins the block as row m - p0, with its z
+        const double kss1 = (kid == K_RBF_BROWNIAN) ? pr[9] * pr[10] * fabs(xn[0]) : pr[9];
+        double dd = kss1 + noise + 1e-8 - sl2a;
+        if (!(dd > 0.0)) {
+          if (bad == 0) bad = t + 1;
+          dd = 1e-300;
+        }
+        d1 = sqrt(dd);
+        znew1 = (p.ys[(size_t)w * p.T + t] - slza) / d1;
+        const int im = m - p0;
+        if (i == im) {
+#pragma unroll
+          for (int j = 0; j < WPB; ++j) a[j] = j < im ? ll1[p0 + j] : (j == im ? d1 : 0.0);
+          zi = znew1;
+        }
+      }
+      // ---- A2
+      {
+        const bool first = pi == 0;
+        if (first) {
+          vz2 = mov_bcast<0>(zi);           // row 0's z after tick t: the component tick t + 1 drops
+          v2i = i == 0 ? 0.0 : a[0];        // column 0 after tick t; row 0 itself is inert from here on
+          zi = i == 0 ? 0.0 : zi;
+          k2i = i == 0 ? 0.0 : k2i;
+        }
+        double idg = 1.0, mine = 0.0;
+        rotate_block(a, v2i, zi, vz2, szzb, idg, c2, first);
+        if (lane < nb2 && !(first && i == 0)) diag_product(a, pmb, peb);
+        substitute_block(a, k2i, zi, idg, sl2b, slzb, mine);
+        if (lane < nb2) ll2[p0 + i] = (first && i == 0) ? 0.0 : mine;
+      }
+      if (lane < nb2) {
+        const unsigned off = eoff(p0 + i, p0);
+#pragma unroll
+        for (int j = 0; j < WPB; ++j)
+          if (j <= i && j < nb2) st64(a[j], off, j * colb);
+        z[o1 + p0 + i] = zi;
+      }
+    };
+
+    if (wave == 0) {
+      double ad[WPB];
+      {
+        const int nb = min(WPB, m + 1);
+        const unsigned off = eoff(i, 0);
+#pragma unroll
+        for (int j = 0; j < WPB; ++j) ad[j] = (j <= i && i < nb && j < nb && i < m) ? ld64(off, j * colb) : (i == j ? 1.0 : 0.0);
+        zi = (i < nb && i < m) ? z[o1 + i] : 0.0;
+        v1i = i < nb ? vv1[i] : 0.0;
+        k1i = i < nb ? kk1[i] : 0.0;
+        k2i = i < nb ? kk2[i] : 0.0;
+      }
+      block_ab(0, ad);
+    }
+    for (int pi = 0; pi < npan; ++pi) {
+      lds_barrier();  // A1 / A2 of panel pi and the sweep of panel pi - 1 are complete
+      const int p0 = pi * WPB;
+      if (wave == 0) {
+        if (pi + 1 < npan) {
+          // the rows of the next diagonal block through panel pi, then A1 / A2 of panel pi + 1
+          const int nbn = min(WPB, m + 1 - (p0 + WPB));   // rows of the next block (row m may be its last)
+          const int rr = p0 + WPB + i;
+          const bool live = i < nbn;
+          double ad[WPB];
+          {
+            const unsigned off = eoff(live && rr < m ? rr : 0, p0 + WPB);
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) {
+              const double x = ld64(off, j * colb);
+              ad[j] = (j <= i && live && rr < m && p0 + WPB + j < m) ? x : (i == j ? 1.0 : 0.0);
+            }
+          }
+          const double zn = (live && rr < m) ? z[o1 + rr] : 0.0;
+          double a[WPB];
+          load_row(a, rr, p0, live);
+          v1i = (live && rr < m) ? vv1[rr] : 0.0;
+          k1i = (live && rr < m) ? kk1[rr] : 0.0;
+          v2i = (live && pi > 0) ? vv2[rr] : 0.0;
+          k2i = live ? kk2[rr] : 0.0;
+          both_ticks(a, rr, pi, v1i, k1i, v2i, k2i);
+          if (!live) v2i = 0.0;
+          if (lane < nbn) {
+            const unsigned off = eoff(rr, p0);
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) st64(a[j], off, j * colb);
+          }
+          zi = zn;
+          block_ab(pi + 1, ad);
+        }
+      } else {
+        for (int rr = p0 + 2 * WPB + (tid - 64); rr <= m; rr += 192) {
+          asm volatile("" ::: "memory");
+          double a[WPB];
+          load_row(a, rr, p0, true);
+          double v1 = vv1[rr], k1 = kk1[rr], v2 = pi > 0 ? vv2[rr] : 0.0, k2 = kk2[rr];
+          both_ticks(a, rr, pi, v1, k1, v2, k2);
+          const unsigned off = eoff(rr, p0);
+#pragma unroll
+          for (int j = 0; j < WPB; ++j) st64(a[j], off, j * colb);
+          vv1[rr] = v1;
+          kk1[rr] = k1;
+          vv2[rr] = v2;
+          kk2[rr] = k2;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- outputs of both ticks; tick t + 1's new row m + 1
+    if (wave == 0) {
+      double la = log(pma) + (double)pea * 0.6931471805599453, lb = log(pmb) + (double)peb * 0.6931471805599453;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        la += __shfl_xor(la, off);
+        lb += __shfl_xor(lb, off);
+      }
+      if (tid == 0) {
+        red[0] = sl2a; red[1] = slza; red[2] = la; red[3] = szza; red[4] = d1; red[5] = znew1;
+        red[8] = sl2b; red[9] = slzb; red[10] = lb; red[11] = szzb;
+      }
+    }
+    __syncthreads();
+    for (int cc = 1 + tid; cc <= m; cc += 256) L[(size_t)(o1 + cc) * CAP + o1 + m + 1] = ll2[cc];
+    if (tid == 0) {
+      const double kss1 = (kid == K_RBF_BROWNIAN) ? pr[9] * pr[10] * fabs(xn[0]) : pr[9];
+      const double kss2 = (kid == K_RBF_BROWNIAN) ? pr[9] * pr[10] * fabs(xn[MAXD]) : pr[9];
+      const double y1 = p.ys[(size_t)w * p.T + t], y2 = p.ys[(size_t)w * p.T + t + 1];
+      const size_t oi = (size_t)w * p.T + t;
+      double pv1 = kss1 - red[0];
+      pv1 = pv1 < 1e-15 ? 1e-15 : pv1;
+      p.pred_mean[oi] = red[1];
+      p.pred_var[oi] = p.include_noise ? pv1 + noise : pv1;
+      p.logml[oi] = -0.5 * (red[3] + red[5] * red[5]) - (red[2] + log(red[4])) - 0.5 * (double)N * 1.8378770664093453;
+      double dd = kss2 + noise + 1e-8 - red[8];
+      if (!(dd > 0.0)) {
+        if (bad == 0) bad = t + 2;
+        dd = 1e-300;
+      }
+      const double d2 = sqrt(dd), znew2 = (y2 - red[9]) / d2;
+      double pv2 = kss2 - red[8];
+      pv2 = pv2 < 1e-15 ? 1e-15 : pv2;
+      p.pred_mean[oi + 1] = red[9];
+      p.pred_var[oi + 1] = p.include_noise ? pv2 + noise : pv2;
+      p.logml[oi + 1] = -0.5 * (red[11] + znew2 * znew2) - (red[10] + log(d2)) - 0.5 * (double)N * 1.8378770664093453;
+      L[(size_t)(o1 + m + 1) * CAP + o1 + m + 1] = d2;
+      z[o1 + m + 1] = znew2;
+      yw[o1 + m] = y1;
+      yw[o1 + m + 1] = y2;
+      for (int q = 0; q < d; ++q) {
+        xw[q * CAP + o1 + m] = xn[q];
+        xw[q * CAP + o1 + m + 1] = xn[MAXD + q];
+      }
+    }
+    o += 2;   // (the status `bad` is per thread; thread 0 sits in wave 0, so its copy carries both ticks' checks)
+    __syncthreads();
+  }
+  if (tid == 0) {
+    st[0] = o;
+    st[1] = N;
+    st[2] = bad;
+    st[3] += p.nt;
   }
 }
 
