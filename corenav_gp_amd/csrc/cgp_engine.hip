@@ -167,6 +167,8 @@ constexpr bool kNoExtraSplit = CGP_NO_EXTRA_SPLIT != 0;
 #define CGP_WIN_PAIRS 1   // sliding window: steady-state ticks two per pass over the factor (`make variant`: 0 = every tick on its own)
 #endif
 constexpr bool kWinPairs = CGP_WIN_PAIRS != 0;
+constexpr int kWinPackLds = 72 * 1024;       // pack windows into a workgroup only while two workgroups still fit a CU's LDS ...
+constexpr int kWinPackMinGroups = 512;       // ... and the chip still gets two workgroups per CU
 constexpr int XSPLIT64_FROM = 28;   // fp64 mid-size calls of at least this many fits put their extra rows on a second stream
 constexpr int MID_FITS_ALLOC = kAbBuild ? 512 : (MID_FITS_F64 > MID_FITS_F32 ? MID_FITS_F64 : MID_FITS_F32);
 template <typename T> inline int mid_fits() {     // ablation build: CGP_MID_FITS moves the crossover (measurement)
@@ -1352,7 +1354,9 @@ extern "C" int cgp_window_init(cgp_ctx *c, int nwin, int N, int d, int kid, cons
   if (theta_stride < nth) return CGP_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
   // the two-ticks-per-pass kernel keeps six window-length vectors in LDS: 98 KB at N = 2048
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_window_pairs), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_window_pairs<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&k_window_pairs<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&k_window_pairs<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
     return CGP_EHIP;
   // the old windows are gone from here on: a failure below must leave the context without windows,
   // not with stale pointers (cgp_window_push checks nwin)
@@ -1426,7 +1430,17 @@ extern "C" int cgp_window_push_device(cgp_ctx *c, int T, const double *dxs, cons
   // through the single-tick kernel.  Origin and size of the windows are deterministic and identical for every window of
   // the context, so the host mirrors them instead of reading them back.
   const size_t lds1 = (size_t)(3 * a.N + 4 * WPB + MAXD + 8) * sizeof(double);
-  const size_t lds2 = (size_t)(6 * ((a.N + 3) & ~1) + 8 * WPB + 2 * MAXD + 16) * sizeof(double);
+  const size_t lds2 = (size_t)(6 * ((a.N + 3) & ~1) + 8 * WPB + 2 * MAXD + 16) * sizeof(double);   // per window
+  // windows per workgroup of the paired kernel (rows of wave 0 per window: 4 / wpw)
+  // measured (tools/r3_winpack.sh, N = 512): 1024 windows 2.20 / 2.65 / 2.03 M ticks/s at 1 / 2 / 4 per workgroup, 512 windows
+  // 2.18 / 1.81 / 1.20 -- two per workgroup once that still leaves two workgroups per CU, four never
+  int wpw = 1;
+  if (c->nwin % 2 == 0 && 2 * lds2 <= (size_t)kWinPackLds && c->nwin / 2 >= kWinPackMinGroups) wpw = 2;
+  if constexpr (kAbBuild) {
+    const char *e = getenv("CGP_WIN_WPW");
+    const int v = e ? atoi(e) : 0;
+    if ((v == 1 || v == 2 || v == 4) && c->nwin % v == 0 && v * lds2 <= 150 * 1024) wpw = v;
+  }
   hipStream_t ws = pick_stream(c, hip_stream);
   const int N = a.N, CAP = a.CAP;
   int o = c->win_o, n = c->win_n;
@@ -1443,7 +1457,9 @@ extern "C" int cgp_window_push_device(cgp_ctx *c, int T, const double *dxs, cons
     for (int oo = o; pair_ok(oo, n, T - t - 2 * np); oo += 2) ++np;
     if (np > 0) {
       a.nt = 2 * np;
-      hipLaunchKernelGGL(k_window_pairs, dim3(c->nwin), dim3(256), lds2, ws, a);
+      if (wpw == 4) hipLaunchKernelGGL(k_window_pairs<4>, dim3(c->nwin / 4), dim3(256), 4 * lds2, ws, a);
+      else if (wpw == 2) hipLaunchKernelGGL(k_window_pairs<2>, dim3(c->nwin / 2), dim3(256), 2 * lds2, ws, a);
+      else hipLaunchKernelGGL(k_window_pairs<1>, dim3(c->nwin), dim3(256), lds2, ws, a);
       o += 2 * np;
       t += 2 * np;
       continue;

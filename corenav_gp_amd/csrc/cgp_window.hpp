@@ -345,33 +345,42 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
 // tick t + 1's rotations only -- with its entries taken from LDS instead of memory.  Same arithmetic as two single ticks
 // (up to the order in which a row's two rotation sets are interleaved with other rows').
 // --------------------------------------------------------------------------------------------------
+// WPW windows per workgroup: with the traffic halved the pass is bound by wave 0's chains, which use ONE 16-lane row (the
+// other three rows of the wave held copies); with WPW = 2 / 4 the rows serve different windows (row g -> window g WPW / 4 of
+// the workgroup; DPP row_newbcast is row-local, nothing in the chain crosses rows), so one pass of the chains advances WPW
+// windows, and waves 1-3 sweep the rows of all of them.  Windows of a context advance in lock-step: origin, size and panel
+// count are workgroup-uniform.
+template <int WPW>
 __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
+  static_assert(WPW == 1 || WPW == 2 || WPW == 4, "rows of wave 0 per window: 4, 2 or 1");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int N = p.N, CAP = p.CAP, d = p.d, kid = p.kernel_id;
   const int NS = (N + 2 + 1) & ~1;                       // per-vector LDS stride (rows 0 .. m + 1)
-  double *vv1 = reinterpret_cast<double *>(smem_raw);   // rank-1 vector of tick t
-  double *kk1 = vv1 + NS, *ll1 = kk1 + NS;               // its append right-hand side / solution
-  double *vv2 = ll1 + NS, *kk2 = vv2 + NS, *ll2 = kk2 + NS;   // the same for tick t + 1
-  double *cs1 = ll2 + NS;                                // [2][2 WPB] (c, s) of a panel, double-buffered, tick t
-  double *cs2 = cs1 + 4 * WPB;                           // tick t + 1
-  double *xn = cs2 + 4 * WPB;                            // [2][MAXD] the incoming points
-  double *red = xn + 2 * MAXD;                           // [16] scalars handed from wave 0 to the block
-  const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int WS = 6 * NS + 8 * WPB + 2 * MAXD + 16;       // LDS doubles per window
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  double *L = p.L + (size_t)w * CAP * CAP;
-  double *z = p.z + (size_t)w * CAP;
-  double *xw = p.xw + (size_t)w * d * CAP;
-  double *yw = p.yw + (size_t)w * CAP;
-  int *st = p.state + w * 4;
-  const double *pr = p.prep + (size_t)w * PREP_N;
-  const double *th = p.theta + (size_t)w * MAX_THETA;
+  const int g = lane >> 4;
+  const int wl0 = (g * WPW) >> 2;                        // wave 0: the window this lane's row serves
+  const bool lead = (g & (4 / WPW - 1)) == 0;            // first row of its window (the others hold copies)
+  double *lds = reinterpret_cast<double *>(smem_raw);
+  // per-window LDS blocks: vv1 kk1 ll1 vv2 kk2 ll2 [NS each] | cs1 cs2 [2][2 WPB] | xn [2][MAXD] | red [16]
+  auto blk = [&](int wl) { return lds + wl * WS; };
+  const int w0 = blockIdx.x * WPW;
+  const size_t LWs = (size_t)CAP * CAP;
+  double *Lg = p.L + (size_t)w0 * LWs;
   const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
-  const double noise = th[nth - 1];
-  int o = st[0], bad = st[2];
+  // wave 0: this lane's window
+  double *vv1 = blk(wl0), *kk1 = vv1 + NS, *ll1 = kk1 + NS, *vv2 = ll1 + NS, *kk2 = vv2 + NS, *ll2 = kk2 + NS;
+  double *cs1 = ll2 + NS, *cs2 = cs1 + 4 * WPB, *xn = cs2 + 4 * WPB, *red = xn + 2 * MAXD;
+  double *z = p.z + (size_t)(w0 + wl0) * CAP;
+  const double *pr = p.prep + (size_t)(w0 + wl0) * PREP_N;
+  const double noise = p.theta[(size_t)(w0 + wl0) * MAX_THETA + nth - 1];
+  const unsigned woff = (unsigned)(wl0 * (int)(LWs * sizeof(double)));
+  int o = p.state[w0 * 4], bad = tid < WPW ? p.state[(w0 + tid) * 4 + 2] : 0;
   const int m = N - 1;
   const int npan = (m + 1 + WPB - 1) / WPB;   // panels of tick t + 1 (columns 1 .. m); tick t uses columns 0 .. m - 1
   const int i = lane & (WPB - 1);
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(L, 0, (int)((size_t)CAP * CAP * sizeof(double)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Lg, 0, (int)(WPW * LWs * sizeof(double)), 0x00020000);
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
   auto ld64 = [&](unsigned off, int soff) {
     const u2 q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, soff, 0);
@@ -387,21 +396,25 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
 
   for (int t = p.t0; t < p.t0 + p.nt; t += 2) {
     const int o1 = o + 1;
-    if (tid < 2 * d) {
-      const int tk = tid / d, q = tid - tk * d;
-      xn[tk * MAXD + q] = p.xs[((size_t)w * p.T + t + tk) * d + q];
+    if (tid < 2 * d * WPW) {
+      const int wl = tid / (2 * d), r2 = tid - wl * 2 * d, tk = r2 / d, q = r2 - tk * d;
+      (blk(wl) + 6 * NS + 8 * WPB)[tk * MAXD + q] = p.xs[((size_t)(w0 + wl) * p.T + t + tk) * d + q];
     }
     __syncthreads();
-    for (int rr = tid; rr <= m; rr += 256) {
+    for (int idx = tid; idx < WPW * (m + 1); idx += 256) {
+      const int wl = idx / (m + 1), rr = idx - wl * (m + 1);
+      double *b = blk(wl);
+      const double *xnw = b + 6 * NS + 8 * WPB, *prw = p.prep + (size_t)(w0 + wl) * PREP_N;
+      const double *xww = p.xw + (size_t)(w0 + wl) * d * CAP;
       if (rr < m) {
-        vv1[rr] = L[(size_t)o * CAP + o1 + rr];
-        kk1[rr] = win_cov(kid, d, pr, xw + o1 + rr, CAP, xn, 1, false);
-        kk2[rr] = win_cov(kid, d, pr, xw + o1 + rr, CAP, xn + MAXD, 1, false);
+        b[rr] = Lg[wl * LWs + (size_t)o * CAP + o1 + rr];                                      // vv1
+        b[NS + rr] = win_cov(kid, d, prw, xww + o1 + rr, CAP, xnw, 1, false);                  // kk1
+        b[4 * NS + rr] = win_cov(kid, d, prw, xww + o1 + rr, CAP, xnw + MAXD, 1, false);       // kk2
       } else {
-        kk2[m] = win_cov(kid, d, pr, xn, 1, xn + MAXD, 1, false);   // the two incoming points
-        vv1[m] = 0.0;
-        kk1[m] = 0.0;
-        ll1[m] = 0.0;
+        b[4 * NS + m] = win_cov(kid, d, prw, xnw, 1, xnw + MAXD, 1, false);   // kk2[m]: the two incoming points
+        b[m] = 0.0;            // vv1[m]
+        b[NS + m] = 0.0;       // kk1[m]
+        b[2 * NS + m] = 0.0;   // ll1[m]
       }
     }
     double vz1 = z[o], vz2 = 0.0;   // the dropped samples' components of z
@@ -409,10 +422,11 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
     double pma = 1.0, pmb = 1.0;    // running products of the diagonals (mantissa, exponent), one per tick
     int pea = 0, peb = 0;
     double d1 = 1.0, znew1 = 0.0;
+    int bad1 = 0;   // tick t's pivot check, seen by wave 0 (handed to the window's tail thread through LDS)
     __syncthreads();
 
     // element (row rr, column cc) of the factor, both counted from o1
-    auto eoff = [&](int rr, int cc) { return (unsigned)(((o1 + cc) * CAP + o1 + rr) * (int)sizeof(double)); };
+    auto eoff = [&](int rr, int cc) { return (unsigned)(((o1 + cc) * CAP + o1 + rr) * (int)sizeof(double)); };   // + the window's slab
     // rotations of one diagonal block (lane = row), branch-free, (c, s) to csb; skip0: step 0 is not part of this tick
     auto rotate_block = [&](double (&a)[WPB], double &vi, double &zi, double &vz, double &szz, double &idg, double *csb, bool skip0) {
       static_for<0, WPB>([&](auto jc) {
@@ -472,19 +486,19 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
       }
     };
     // a row below the diagonal block of panel pi through both ticks: tick t (rows < m), then tick t + 1
-    auto both_ticks = [&](double (&a)[WPB], int rr, int pi, double &v1, double &k1, double &v2, double &k2) {
+    auto both_ticks = [&](double (&a)[WPB], int rr, int pi, double &v1, double &k1, double &v2, double &k2, const double *b) {
       const int p0 = pi * WPB, cso = (pi & 1) * 2 * WPB;
-      if (rr < m) sweep_row(a, v1, k1, cs1 + cso, ll1 + p0);
+      if (rr < m) sweep_row(a, v1, k1, b + 6 * NS + cso, b + 2 * NS + p0);                 // cs1, ll1
       if (pi == 0) v2 = a[0];   // column 0 after tick t: this row's entry of tick t + 1's rank-1 vector
-      sweep_row(a, v2, k2, cs2 + cso, ll2 + p0);
+      sweep_row(a, v2, k2, b + 6 * NS + 4 * WPB + cso, b + 5 * NS + p0);                   // cs2, ll2
     };
     // the 16 panel entries of row rr: memory, or -- tick t's new row m, which exists only as l1 so far -- LDS
-    auto load_row = [&](double (&a)[WPB], int rr, int p0, bool live) {
-      const unsigned off = eoff(live ? rr : 0, p0);
+    auto load_row = [&](double (&a)[WPB], int rr, int p0, bool live, unsigned wo, const double *b) {
+      const unsigned off = wo + eoff(live ? rr : 0, p0);
 #pragma unroll
       for (int j = 0; j < WPB; ++j) {
         const double x = ld64(off, j * colb);
-        a[j] = !live ? 0.0 : (rr == m ? ll1[p0 + j] : x);
+        a[j] = !live ? 0.0 : (rr == m ? b[2 * NS + p0 + j] : x);   // ll1
       }
     };
 
@@ -499,20 +513,20 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
       {
         double idg = 1.0, mine = 0.0;
         rotate_block(a, v1i, zi, vz1, szza, idg, c1, false);
-        if (lane < nb1) diag_product(a, pma, pea);
+        if (lead && i < nb1) diag_product(a, pma, pea);
         substitute_block(a, k1i, zi, idg, sl2a, slza, mine);
-        if (lane < nb1) ll1[p0 + i] = mine;
+        if (lead && i < nb1) ll1[p0 + i] = mine;
       }
       if (p0 + WPB > m) {
         // the last panel: tick t's new row m = (l1, d1) joins the block as row m - p0, with its z
         const double kss1 = (kid == K_RBF_BROWNIAN) ? pr[9] * pr[10] * fabs(xn[0]) : pr[9];
         double dd = kss1 + noise + 1e-8 - sl2a;
         if (!(dd > 0.0)) {
-          if (bad == 0) bad = t + 1;
+          bad1 = t + 1;
           dd = 1e-300;
         }
         d1 = sqrt(dd);
-        znew1 = (p.ys[(size_t)w * p.T + t] - slza) / d1;
+        znew1 = (p.ys[(size_t)(w0 + wl0) * p.T + t] - slza) / d1;
         const int im = m - p0;
         if (i == im) {
 #pragma unroll
@@ -531,12 +545,12 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
         }
         double idg = 1.0, mine = 0.0;
         rotate_block(a, v2i, zi, vz2, szzb, idg, c2, first);
-        if (lane < nb2 && !(first && i == 0)) diag_product(a, pmb, peb);
+        if (lead && i < nb2 && !(first && i == 0)) diag_product(a, pmb, peb);
         substitute_block(a, k2i, zi, idg, sl2b, slzb, mine);
-        if (lane < nb2) ll2[p0 + i] = (first && i == 0) ? 0.0 : mine;
+        if (lead && i < nb2) ll2[p0 + i] = (first && i == 0) ? 0.0 : mine;
       }
-      if (lane < nb2) {
-        const unsigned off = eoff(p0 + i, p0);
+      if (lead && i < nb2) {
+        const unsigned off = woff + eoff(p0 + i, p0);
 #pragma unroll
         for (int j = 0; j < WPB; ++j)
           if (j <= i && j < nb2) st64(a[j], off, j * colb);
@@ -548,7 +562,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
       double ad[WPB];
       {
         const int nb = min(WPB, m + 1);
-        const unsigned off = eoff(i, 0);
+        const unsigned off = woff + eoff(i, 0);
 #pragma unroll
         for (int j = 0; j < WPB; ++j) ad[j] = (j <= i && i < nb && j < nb && i < m) ? ld64(off, j * colb) : (i == j ? 1.0 : 0.0);
         zi = (i < nb && i < m) ? z[o1 + i] : 0.0;
@@ -569,7 +583,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
           const bool live = i < nbn;
           double ad[WPB];
           {
-            const unsigned off = eoff(live && rr < m ? rr : 0, p0 + WPB);
+            const unsigned off = woff + eoff(live && rr < m ? rr : 0, p0 + WPB);
 #pragma unroll
             for (int j = 0; j < WPB; ++j) {
               const double x = ld64(off, j * colb);
@@ -578,15 +592,15 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
           }
           const double zn = (live && rr < m) ? z[o1 + rr] : 0.0;
           double a[WPB];
-          load_row(a, rr, p0, live);
+          load_row(a, rr, p0, live, woff, blk(wl0));
           v1i = (live && rr < m) ? vv1[rr] : 0.0;
           k1i = (live && rr < m) ? kk1[rr] : 0.0;
           v2i = (live && pi > 0) ? vv2[rr] : 0.0;
           k2i = live ? kk2[rr] : 0.0;
-          both_ticks(a, rr, pi, v1i, k1i, v2i, k2i);
+          both_ticks(a, rr, pi, v1i, k1i, v2i, k2i, blk(wl0));
           if (!live) v2i = 0.0;
-          if (lane < nbn) {
-            const unsigned off = eoff(rr, p0);
+          if (lead && i < nbn) {
+            const unsigned off = woff + eoff(rr, p0);
 #pragma unroll
             for (int j = 0; j < WPB; ++j) st64(a[j], off, j * colb);
           }
@@ -594,19 +608,24 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
           block_ab(pi + 1, ad);
         }
       } else {
-        for (int rr = p0 + 2 * WPB + (tid - 64); rr <= m; rr += 192) {
+        const int R = m + 1 - (p0 + 2 * WPB);   // rows per window below the next diagonal block (may be <= 0)
+        for (int idx = tid - 64; idx < WPW * R; idx += 192) {
           asm volatile("" ::: "memory");
+          const int wl = WPW == 1 ? 0 : idx / R;
+          const int rr = p0 + 2 * WPB + (idx - wl * R);
+          double *b = blk(wl);
+          const unsigned wo = (unsigned)(wl * (int)(LWs * sizeof(double)));
           double a[WPB];
-          load_row(a, rr, p0, true);
-          double v1 = vv1[rr], k1 = kk1[rr], v2 = pi > 0 ? vv2[rr] : 0.0, k2 = kk2[rr];
-          both_ticks(a, rr, pi, v1, k1, v2, k2);
-          const unsigned off = eoff(rr, p0);
+          load_row(a, rr, p0, true, wo, b);
+          double v1 = b[rr], k1 = b[NS + rr], v2 = pi > 0 ? b[3 * NS + rr] : 0.0, k2 = b[4 * NS + rr];
+          both_ticks(a, rr, pi, v1, k1, v2, k2, b);
+          const unsigned off = wo + eoff(rr, p0);
 #pragma unroll
           for (int j = 0; j < WPB; ++j) st64(a[j], off, j * colb);
-          vv1[rr] = v1;
-          kk1[rr] = k1;
-          vv2[rr] = v2;
-          kk2[rr] = k2;
+          b[rr] = v1;
+          b[NS + rr] = k1;
+          b[3 * NS + rr] = v2;
+          b[4 * NS + rr] = k2;
         }
       }
     }
@@ -616,18 +635,28 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
     if (wave == 0) {
       double la = log(pma) + (double)pea * 0.6931471805599453, lb = log(pmb) + (double)peb * 0.6931471805599453;
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
+      for (int off = 32 / WPW; off > 0; off >>= 1) {   // within the window's rows
         la += __shfl_xor(la, off);
         lb += __shfl_xor(lb, off);
       }
-      if (tid == 0) {
-        red[0] = sl2a; red[1] = slza; red[2] = la; red[3] = szza; red[4] = d1; red[5] = znew1;
+      if (lead && i == 0) {
+        red[0] = sl2a; red[1] = slza; red[2] = la; red[3] = szza; red[4] = d1; red[5] = znew1; red[6] = (double)bad1;
         red[8] = sl2b; red[9] = slzb; red[10] = lb; red[11] = szzb;
       }
     }
     __syncthreads();
-    for (int cc = 1 + tid; cc <= m; cc += 256) L[(size_t)(o1 + cc) * CAP + o1 + m + 1] = ll2[cc];
-    if (tid == 0) {
+    for (int idx = tid; idx < WPW * m; idx += 256) {
+      const int wl = idx / m, cc = 1 + (idx - wl * m);
+      Lg[wl * LWs + (size_t)(o1 + cc) * CAP + o1 + m + 1] = (blk(wl) + 5 * NS)[cc];   // ll2
+    }
+    if (tid < WPW) {
+      const int wl = tid, w = w0 + wl;
+      double *b = blk(wl);
+      const double *xn = b + 6 * NS + 8 * WPB, *red = xn + 2 * MAXD;
+      const double *pr = p.prep + (size_t)w * PREP_N;
+      const double noise = p.theta[(size_t)w * MAX_THETA + nth - 1];
+      double *L = Lg + wl * LWs, *z = p.z + (size_t)w * CAP, *yw = p.yw + (size_t)w * CAP, *xw = p.xw + (size_t)w * d * CAP;
+      if (bad == 0 && red[6] != 0.0) bad = (int)red[6];
       const double kss1 = (kid == K_RBF_BROWNIAN) ? pr[9] * pr[10] * fabs(xn[0]) : pr[9];
       const double kss2 = (kid == K_RBF_BROWNIAN) ? pr[9] * pr[10] * fabs(xn[MAXD]) : pr[9];
       const double y1 = p.ys[(size_t)w * p.T + t], y2 = p.ys[(size_t)w * p.T + t + 1];
@@ -660,7 +689,8 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
     o += 2;   // (the status `bad` is per thread; thread 0 sits in wave 0, so its copy carries both ticks' checks)
     __syncthreads();
   }
-  if (tid == 0) {
+  if (tid < WPW) {
+    int *st = p.state + (w0 + tid) * 4;
     st[0] = o;
     st[1] = N;
     st[2] = bad;

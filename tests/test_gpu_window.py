@@ -97,3 +97,29 @@ def test_many_windows_independent(engine):
         opm, opv, olm = go.sliding_window_stream(2, theta[w], N, Xs[w], ys[w])
         assert np.max(np.abs(pm[w] - opm)) <= TOL * np.max(np.abs(opm))
         assert np.max(np.abs(lm[w] - olm) / np.abs(olm)) < TOL
+
+
+def test_many_windows_take_the_packed_paired_kernel(engine):
+    """A context of >= 1024 windows runs its steady-state ticks two per pass over the factor with TWO windows per workgroup
+    (rows of wave 0 split between them): 1024 windows of N = 48 with different data and hyper-parameters each, streamed in
+    uneven blocks across ring compactions; a sample of windows -- both members of a workgroup's pair, first / last workgroup
+    -- against the refit-per-tick oracle, and every window's status clean."""
+    W, N, d, T = 1024, 48, 2, 230
+    rng = np.random.default_rng(1024)
+    t = np.arange(11, 11 + T, dtype=np.float64)
+    X = np.empty((W, T, d))
+    X[:, :, 0] = (t - t.mean()) / t.std()
+    X[:, :, 1] = rng.normal(size=(W, T))
+    y = 0.1 * np.sin(2 * np.pi * t / 40.0)[None] * rng.uniform(0.5, 1.5, (W, 1)) + rng.normal(0, 0.03, (W, T))
+    theta = np.column_stack([rng.uniform(0.01, 0.04, W), rng.uniform(0.7, 1.5, (W, d)), np.full(W, 1e-3)])
+    ctx = engine.Context(max_n=8, max_m=8, max_d=d)
+    ctx.window_init(W, N, d, 1, theta)
+    cuts = [0, 31, 32, 135, T]          # filling, an odd tick, steady-state runs across a compaction
+    outs = [ctx.window_push(X[:, a:b], y[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    pm, pv, lm = (np.concatenate([o[k] for o in outs], axis=1) for k in range(3))
+    for w in (0, 1, 2, 511, 1022, 1023):
+        opm, opv, olm = go.sliding_window_stream(1, theta[w], N, X[w], y[w])
+        assert np.max(np.abs(pm[w] - opm)) <= TOL * max(np.max(np.abs(opm)), 1e-12)
+        assert np.max(np.abs(pv[w] - opv) / opv) < TOL
+        assert np.max(np.abs(lm[w] - olm) / np.maximum(np.abs(olm), 1.0)) < TOL
+    assert all(ctx.window_state(w) == (N, 0) for w in (0, 1, 777, 1023))
