@@ -249,12 +249,18 @@ __device__ __forceinline__ float exp_nonpos(float x, const ExpC &) { return __ex
 // in a[] (replicated over the four 16-lane groups).  On return a[] holds the row of the Cholesky
 // factor and w[i] = Dinv[i][lane & 15] (column (lane & 15) of the block's inverse, by forward
 // substitution).  A non-positive pivot is replaced by 1 and reported in `bad` (1-based global index).
-// This is the serial critical path of the factorisation (128 dependent pivots per tile) and it is
-// bound by instruction issue, not latency (tools/potf2_block_bench.hip), so the fp64 form uses the
-// 64-bit DPP row_newbcast of gfx90a+: "times lane c's value" is ONE v_fmac_f64_dpp instead of two
-// v_readlane_b32 and an fma (the four rows hold identical copies, a row-local broadcast is the right
-// one).  3.76 -> 2.42 us per block with two such waves per SIMD.  A DPP read of a VGPR needs two wait
-// states after the VALU write: the first DPP instruction after each producer carries an s_nop 1.
+// This is the serial critical path of the factorisation (128 dependent pivots per tile) and a lone wave
+// pays for it by INSTRUCTION COUNT: every VALU instruction, DPP or not, is 4 cycles of issue, dependent
+// ones issue back to back, and reordering alone bought 3 % (tools/potf2_block_bench.hip, variants 4 / 6).  So:
+//  * "times lane c's value" is ONE v_fmac_f64_dpp (64-bit DPP row_newbcast of gfx90a+; the four rows hold
+//    identical copies, a row-local broadcast is the right one) with the sign as its neg modifier;
+//  * the Newton step of 1/sqrt(pivot) is folded into the column: l = l0 + l0 q with l0 = a r, not a (r + r q);
+//  * no per-pivot repair on the fast path: a non-positive pivot turns every later pivot into NaN, so ONE test
+//    of the last pivot tells, and the rare block that fails it is reloaded and redone by the repairing form;
+//  * the inverse's substitution step J rides in the factor loop (column J of L is final there), no masks:
+//    the exact zeros above the diagonal of the inverse stay exact zeros.
+// 1.51 -> 1.02 us per fp64 block for a lone wave.  A DPP read of a VGPR needs two wait states after the
+// VALU write: the first DPP instruction after each producer carries an s_nop 1.
 template <int B, int E, typename F> __device__ __forceinline__ void static_for(F &&f) {
   if constexpr (B < E) {
     f(std::integral_constant<int, B>{});
@@ -287,9 +293,27 @@ __device__ __forceinline__ double rsqrt3(double x) {
   return __builtin_fma(r, q, r);
 }
 
+template <int C, bool NOP> __device__ __forceinline__ void fnmac_bcast(float &acc, float src, float own) {  // acc -= src[lane C of the row] * own
+  if constexpr (NOP) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own), "n"(C));
+  else asm volatile("v_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own), "n"(C));
+}
+template <int C, bool NOP> __device__ __forceinline__ void fnmac_bcast(double &acc, double src, double own) {
+  if constexpr (NOP) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own), "n"(C));
+  else asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own), "n"(C));
+}
+// 1/sqrt(x) = r + r q with r the hardware seed: q of one third-order step (fp64, seed ~2^-23: error ~ e^3) or of
+// one Newton step (fp32)
+__device__ __forceinline__ double rsqrt_corr(double x, double r) {
+  const double e = __builtin_fma(-(x * r), r, 1.0);
+  return __builtin_fma(0.375, e, 0.5) * e;
+}
+__device__ __forceinline__ float rsqrt_corr(float x, float r) { return __builtin_fmaf(-0.5f * x * r, r, 0.5f); }
+__device__ __forceinline__ double rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }
+__device__ __forceinline__ float rsq_seed(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// the repairing form: a non-positive pivot is replaced by 1 and reported
 template <typename T>
-__device__ __forceinline__ void factor_block16(T (&a)[DB], T (&w)[DB], int &bad, int pivot_base, int l15) {
-  using P = Prec<T>;
+__device__ __forceinline__ void factor_block16_repair(T (&a)[DB], T (&w)[DB], int &bad, int pivot_base, int l15) {
   T rinv[DB];
   static_for<0, DB>([&](auto jc) {
     constexpr int J = decltype(jc)::value;
@@ -297,16 +321,14 @@ __device__ __forceinline__ void factor_block16(T (&a)[DB], T (&w)[DB], int &bad,
     const bool ok = dj > T(0);
     if (!ok && bad == 0) bad = pivot_base + J + 1;
     dj = ok ? dj : T(1);
-    T rs;
-    if constexpr (sizeof(T) == 8) rs = rsqrt3(dj);
-    else rs = P::rsqrt_(dj);
-    rinv[J] = rs;
-    const T l = (ok ? a[J] : ((l15 == J) ? T(1) : a[J])) * rs;   // lane J's a[J] is the pivot itself
+    const T r = rsq_seed(dj), q = rsqrt_corr(dj, r);
+    const T l0 = (ok ? a[J] : ((l15 == J) ? T(1) : a[J])) * r;   // lane J's a[J] is the pivot itself
+    const T l = __builtin_fma(l0, q, l0);
+    rinv[J] = __builtin_fma(r, q, r);
     a[J] = l;
-    const T nl = -l;
     static_for<J + 1, DB>([&](auto cc) {
       constexpr int C = decltype(cc)::value;
-      fmac_bcast<C, C == J + 1>(a[C], l, nl);
+      fnmac_bcast<C, C == J + 1>(a[C], l, l);
     });
   });
   // right-looking forward substitution for column l15 of the inverse: independent updates per step
@@ -316,14 +338,49 @@ __device__ __forceinline__ void factor_block16(T (&a)[DB], T (&w)[DB], int &bad,
   static_for<0, DB>([&](auto qc) {
     constexpr int Q = decltype(qc)::value;
     w[Q] = t[Q] * rinv[Q];
-    const T nw = -w[Q];
     static_for<Q + 1, DB>([&](auto ic) {
       constexpr int I = decltype(ic)::value;
-      fmac_bcast<I, false>(t[I], a[Q], nw);
+      fnmac_bcast<I, false>(t[I], a[Q], w[Q]);
     });
   });
 #pragma unroll
   for (int i = 0; i < DB; ++i) w[i] = (i < l15) ? T(0) : w[i];
+}
+
+// `reload` refills a[] with the block as it was (only called when a pivot failed)
+template <typename T, typename Reload>
+__device__ __forceinline__ void factor_block16(T (&a)[DB], T (&w)[DB], int &bad, int pivot_base, int l15, Reload &&reload) {
+  T t[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i) t[i] = (i == l15) ? T(1) : T(0);
+  T lp = T(0), wp = T(0), last = T(0);
+  static_for<0, DB>([&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    const T dj = mov_bcast<J>(a[J]);
+    if constexpr (J > 0) {   // step J-1's updates of the columns that pivot J does not need, and its substitution step
+      static_for<J + 1, DB>([&](auto cc) {
+        constexpr int C = decltype(cc)::value;
+        fnmac_bcast<C, false>(a[C], lp, lp);
+      });
+      static_for<J, DB>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        fnmac_bcast<I, false>(t[I], lp, wp);
+      });
+    }
+    const T r = rsq_seed(dj), q = rsqrt_corr(dj, r);
+    const T l0 = a[J] * r;
+    const T l = __builtin_fma(l0, q, l0);
+    a[J] = l;
+    if constexpr (J + 1 < DB) fnmac_bcast<J + 1, true>(a[J + 1], l, l);
+    w[J] = t[J] * __builtin_fma(r, q, r);
+    lp = l;
+    wp = w[J];
+    last = dj;
+  });
+  if (!(last > T(0))) {   // wave-uniform and rare: some pivot was not positive (every later one is NaN then)
+    reload();
+    factor_block16_repair<T>(a, w, bad, pivot_base, l15);
+  }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -371,64 +428,81 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
 #pragma unroll
     for (int r = 0; r < 4; ++r) At[(bj * DB + P::drow(lane, r)) * LDP + bi * DB + l15] = acc[r];
   };
-  // two independent trailing blocks at once: 24 LDS reads in flight, two MFMA chains interleaved
-  auto trailing_pair = [&](int bi0, int bj0, int bi1, int bj1, int jp) {
-    acc_t a0, a1;
-    T fa0[4], fb0[4], fa1[4], fb1[4];
+  // N blocks of one block row at once, C(bi, bj0 + m) -= L(bi, jp) L(bj0 + m, jp)^T: the row's panel block is loaded
+  // once, every LDS read is in flight before the first MFMA, N MFMA chains interleaved (the helper waves are bound
+  // by LDS and MFMA latency, not by the pipes: one block at a time ran at a sixth of the MFMA rate).  Per block
+  // the arithmetic is trailing_block's.
+  auto trailing_multi = [&](auto nc, int bi, int bj0, int jp) {
+    constexpr int N = decltype(nc)::value;
+    acc_t a[N];
+    T fa[N][4], fb[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      a0[r] = At[(bj0 * DB + P::drow(lane, r)) * LDP + bi0 * DB + l15];
-      a1[r] = At[(bj1 * DB + P::drow(lane, r)) * LDP + bi1 * DB + l15];
+    for (int ks = 0; ks < 4; ++ks) fb[ks] = At[(jp * DB + ks * 4 + lq) * LDP + bi * DB + l15];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[m][ks] = -At[(jp * DB + ks * 4 + lq) * LDP + (bj0 + m) * DB + l15];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[m][r] = At[((bj0 + m) * DB + P::drow(lane, r)) * LDP + bi * DB + l15];
     }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      fa0[ks] = -At[(jp * DB + ks * 4 + lq) * LDP + bj0 * DB + l15];
-      fb0[ks] = At[(jp * DB + ks * 4 + lq) * LDP + bi0 * DB + l15];
-      fa1[ks] = -At[(jp * DB + ks * 4 + lq) * LDP + bj1 * DB + l15];
-      fb1[ks] = At[(jp * DB + ks * 4 + lq) * LDP + bi1 * DB + l15];
-    }
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      a0 = P::mfma(fa0[ks], fb0[ks], a0);
-      a1 = P::mfma(fa1[ks], fb1[ks], a1);
-    }
+      for (int m = 0; m < N; ++m) a[m] = P::mfma(fa[m][ks], fb[ks], a[m]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      At[(bj0 * DB + P::drow(lane, r)) * LDP + bi0 * DB + l15] = a0[r];
-      At[(bj1 * DB + P::drow(lane, r)) * LDP + bi1 * DB + l15] = a1[r];
+    for (int m = 0; m < N; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) At[((bj0 + m) * DB + P::drow(lane, r)) * LDP + bi * DB + l15] = a[m][r];
+  };
+  // blocks (bi, bj0 .. bi) of block row bi
+  auto trailing_row = [&](int bi, int bj0, int jp) {
+    using std::integral_constant;
+    switch (bi - bj0 + 1) {
+      case 1: trailing_multi(integral_constant<int, 1>{}, bi, bj0, jp); break;
+      case 2: trailing_multi(integral_constant<int, 2>{}, bi, bj0, jp); break;
+      case 3: trailing_multi(integral_constant<int, 3>{}, bi, bj0, jp); break;
+      case 4: trailing_multi(integral_constant<int, 4>{}, bi, bj0, jp); break;
+      case 5: trailing_multi(integral_constant<int, 3>{}, bi, bj0, jp); trailing_multi(integral_constant<int, 2>{}, bi, bj0 + 3, jp); break;
+      case 6: trailing_multi(integral_constant<int, 3>{}, bi, bj0, jp); trailing_multi(integral_constant<int, 3>{}, bi, bj0 + 3, jp); break;
+      default: break;
     }
   };
   // W(i, j) = -Dinv_i sum_{j <= q < i} L(i, q) W(q, j), written to LDS (transposed, upper triangle) and, negated,
   // to its block of the HBM image straight from the accumulator.  The sum runs on two accumulators (even / odd
   // q) so that consecutive 4-MFMA products do not wait for each other.
   auto inverse_block = [&](int i, int j) {
-    acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc0;
-    auto term = [&](int kk, acc_t &acc) {
-      T fa[4], fb[4];
+    constexpr int MAXT = NB - 1;
+    const int n = i - j;   // terms, 1 .. 7; every operand is read before the first MFMA
+    T fa[MAXT][4], fb[MAXT][4], ga[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        fa[ks] = At[(kk * DB + ks * 4 + lq) * LDP + i * DB + l15];  // L_{i,kk}[r = l15][q]
-        fb[ks] = (kk == j) ? Dv[j * DB * DB + l15 * DB + ks * 4 + lq]  // Dinv_j[q][c = l15]
-                           : At[(kk * DB + ks * 4 + lq) * LDP + j * DB + l15];  // W_{kk,j}[q][c]
+    for (int t = 0; t < MAXT; ++t)
+      if (t < n) {
+        const int kk = j + t;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          fa[t][ks] = At[(kk * DB + ks * 4 + lq) * LDP + i * DB + l15];  // L_{i,kk}[r = l15][q]
+          fb[t][ks] = (t == 0) ? Dv[j * DB * DB + l15 * DB + ks * 4 + lq]  // Dinv_j[q][c = l15]
+                               : At[(kk * DB + ks * 4 + lq) * LDP + j * DB + l15];  // W_{kk,j}[q][c]
+        }
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
-    };
-    int kk = j;
-    for (; kk + 1 < i; kk += 2) {
-      term(kk, acc0);
-      term(kk + 1, acc1);
-    }
-    if (kk < i) term(kk, acc0);
+    for (int ks = 0; ks < 4; ++ks) ga[ks] = -Dv[i * DB * DB + (ks * 4 + lq) * DB + l15];  // -Dinv_i[r = l15][q]
+    acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+      if (t < n) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (t & 1) acc1 = P::mfma(fa[t][ks], fb[t][ks], acc1);
+          else acc0 = P::mfma(fa[t][ks], fb[t][ks], acc0);
+        }
+      }
 #pragma unroll
     for (int r = 0; r < 4; ++r) tsw[P::drow(lane, r) * DB + l15] = acc0[r] + acc1[r];  // T[r][c] (wave-private scratch)
     acc_t acc2 = acc_t{0, 0, 0, 0};
-    T ga[4], gb[4];
+    T gb[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      ga[ks] = -Dv[i * DB * DB + (ks * 4 + lq) * DB + l15];  // -Dinv_i[r = l15][q]
-      gb[ks] = tsw[(ks * 4 + lq) * DB + l15];                // T[q][c = l15]
-    }
+    for (int ks = 0; ks < 4; ++ks) gb[ks] = tsw[(ks * 4 + lq) * DB + l15];                // T[q][c = l15]
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) acc2 = P::mfma(ga[ks], gb[ks], acc2);
 #pragma unroll
@@ -485,16 +559,31 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
       if (j0 < live) {
 #pragma unroll
         for (int c = 0; c < DB; ++c) a[c] = At[(j0 + c) * LDP + j0 + l15];
-        factor_block16<T>(a, w, bad, k * TS + j0, l15);
+#ifdef CGP_ABLATION
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const long long tl = __builtin_amdgcn_s_memtime();
+#endif
+        factor_block16<T>(a, w, bad, k * TS + j0, l15, [&] {
+#pragma unroll
+          for (int c = 0; c < DB; ++c) a[c] = At[(j0 + c) * LDP + j0 + l15];
+        });
+#ifdef CGP_ABLATION
+        if (CGP_DBG_ON(p, 1024) && tid == 0) {
+          asm volatile("" : "+v"(w[15]), "+v"(a[15]));
+          const long long tf = __builtin_amdgcn_s_memtime();
+          unsigned long long *d = reinterpret_cast<unsigned long long *>(p.dbgbuf);
+          atomicAdd(d + 42, (unsigned long long)(tl - tm));
+          atomicAdd(d + 43, (unsigned long long)(tf - tl));
+        }
+#endif
+        if (bad != 0 && lane == 0 && *flag == 0) *flag = bad;
       } else {  // identity padding beyond the window (N not a multiple of 128): nothing to factor
 #pragma unroll
         for (int c = 0; c < DB; ++c) a[c] = w[c] = (c == l15) ? T(1) : T(0);
       }
-      if (bad != 0 && lane == 0 && *flag == 0) *flag = bad;
-      if (lane < DB) {
+      if (lane < DB) {   // the block's strictly upper triangle in LDS is read by nobody (store_blocks masks it)
 #pragma unroll
-        for (int c = 0; c < DB; ++c)
-          if (l15 >= c) At[(j0 + c) * LDP + j0 + l15] = a[c];
+        for (int c = 0; c < DB; ++c) At[(j0 + c) * LDP + j0 + l15] = a[c];
 #pragma unroll
         for (int i = 0; i < DB; ++i) Dv[jb * DB * DB + l15 * DB + i] = w[i];
       }
@@ -504,7 +593,6 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
     } else {
       if (jb > 0) {
         const int jp = jb - 1, nb = NB - 1 - jb;  // block columns jb+1 .. 7 still take panel jp
-        const int ntr = nb * (nb + 1) / 2;
 #ifdef CGP_ABLATION
         long long h0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -513,27 +601,12 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
 #ifdef CGP_ABLATION
         long long h1 = __builtin_amdgcn_s_memtime();
 #endif
-        auto tr_decode = [&](int idx, int &bi, int &bj) {
-          int c = 0, rem = idx;
-          while (rem >= nb - c) {
-            rem -= nb - c;
-            ++c;
-          }
-          bi = c + rem + jb + 1;
-          bj = c + jb + 1;
-        };
-        int idx = wave - 1;
-        for (; idx + 3 < ntr; idx += 6) {
-          int bi0, bj0, bi1, bj1;
-          tr_decode(idx, bi0, bj0);
-          tr_decode(idx + 3, bi1, bj1);
-          trailing_pair(bi0, bj0, bi1, bj1, jp);
-        }
-        if (idx < ntr) {
-          int bi0, bj0;
-          tr_decode(idx, bi0, bj0);
-          trailing_block(bi0, bj0, jp);
-        }
+        // block rows jb+1 .. 7 of the trailing matrix have 1 .. nb blocks; dealt so that the three helpers get
+        // 7 7 7 / 5 5 5 / 4 3 3 / 3 2 1 / 2 1 / 1 blocks: rows nb - h and nb - 5 + h (1-based row lengths), helper h
+        const int h = wave - 1;
+        const int r1 = nb - h, r2 = nb - 5 + h;
+        if (r1 >= 1) trailing_row(jb + r1, jb + 1, jp);
+        if (r2 >= 1 && r2 < r1) trailing_row(jb + r2, jb + 1, jp);
 #ifdef CGP_ABLATION
         if (CGP_DBG_ON(p, 1024) && tid == 64) {
           unsigned long long *d = reinterpret_cast<unsigned long long *>(p.dbgbuf);

@@ -641,7 +641,10 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
       if (j0 < live) {
 #pragma unroll
         for (int c = 0; c < DB; ++c) a[c] = Djj[c * DB + l15];
-        factor_block16<T>(a, w, bad, k * TS + j0, l15);
+        factor_block16<T>(a, w, bad, k * TS + j0, l15, [&] {
+#pragma unroll
+          for (int c = 0; c < DB; ++c) a[c] = Djj[c * DB + l15];
+        });
       } else {  // identity padding beyond the window (N not a multiple of 128): nothing to factor
 #pragma unroll
         for (int c = 0; c < DB; ++c) a[c] = w[c] = (c == l15) ? T(1) : T(0);

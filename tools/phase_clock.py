@@ -37,10 +37,10 @@ if ka[7]:
     extra["kind_A_wgs"] = int(ka[7])
 if fin[7]:
     extra["diag_finish_ticks_per_wg"] = {n: float(fin[i]) / fin[7] for i, n in enumerate(["fence_image_or_gram", "newest_two_block_columns", "tile_to_lds", "packed_factor_inverse_stores"])}
-pf = out[32:42]      # potf2_tile (fat diagonal tile): per tile F / P / U phase sums, tail, count, wave-0 factor, helper side, inverse, trailing
+pf = out[32:44]      # potf2_tile (fat diagonal tile): per tile F / P / U phase sums, tail, count, wave-0 factor, helper side, inverse, trailing
 if pf[4]:
     n = float(pf[4])
     extra["potf2_tile_ticks_per_tile"] = {"F_phases": pf[0] / n, "P_phases": pf[1] / n, "U_phases": pf[2] / n, "tail": pf[3] / n,
                                           "wave0_factor_in_F": pf[5] / n, "helpers_in_F": pf[6] / n, "helpers_inverse": pf[8] / n,
-                                          "helpers_trailing": pf[9] / n, "tiles": int(pf[4])}
+                                          "helpers_trailing": pf[9] / n, "wave0_block_load": pf[10] / n, "wave0_block_factor": pf[11] / n, "tiles": int(pf[4])}
 print(json.dumps({"config": a.config, "batch": a.batch, "step_ms": t0.elapsed_time(t1), "ticks_per_wg": rows, **extra}))
