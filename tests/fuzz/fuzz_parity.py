@@ -107,6 +107,7 @@ while time.time() < t_end:
         if not (e < tol_b):
             if f32 and e < 2.0 * tol_b:
                 marginal += 1       # single precision on an ill-conditioned window: within 2x of the bar, counted apart
+                print("marginal", tag, "fit", b, "err", e, "bar", tol_b)
             else:
                 print("FAIL", tag, "fit", b, "err", e, "bar", tol_b); bad += 1
 print(f"cases {cases} failures {bad} fp32-marginal {marginal} worst error / bar: fp64 {worst['f64']:.3g} fp32 {worst['f32']:.3g} "
