@@ -516,6 +516,10 @@ def extras(engine, torch, dev, local, W):
         ex.update(lookahead_line(engine, local))
     except Exception as e:
         ex["lookahead_error"] = repr(e)
+    try:
+        ex.update(node_line(engine, local))
+    except Exception as e:
+        ex["node_error"] = repr(e)
     return ex
 
 
@@ -659,6 +663,32 @@ def lookahead_line(engine, local, T=4096):
         ctx.predict_stop_batch(means, sigmas, P, Q, STM, Hv, pos, 10.0, 10.0)
     el = (time.perf_counter() - t0) / 3
     return {"lookahead_traj_per_s": T / el, "lookahead_workload": f"{T} trajectories x 599 x 5 steps, host buffers (PCIe copies included)"}
+
+
+def node_line(engine, local):
+    """The reference node's own work item (gp_slip_node.py:16-63): ONE GP_Input window of its recorded slip series
+    (149 ticks, 90 % kept, 599 predicted ticks, RBF x Brownian), host buffers in and out, with the fixed theta of the
+    fixture and with the reference's m.optimize() from theta = ones."""
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "slipval_window_rbfbrownian.npz"))
+    t, s, th = g["time_array"], g["slip_array"], g["theta"]
+    ctx = engine.Context(device=local, max_n=256, max_m=1024, max_d=1, max_batch=1)
+    for _ in range(3):
+        ctx.slip_node_callback(t, s, th)
+    ts = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        ctx.slip_node_callback(t, s, th)
+        ts.append(time.perf_counter() - t0)
+    ctx.slip_node_callback_opt(t, s, np.ones(4))
+    to = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ctx.slip_node_callback_opt(t, s, np.ones(4))
+        to.append(time.perf_counter() - t0)
+    return {"node_callback_us": 1e6 * float(np.median(ts)), "node_callback_opt_ms": 1e3 * float(np.median(to)),
+            "node_workload": f"one GP_Input window of the reference's slip series ({len(t)} ticks, 599 predictions, RBF x Brownian, fp64), "
+                             "host buffers, per callback: fixed theta / with m.optimize() from theta = ones"}
 
 
 def host_description():
