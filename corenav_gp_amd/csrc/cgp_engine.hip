@@ -87,6 +87,9 @@ struct cgp_ctx {
   // cgp_window_push staging, grown on demand and kept: one pinned host block and one device block per direction
   void *win_pin = nullptr, *win_dev = nullptr;
   size_t win_pin_cap = 0, win_dev_cap = 0;
+  // gradient-mode evaluations (cgp_nll_grad / cgp_optimize*): theta + jitter out, partial sums + logML + info back, one pinned block
+  void *opt_pin = nullptr;
+  size_t opt_pin_cap = 0;
   int *dinfo = nullptr;
   size_t lw_stride = 0, winv_stride = 0, alpha_stride = 0;
   // state of the last single fit (cgp_fit -> cgp_predict)
@@ -163,6 +166,7 @@ constexpr int MID_FITS_F64 = 48, MID_FITS_F32 = 96;
 #define CGP_NO_EXTRA_SPLIT 0   // `make variant` A/B: mid-size calls keep the extra rows inside the factorisation launches
 #endif
 constexpr bool kNoExtraSplit = CGP_NO_EXTRA_SPLIT != 0;
+constexpr size_t kOptPinIn = CGP_MAX_THETA + 8;   // doubles at the head of the gradient-mode pinned block: theta, jitter
 #ifndef CGP_WIN_PAIRS
 #define CGP_WIN_PAIRS 1   // sliding window: steady-state ticks two per pass over the factor (`make variant`: 0 = every tick on its own)
 #endif
@@ -794,6 +798,7 @@ void cgp_destroy(cgp_ctx *c) {
   for (void *wb : c->winbuf)
     if (wb) (void)hipFree(wb);
   if (c->win_pin) (void)hipHostFree(c->win_pin);
+  if (c->opt_pin) (void)hipHostFree(c->opt_pin);
   if (c->win_dev) (void)hipFree(c->win_dev);
   if (c->pin_in) (void)hipHostFree(c->pin_in);
   if (c->pin_out) (void)hipHostFree(c->pin_out);
@@ -1233,38 +1238,49 @@ int grad_eval(cgp_ctx *c, int N, int d, int kid, double *logml, double sums[GRAD
   const int npairs = a.NT * (a.NT + 1) / 2;
   hipLaunchKernelGGL(k_grad<T>, dim3(npairs, 1), dim3(256), upd_lds_bytes<T>(), s, a, npairs);
   HIP_TRY(c, hipGetLastError());
-  std::vector<double> part((size_t)npairs * GRAD_N);
-  HIP_TRY(c, hipMemcpyAsync(part.data(), c->dgpart, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipMemcpyAsync(logml, c->dlogml, sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipMemcpyAsync(info, c->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+  // results come back into the pinned block (real asynchronous copies, no pageable staging): [sums | logml | info]
+  const size_t npart = (size_t)npairs * GRAD_N;
+  if (!grow_pinned(c->opt_pin, c->opt_pin_cap, (kOptPinIn + npart + 2) * sizeof(double))) return CGP_ENOMEM;
+  double *part = static_cast<double *>(c->opt_pin) + kOptPinIn, *hl = part + npart;
+  int *hi = reinterpret_cast<int *>(hl + 1);
+  HIP_TRY(c, hipMemcpyAsync(part, c->dgpart, npart * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(hl, c->dlogml, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(hi, c->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  *logml = *hl;
+  *info = *hi;
   for (int i = 0; i < GRAD_N; ++i) sums[i] = 0.0;
   for (int pz = 0; pz < npairs; ++pz)  // fixed order: deterministic
     for (int i = 0; i < GRAD_N; ++i) sums[i] += part[(size_t)pz * GRAD_N + i];
   return CGP_OK;
 }
-}  // namespace
 
-extern "C" int cgp_nll_grad(cgp_ctx *c, const double *X, const double *y, int N, int d, int kid, const double *theta,
-                            double *nll, double *grad) {
-  int rc = check_shape(c, 1, N, d, N, kid);
-  if (rc != CGP_OK) return rc;
-  if (!X || !y || !theta || !nll || !grad) return CGP_EINVAL;
-  const int nth = ntheta(kid, d);
-  HIP_TRY(c, hipSetDevice(c->device));
-  hipStream_t s = c->stream;
+void grad_from_sums(int kid, int d, const double *theta, const double *sums, double *grad);   // below, with the batched optimiser
+
+// The window of a gradient-mode evaluation -> slot 0 (once per cgp_nll_grad call, once per cgp_optimize run)
+int upload_window(cgp_ctx *c, const double *X, const double *y, int N, int d, hipStream_t s) {
   std::vector<char> hx((size_t)d * N * c->esz), hy((size_t)N * c->esz);
   pack_soa(X, N, d, c->dtype, hx, 0);
   pack_vec(y, N, c->dtype, hy, 0);
-  std::vector<double> hth;
-  HIP_TRY(c, hipMemcpyAsync(c->dX, hx.data(), hx.size(), hipMemcpyHostToDevice, s));
-  HIP_TRY(c, hipMemcpyAsync(c->dy, hy.data(), hy.size(), hipMemcpyHostToDevice, s));
-  rc = upload_theta(c, theta, nth, nth, 1, s, hth);
-  if (rc != CGP_OK) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->dX, hx.data(), hx.size(), hipMemcpyHostToDevice, s));   // pageable source: staged by the
+  HIP_TRY(c, hipMemcpyAsync(c->dy, hy.data(), hy.size(), hipMemcpyHostToDevice, s));   // runtime before the call returns
+  return CGP_OK;
+}
+
+// -logML and its gradient at theta for the window in slot 0 (upload_window); X only feeds the jitter ladder's mean diagonal
+int nll_grad_resident(cgp_ctx *c, const double *X, int N, int d, int kid, const double *theta, double *nll, double *grad) {
+  const int nth = ntheta(kid, d);
+  hipStream_t s = c->stream;
+  if (!grow_pinned(c->opt_pin, c->opt_pin_cap, (kOptPinIn + 64) * sizeof(double))) return CGP_ENOMEM;
+  double *hin = static_cast<double *>(c->opt_pin);   // [theta (CGP_MAX_THETA) | jitter]; re-read after a grow in grad_eval
   double jit = 0.0, logml = 0.0, sums[GRAD_N];
-  int info = 0;
+  int info = 0, rc = CGP_OK;
   for (int attempt = 0; attempt <= 5; ++attempt) {  // GPy jitchol policy
-    HIP_TRY(c, hipMemcpyAsync(c->djitter, &jit, sizeof(double), hipMemcpyHostToDevice, s));
+    hin = static_cast<double *>(c->opt_pin);
+    for (int q = 0; q < CGP_MAX_THETA; ++q) hin[q] = q < nth ? theta[q] : 0.0;
+    hin[CGP_MAX_THETA] = jit;
+    HIP_TRY(c, hipMemcpyAsync(c->dtheta, hin, sizeof(double) * CGP_MAX_THETA, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->djitter, hin + CGP_MAX_THETA, sizeof(double), hipMemcpyHostToDevice, s));
     rc = c->dtype == CGP_F64 ? grad_eval<double>(c, N, d, kid, &logml, sums, &info)
                              : grad_eval<float>(c, N, d, kid, &logml, sums, &info);
     if (rc != CGP_OK) return rc;
@@ -1279,24 +1295,20 @@ extern "C" int cgp_nll_grad(cgp_ctx *c, const double *X, const double *y, int N,
   memcpy(c->ftheta, theta, sizeof(double) * nth);
   if (info != 0) return info;
   *nll = -logml;
-  // dlogML/dtheta = 0.5 * sum_ij w_ij dK_ij/dtheta  ->  gradient of the NEGATIVE log likelihood
-  if (kid == CGP_KERNEL_SE_ISO) {
-    double se = 0;
-    for (int q = 0; q < d; ++q) se += sums[1 + q];
-    grad[0] = -0.5 * sums[0] / theta[0];
-    grad[1] = -0.5 * se / theta[1];
-    grad[2] = -0.5 * sums[9];
-  } else if (kid == CGP_KERNEL_SE_ARD) {
-    grad[0] = -0.5 * sums[0] / theta[0];
-    for (int q = 0; q < d; ++q) grad[1 + q] = -0.5 * sums[1 + q] / theta[1 + q];
-    grad[d + 1] = -0.5 * sums[9];
-  } else {
-    grad[0] = -0.5 * sums[0] / theta[0];
-    grad[1] = -0.5 * sums[1] / theta[1];
-    grad[2] = -0.5 * sums[0] / theta[2];
-    grad[3] = -0.5 * sums[9];
-  }
+  grad_from_sums(kid, d, theta, sums, grad);   // dlogML/dtheta = 0.5 * sum_ij w_ij dK_ij/dtheta -> gradient of the NEGATIVE log likelihood
   return CGP_OK;
+}
+}  // namespace
+
+extern "C" int cgp_nll_grad(cgp_ctx *c, const double *X, const double *y, int N, int d, int kid, const double *theta,
+                            double *nll, double *grad) {
+  int rc = check_shape(c, 1, N, d, N, kid);
+  if (rc != CGP_OK) return rc;
+  if (!X || !y || !theta || !nll || !grad) return CGP_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  rc = upload_window(c, X, y, N, d, c->stream);
+  if (rc != CGP_OK) return rc;
+  return nll_grad_resident(c, X, N, d, kid, theta, nll, grad);
 }
 
 extern "C" int cgp_optimize(cgp_ctx *c, const double *X, const double *y, int N, int d, int kid, double *theta,
@@ -1314,10 +1326,13 @@ extern "C" int cgp_optimize(cgp_ctx *c, const double *X, const double *y, int N,
     x[i] = to_x(theta[i]);
   }
   int hard_error = CGP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  rc = upload_window(c, X, y, N, d, c->stream);   // the window does not change between evaluations: only theta travels
+  if (rc != CGP_OK) return rc;
   auto fg = [&](const std::vector<double> &xx, std::vector<double> &gx) -> double {
     for (int i = 0; i < nth; ++i) th[i] = std::max(to_theta(xx[i]), 1e-300);
     double nll = 0.0;
-    const int r = cgp_nll_grad(c, X, y, N, d, kid, th.data(), &nll, g.data());
+    const int r = nll_grad_resident(c, X, N, d, kid, th.data(), &nll, g.data());
     if (r < 0) hard_error = r;
     if (r != 0) return INFINITY;  // not PD even with jitter: infeasible point
     for (int i = 0; i < nth; ++i) gx[i] = g[i] * (xx[i] > 35.0 ? 1.0 : -std::expm1(-th[i]));  // dtheta/dx = 1 - exp(-theta)
@@ -1328,7 +1343,7 @@ extern "C" int cgp_optimize(cgp_ctx *c, const double *X, const double *y, int N,
   for (int i = 0; i < nth; ++i) theta[i] = to_theta(x[i]);
   // leave the context fitted at the optimum
   double nll = 0.0;
-  rc = cgp_nll_grad(c, X, y, N, d, kid, theta, &nll, g.data());
+  rc = nll_grad_resident(c, X, N, d, kid, theta, &nll, g.data());
   if (rc != CGP_OK) return rc;
   if (logml) *logml = -nll;
   if (n_evals) *n_evals = res.evals + 1;

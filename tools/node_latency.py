@@ -20,3 +20,16 @@ ts = []
 for _ in range(10):
     t0 = time.perf_counter(); m, sg, tho = ctx.slip_node_callback_opt(t, s, np.ones(4)); ts.append(time.perf_counter() - t0)
 print(f"with optimize(): median {1e3 * np.median(ts):.2f} ms, min {1e3 * min(ts):.2f} ms per callback; theta -> {np.round(tho, 5).tolist()}")
+# what one evaluation of the objective costs, and how many the optimiser takes
+X, y = t[:int(0.9 * len(t))], s[:int(0.9 * len(s))]
+for _ in range(3): ctx.nll_grad(X, y, engine.KERNEL_RBF_BROWNIAN, np.ones(4))
+t0 = time.perf_counter()
+for _ in range(100): ctx.nll_grad(X, y, engine.KERNEL_RBF_BROWNIAN, np.ones(4))
+ev = (time.perf_counter() - t0) / 100
+tho, logml, nev = ctx.optimize(X, y, engine.KERNEL_RBF_BROWNIAN, np.ones(4))
+print(f"one nll + gradient evaluation (host theta in, host gradient out): {1e6 * ev:.0f} us; optimize() took {nev} evaluations")
+# per-kernel time of one evaluation (the engine's own event profiler: update / diag / trsm / finalize / alpha groups)
+ctx.profile_enable(True)
+ctx.nll_grad(X, y, engine.KERNEL_RBF_BROWNIAN, np.ones(4))
+print("per-kernel time of one evaluation:", {k: (round(v["ms"], 4), v["launches"]) for k, v in ctx.profile_read().items() if v["launches"]})
+ctx.profile_enable(False)
