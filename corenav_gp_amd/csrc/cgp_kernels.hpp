@@ -770,26 +770,52 @@ __global__ __launch_bounds__(256) void k_alpha(FitArgs p) {
   const T *Winv = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride;
   const int ld = p.ld, NP = p.NT * TS, M = p.M;
   const size_t rb = (size_t)p.NT * TS;
+  // CG columns per wave at a time: their loads are all in flight before the first reduction (one column at a time
+  // was one HBM round trip per column, 32 in a row per wave and phase); per column the sums are formed in the same order.
+  constexpr int CG = 8;
   for (int tb = p.NT - 1; tb >= 0; --tb) {
     const int c0 = tb * TS, rbelow = c0 + TS;
-    for (int cl = wave; cl < TS; cl += 4) {
-      const T *col = Lw + (size_t)(c0 + cl) * ld;
-      double s = 0;
-      for (int r = rbelow + lane; r < NP; r += 64) s += (double)col[r] * al[r];
+    for (int cg = wave * CG; cg < TS; cg += 4 * CG) {
+      double s[CG];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      if (lane == 0) rhs[cl] = (double)col[rb + M] - s;
+      for (int j = 0; j < CG; ++j) s[j] = 0;
+      for (int r = rbelow + lane; r < NP; r += 64) {
+        const double a = al[r];
+#pragma unroll
+        for (int j = 0; j < CG; ++j) s[j] += (double)Lw[(size_t)(c0 + cg + j) * ld + r] * a;
+      }
+      double z[CG];
+#pragma unroll
+      for (int j = 0; j < CG; ++j) z[j] = (double)Lw[(size_t)(c0 + cg + j) * ld + rb + M];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int j = 0; j < CG; ++j) s[j] += __shfl_xor(s[j], off);
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < CG; ++j) rhs[cg + j] = z[j] - s[j];
+      }
     }
     __syncthreads();
     const T *Wt = Winv + (size_t)tb * WIMG;
-    for (int cl = wave; cl < TS; cl += 4) {
-      const int qb = cl >> 4, q = cl & 15;
-      double s = 0;
-      for (int r = qb * DB + lane; r < TS; r += 64)   // -W[r][cl] at block (r >> 4, qb), entry [q][r & 15]
-        s -= (double)Wt[wimg_blk(r >> 4, qb) + q * DB + (r & 15)] * rhs[r];
+    for (int cg = wave * CG; cg < TS; cg += 4 * CG) {
+      const int qb = cg >> 4;   // the CG columns share their 16-column block (CG divides 16)
+      double s[CG];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      if (lane == 0) al[c0 + cl] = s;
+      for (int j = 0; j < CG; ++j) s[j] = 0;
+      for (int r = qb * DB + lane; r < TS; r += 64) {  // -W[r][cl] at block (r >> 4, qb), entry [q][r & 15]
+        const double x = rhs[r];
+#pragma unroll
+        for (int j = 0; j < CG; ++j) s[j] -= (double)Wt[wimg_blk(r >> 4, qb) + ((cg + j) & 15) * DB + (r & 15)] * x;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int j = 0; j < CG; ++j) s[j] += __shfl_xor(s[j], off);
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < CG; ++j) al[c0 + cg + j] = s[j];
+      }
     }
     __syncthreads();
   }
