@@ -166,6 +166,9 @@ constexpr int MID_FITS_F64 = 48, MID_FITS_F32 = 96;
 #define CGP_NO_EXTRA_SPLIT 0   // `make variant` A/B: mid-size calls keep the extra rows inside the factorisation launches
 #endif
 constexpr bool kNoExtraSplit = CGP_NO_EXTRA_SPLIT != 0;
+#ifndef CGP_LAT_MIN_NT
+#define CGP_LAT_MIN_NT 1   // block steps from which a handful of fits takes the latency schedule (3 until the end of round 3: `make variant` A/B)
+#endif
 constexpr size_t kOptPinIn = CGP_MAX_THETA + 8;   // doubles at the head of the gradient-mode pinned block: theta, jitter
 #ifndef CGP_WIN_PAIRS
 #define CGP_WIN_PAIRS 1   // sliding window: steady-state ticks two per pass over the factor (`make variant`: 0 = every tick on its own)
@@ -358,7 +361,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   if (c->prof || !in_rows) G = 1;  // per-kernel timing wants isolated launches
   // latency schedule: a handful of fits, windows long enough for splitting to pay and short enough for the
   // diagonal tile's pre-update images (N <= 2560); anything else takes the throughput schedule
-  const bool latency = !sw.no_latency && batch <= std::min(lat_fits<T>(), c->lat_cap) && a.NT >= 3 && lat_images(a.NT - 1) <= LAT_IMG_MAX;
+  const bool latency = !sw.no_latency && batch <= std::min(lat_fits<T>(), c->lat_cap) && a.NT >= CGP_LAT_MIN_NT && lat_images(a.NT - 1) <= LAT_IMG_MAX;
   const bool mid = batch <= std::min(mid_fits<T>(), c->mid_cap);  // the whole call (the images are indexed by fit)
   if (latency || mid) G = 1;  // a mid-size call has its own concurrency (factorisation || extra rows, below)
   std::vector<FitArgs> ga(G);
