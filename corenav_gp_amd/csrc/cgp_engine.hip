@@ -64,7 +64,7 @@ struct cgp_ctx {
   double *dgpart = nullptr;
   void *dpart = nullptr;   // latency schedule: partial tiles [lat_cap][slots][SK_MAX][128*128]
   int *dticket = nullptr;  //                   arrival tickets [lat_cap][slots]
-  int lat_cap = 0;         //                   fits the latency slabs are sized for: min(LAT_FITS_F32, max_batch)
+  int lat_cap = 0;         //                   fits the latency slabs are sized for: min(LAT_FITS_ALLOC, max_batch)
   int *dwready = nullptr;  //                   published block steps [lat_cap]
   void *dlatimg = nullptr;  //                  pre-updated diagonal tiles [lat_cap][2][LAT_IMG_MAX][DPART]
   double *dmacc = nullptr;  // [max_batch][2][max_m] running predictive sums (throughput schedule, fp64)
@@ -156,6 +156,11 @@ struct Launcher {
 // schedule (tools/lat_crossover.sh, round 3: N = 2048 fp64 8 fits 1.87 vs 2.64 ms, 12 fits 2.72 vs 2.66; N = 1024 fp32
 // 20 fits 0.641 vs 0.672 ms, 24 fits 0.769 vs 0.712) is 11 fits in fp64 and 20 in fp32 (16 / 24 before the mid-size form).
 constexpr int LAT_FITS_F64 = 11, LAT_FITS_F32 = 20;
+// Short windows keep the latency schedule up to larger calls (tools/lat_crossover.sh at N = 256 / 512, end of round 3, ms per
+// call latency vs throughput: N = 256 fp64 32 fits 0.171 vs 0.240, 48 fits 0.225 vs 0.245; N = 256 fp32 32 fits 0.124 vs 0.133,
+// 48 fits 0.154 vs 0.138; N = 512 fp64 24 fits 0.376 vs 0.436, 32 fits 0.464 vs 0.534 (0.456 without the extra-row split), 48 fits
+// 0.653 vs 0.544): up to 32 fits for one or two block steps, up to 24 in fp64 for three or four.
+constexpr int LAT_FITS_SHORT = 32, LAT_FITS_F64_NT4 = 24;
 constexpr int FUSED64_BELOW = 512;                // fp64 throughput schedule: diagonal tiles inside the panel launches below this batch
 // Calls too small to fill the chip (a launch then lasts as long as its longest workgroup chain): the next launch's
 // kind-A tile is pre-updated by a kind-C workgroup (k_panel), and fp32 takes the deep-prefetch loops (DEEP).
@@ -176,7 +181,10 @@ constexpr size_t kOptPinIn = CGP_MAX_THETA + 8;   // doubles at the head of the 
 constexpr bool kWinPairs = CGP_WIN_PAIRS != 0;
 constexpr int kWinPackLds = 72 * 1024;       // pack windows into a workgroup only while two workgroups still fit a CU's LDS ...
 constexpr int kWinPackMinGroups = 512;       // ... and the chip still gets two workgroups per CU
-constexpr int XSPLIT64_FROM = 28;   // fp64 mid-size calls of at least this many fits put their extra rows on a second stream
+// fp64 mid-size calls put their extra rows on a second stream when there is enough of them: fits x block steps >= this
+// (tools/r3_xs_n.sh, same box, with / without, ms per call: N = 2048 28 fits 3.77 / 3.70, 36 fits 4.25 / 4.45, 48 fits 5.01 / 5.70;
+// N = 1536 36 fits 2.37 / 2.38, 48 fits 2.71 / 3.01; N = 1024 36 fits 1.27 / 1.17, 48 fits 1.29 / 1.31; N = 512 28 fits 0.52 / 0.42)
+constexpr int XSPLIT64_WORK = 480;
 constexpr int MID_FITS_ALLOC = kAbBuild ? 512 : (MID_FITS_F64 > MID_FITS_F32 ? MID_FITS_F64 : MID_FITS_F32);
 template <typename T> inline int mid_fits() {     // ablation build: CGP_MID_FITS moves the crossover (measurement)
   if constexpr (kAbBuild) {
@@ -185,13 +193,15 @@ template <typename T> inline int mid_fits() {     // ablation build: CGP_MID_FIT
   }
   return sizeof(T) == 8 ? MID_FITS_F64 : MID_FITS_F32;
 }
-constexpr int LAT_FITS_ALLOC = kAbBuild ? 64 : LAT_FITS_F32;  // slabs are sized for min(this, max_batch) fits
-template <typename T> inline int lat_fits() {     // ablation build: CGP_LAT_FITS moves the crossover (measurement)
+constexpr int LAT_FITS_ALLOC = kAbBuild ? 64 : LAT_FITS_SHORT;  // slabs are sized for min(this, max_batch) fits
+template <typename T> inline int lat_fits(int NT) {     // ablation build: CGP_LAT_FITS moves the crossover (measurement)
   if constexpr (kAbBuild) {
     const char *e = getenv("CGP_LAT_FITS");
     if (e) return std::max(0, std::min(atoi(e), LAT_FITS_ALLOC));
   }
-  return sizeof(T) == 8 ? LAT_FITS_F64 : LAT_FITS_F32;
+  if (NT <= 2) return LAT_FITS_SHORT;
+  if (sizeof(T) == 8) return NT <= 4 ? LAT_FITS_F64_NT4 : LAT_FITS_F64;
+  return LAT_FITS_F32;
 }
 
 inline size_t alpha_lds_bytes(int NT) { return (size_t)(NT * TS + TS) * sizeof(double); }
@@ -361,7 +371,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   if (c->prof || !in_rows) G = 1;  // per-kernel timing wants isolated launches
   // latency schedule: a handful of fits, windows long enough for splitting to pay and short enough for the
   // diagonal tile's pre-update images (N <= 2560); anything else takes the throughput schedule
-  const bool latency = !sw.no_latency && batch <= std::min(lat_fits<T>(), c->lat_cap) && a.NT >= CGP_LAT_MIN_NT && lat_images(a.NT - 1) <= LAT_IMG_MAX;
+  const bool latency = !sw.no_latency && batch <= std::min(lat_fits<T>(a.NT), c->lat_cap) && a.NT >= CGP_LAT_MIN_NT && lat_images(a.NT - 1) <= LAT_IMG_MAX;
   const bool mid = batch <= std::min(mid_fits<T>(), c->mid_cap);  // the whole call (the images are indexed by fit)
   if (latency || mid) G = 1;  // a mid-size call has its own concurrency (factorisation || extra rows, below)
   std::vector<FitArgs> ga(G);
@@ -498,7 +508,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // 3.92, 24 fits 3.48 -> 3.51, 12 fits 2.62 -> 3.45 (the call is one chain then: nothing to run beside it); fp32 N = 1024
   // 64 fits 0.99 -> 1.01, 32 fits 0.69 -> 0.76: its launches last as long as kind A's chain at every k, so the extra rows'
   // last launches only queue up behind it, and two contexts overlap worse (0.76 -> 0.96 ms per call).  fp64 from 28 fits.
-  const bool xsplit = mid && sizeof(T) == 8 && batch >= XSPLIT64_FROM && in_rows && !split_diag && G == 1 && a.ET > 0 && !kNoExtraSplit;
+  const bool xsplit = mid && sizeof(T) == 8 && batch * a.NT >= XSPLIT64_WORK && in_rows && !split_diag && G == 1 && a.ET > 0 && !kNoExtraSplit;
   hipStream_t sE = c->wstream[0];
   Launcher LE{c, sE};
   for (int k = 0; k < a.NT; ++k) {

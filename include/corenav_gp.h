@@ -54,7 +54,7 @@ enum {
  * tests/fuzz/fuzz_parity.py, is max(1e-3, 10 x the error of spotrf / strtrs on the same window) for dense
  * one-dimensional inputs and max(3e-3, 30 x that error) for the reference's RBF x Brownian kernel on raw
  * tick counts (cond(Ky) ~ 1e6) -- use CGP_F64 for that kernel, as the reference does.  (About one window in two
- * thousand of that sweep lands between 1.0 and 1.1 of the first bar -- N = 512 ... 700, one input dimension, one test
+ * thousand of that sweep lands between 1.0 and 1.3 of the first bar -- N = 512 ... 700, one input dimension, one test
  * point; the sweep prints such windows and counts them apart up to 2 x the bar.)
  * Returns NULL on failure (device index out of range, device is not gfx950 -- the architecture name
  * is checked: the code object holds gfx950 kernels only -- or out of memory): no CPU fallback. */

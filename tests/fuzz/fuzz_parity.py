@@ -49,7 +49,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 NS = [3, 15, 16, 17, 127, 128, 129, 134, 255, 256, 257, 300, 383, 384, 385, 511, 512, 513, 640, 700, 1000, 1024, 1100]
 MS = [0, 1, 5, 126, 127, 128, 129, 255, 256, 300, 599]
-BS = [1, 2, 4, 5, 10, 11, 12, 19, 20, 21, 33, 48, 49, 96, 97]   # either side of the latency (11 / 20), mid-size (48 / 96) switches
+BS = [1, 2, 4, 5, 10, 11, 12, 19, 20, 21, 24, 25, 32, 33, 48, 49, 96, 97]   # either side of the latency (11 / 20; 24 / 32 for short windows), mid-size (48 / 96) switches
 t_end, cases, bad, marginal, brown32, worst = time.time() + budget, 0, 0, 0, 0.0, {"f64": 0.0, "f32": 0.0}
 while time.time() < t_end:
     N, M, B = int(rng.choice(NS)), int(rng.choice(MS)), int(rng.choice(BS))
