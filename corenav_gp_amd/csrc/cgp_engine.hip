@@ -963,7 +963,19 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
     if (e == hipSuccess) e = one(nX + ny + b0 * M * d, (b1 - b0) * (size_t)M * d);
     return e;
   };
-  {
+  if (nthr == 1) {
+    // a small call: the whole staged block [X | y | Xs | theta] in ONE DMA, unpacked by ONE launch
+    stage(0, B);
+    HIP_TRY(c, hipMemcpyAsync(c->draw, hin, in_bytes, hipMemcpyHostToDevice, s));
+    lap("stage + queue DMA");
+    const dim3 grid(std::min(64, cdiv(std::max(N, M) * d, 256)), batch);
+    if (c->dtype == CGP_F64)
+      hipLaunchKernelGGL(k_pack_call<double>, grid, dim3(256), 0, s, draw, static_cast<double *>(c->dX), static_cast<double *>(c->dy),
+                         static_cast<double *>(c->dXs), c->dtheta, c->djitter, batch, N, d, M);
+    else
+      hipLaunchKernelGGL(k_pack_call<float>, grid, dim3(256), 0, s, draw, static_cast<float *>(c->dX), static_cast<float *>(c->dy),
+                         static_cast<float *>(c->dXs), c->dtheta, c->djitter, batch, N, d, M);
+  } else {
     std::vector<std::thread> th;
     auto lo = [&](int w) { return B * w / nthr; };
     for (int w = 1; w < nthr; ++w) th.emplace_back(stage, lo(w), lo(w + 1));
@@ -974,20 +986,20 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
       if (e == hipSuccess) e = dma(lo(w), lo(w + 1));
     }
     HIP_TRY(c, e);
+    lap("stage + queue DMA");
+    HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(c->draw) + (nX + ny + nXs) * sizeof(double), hth, nTh * sizeof(double),
+                              hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->dtheta, draw + nX + ny + nXs, nTh * sizeof(double), hipMemcpyDeviceToDevice, s));
+    auto pack = [&](const double *src, void *dst, int n, int dd) {
+      const dim3 grid(std::min(64, cdiv(n * dd, 256)), batch);
+      if (c->dtype == CGP_F64) hipLaunchKernelGGL(k_pack_soa<double>, grid, dim3(256), 0, s, src, static_cast<double *>(dst), n, dd);
+      else hipLaunchKernelGGL(k_pack_soa<float>, grid, dim3(256), 0, s, src, static_cast<float *>(dst), n, dd);
+    };
+    pack(draw, c->dX, N, d);
+    pack(draw + nX, c->dy, N, 1);
+    if (M > 0) pack(draw + nX + ny, c->dXs, M, d);
+    HIP_TRY(c, hipMemsetAsync(c->djitter, 0, sizeof(double) * batch, s));
   }
-  lap("stage + queue DMA");
-  HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(c->draw) + (nX + ny + nXs) * sizeof(double), hth, nTh * sizeof(double),
-                            hipMemcpyHostToDevice, s));
-  HIP_TRY(c, hipMemcpyAsync(c->dtheta, draw + nX + ny + nXs, nTh * sizeof(double), hipMemcpyDeviceToDevice, s));
-  auto pack = [&](const double *src, void *dst, int n, int dd) {
-    const dim3 grid(std::min(64, cdiv(n * dd, 256)), batch);
-    if (c->dtype == CGP_F64) hipLaunchKernelGGL(k_pack_soa<double>, grid, dim3(256), 0, s, src, static_cast<double *>(dst), n, dd);
-    else hipLaunchKernelGGL(k_pack_soa<float>, grid, dim3(256), 0, s, src, static_cast<float *>(dst), n, dd);
-  };
-  pack(draw, c->dX, N, d);
-  pack(draw + nX, c->dy, N, 1);
-  if (M > 0) pack(draw + nX + ny, c->dXs, M, d);
-  HIP_TRY(c, hipMemsetAsync(c->djitter, 0, sizeof(double) * batch, s));
   rc = cgp_fit_predict_batch_device(c, batch, N, d, M, kid, c->dX, c->dy, c->dXs, c->dtheta, c->djitter,
                                     include_noise, c->dmean, c->dvar, c->dlogml, c->dinfo, CGP_STREAM_CTX);
   if (rc != CGP_OK) return rc;
@@ -995,15 +1007,28 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
   double *hl = reinterpret_cast<double *>(hout + out_elems * esz);
   int *hinfo = reinterpret_cast<int *>(hl + B);
   lap("queue schedule");
+  // results are requested together with the status: one synchronisation per call unless a fit needs the jitter ladder
+  auto queue_results = [&]() -> hipError_t {
+    hipError_t e = hipSuccess;
+    if (M > 0) {
+      e = hipMemcpyAsync(hout, c->dmean, B * M * esz, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(hout + B * M * esz, c->dvar, B * M * esz, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hl, c->dlogml, sizeof(double) * batch, hipMemcpyDeviceToHost, s);
+    return e;
+  };
   HIP_TRY(c, hipMemcpyAsync(hinfo, c->dinfo, sizeof(int) * batch, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, queue_results());
   HIP_TRY(c, hipStreamSynchronize(s));
-  lap("device done (info)");
+  lap("device done (info + results)");
+  bool retried = false;
   // GPy jitchol policy for the fits that failed: jitter = mean(diag) * 1e-6 * 10^k, k = 0..4,
   // re-submitted one fit at a time (rare path) into the same device slots.
   std::vector<double> hjit(batch, 0.0);
   for (int b = 0; b < batch; ++b) {
     if (hinfo[b] == 0) continue;
     double jit = mean_diag(kid, theta + (size_t)b * theta_stride, d, X + (size_t)b * N * d, N) * 1e-6;
+    retried = true;
     for (int attempt = 0; attempt < 5 && hinfo[b] != 0; ++attempt, jit *= 10.0) {
       HIP_TRY(c, hipMemcpyAsync(c->djitter + b, &jit, sizeof(double), hipMemcpyHostToDevice, s));
       rc = cgp_fit_predict_batch_device(
@@ -1018,12 +1043,10 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
     }
   }
   c->fjitter = hjit[0];
-  if (M > 0) {
-    HIP_TRY(c, hipMemcpyAsync(hout, c->dmean, B * M * esz, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(hout + B * M * esz, c->dvar, B * M * esz, hipMemcpyDeviceToHost, s));
+  if (retried) {
+    HIP_TRY(c, queue_results());
+    HIP_TRY(c, hipStreamSynchronize(s));
   }
-  HIP_TRY(c, hipMemcpyAsync(hl, c->dlogml, sizeof(double) * batch, hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipStreamSynchronize(s));
   lap("D2H");
   if (M > 0) {
     if (c->dtype == CGP_F64) {

@@ -836,4 +836,27 @@ __global__ void k_pack_soa(const double *__restrict__ src, T *__restrict__ dst, 
   }
 }
 
+// The three k_pack_soa of a host-buffer call, the copy of theta to its own buffer and the zeroing of the jitter in ONE
+// launch (a small call is a handful of short launches: five of them were staging).  raw = [X | y | Xs | theta] as staged.
+template <typename T>
+__global__ void k_pack_call(const double *__restrict__ raw, T *__restrict__ dX, T *__restrict__ dy, T *__restrict__ dXs,
+                            double *__restrict__ dtheta, double *__restrict__ djitter, int batch, int N, int d, int M) {
+  const size_t b = blockIdx.y, B = batch;
+  const double *sx = raw + b * (size_t)N * d, *sy = raw + B * N * d + b * (size_t)N;
+  const double *sxs = raw + B * N * d + B * N + b * (size_t)M * d, *sth = raw + B * N * d + B * N + B * (size_t)M * d + b * MAX_THETA;
+  T *ox = dX + b * (size_t)N * d, *oy = dy + b * (size_t)N, *oxs = dXs + b * (size_t)M * d;
+  const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = t0; i < N * d; i += stride) {
+    const int r = i / d, q = i - r * d;
+    ox[(size_t)q * N + r] = (T)sx[i];
+  }
+  for (int i = t0; i < N; i += stride) oy[i] = (T)sy[i];
+  for (int i = t0; i < M * d; i += stride) {
+    const int r = i / d, q = i - r * d;
+    oxs[(size_t)q * M + r] = (T)sxs[i];
+  }
+  if (t0 < MAX_THETA) dtheta[b * MAX_THETA + t0] = sth[t0];
+  if (t0 == 0) djitter[b] = 0.0;
+}
+
 }  // namespace cgp
