@@ -396,12 +396,12 @@ def test_throughput_schedule_matches_oracle(engine, dtype_name, N):
     assert relmax(m2, mean[:2]) < tol and np.max(np.abs(l2 - logml[:2]) / np.abs(logml[:2])) < tol
 
 
-@pytest.mark.parametrize("dtype_name,N", [("F64", 700), ("F32", 520)])
-def test_latency_schedule_mid_batch(engine, dtype_name, N):
-    """The latency schedule at the top of its range (11 fits per call in fp64, 20 in fp32): oracle parity, and a
-    fit's result does not depend on its companions or on its slot in the call (bitwise)."""
+@pytest.mark.parametrize("dtype_name,N,B", [("F64", 700, 11), ("F32", 520, 20), ("F64", 200, 32), ("F32", 130, 32), ("F64", 500, 24)])
+def test_latency_schedule_mid_batch(engine, dtype_name, N, B):
+    """The latency schedule at the top of its range (11 fits per call in fp64, 20 in fp32; 32 for windows of one or two
+    block steps, 24 in fp64 for three or four): oracle parity, and a fit's result does not depend on its companions or
+    on its slot in the call (bitwise)."""
     dtype, tol = getattr(engine, dtype_name), (TOL64 if dtype_name == "F64" else TOL32)
-    B = 11 if dtype_name == "F64" else 20
     kid, X, y, Xs, th, _ = synth.config(2, batch=B, N=N)
     ctx = engine.Context(max_n=N, max_m=Xs.shape[1], max_d=X.shape[2], max_batch=B, dtype=dtype)
     rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
