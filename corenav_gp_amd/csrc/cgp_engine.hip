@@ -762,7 +762,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc(&c->dalpha, B * c->alpha_stride * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dtheta, B * CGP_MAX_THETA * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->djitter, B * sizeof(double)) == hipSuccess;
-  ok = ok && hipMalloc((void **)&c->dgpart, B * c->NTmax * (c->NTmax + 1) / 2 * GRAD_N * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->dgpart, (B * c->NTmax * (c->NTmax + 1) / 2 * GRAD_N + 2) * sizeof(double)) == hipSuccess;  // + logML, info of a single evaluation
   c->sk_slots = c->NTmax + c->ETmax + 1;
   c->lat_cap = std::min(LAT_FITS_ALLOC, max_batch);
   ok = ok && hipMalloc(&c->dpart, (size_t)c->lat_cap * c->sk_slots * SK_MAX * TS * TS * c->esz) == hipSuccess;
@@ -1266,22 +1266,21 @@ int grad_eval(cgp_ctx *c, int N, int d, int kid, double *logml, double sums[GRAD
   a.jitter = c->djitter;
   a.mean = c->dmean;
   a.var = c->dvar;
-  a.logml = c->dlogml;
-  a.info = c->dinfo;
+  // logML and info of this one window live right behind its partial sums: [sums | logml | info] comes back in ONE copy,
+  // into the pinned block (a real asynchronous copy, no pageable staging)
+  const int npairs = a.NT * (a.NT + 1) / 2;
+  const size_t npart = (size_t)npairs * GRAD_N;
   a.gpart = c->dgpart;
+  a.logml = c->dgpart + npart;
+  a.info = reinterpret_cast<int *>(c->dgpart + npart + 1);
   int rc = run(c, a, 1, true, true, s);
   if (rc != CGP_OK) return rc;
-  const int npairs = a.NT * (a.NT + 1) / 2;
   hipLaunchKernelGGL(k_grad<T>, dim3(npairs, 1), dim3(256), upd_lds_bytes<T>(), s, a, npairs);
   HIP_TRY(c, hipGetLastError());
-  // results come back into the pinned block (real asynchronous copies, no pageable staging): [sums | logml | info]
-  const size_t npart = (size_t)npairs * GRAD_N;
   if (!grow_pinned(c->opt_pin, c->opt_pin_cap, (kOptPinIn + npart + 2) * sizeof(double))) return CGP_ENOMEM;
   double *part = static_cast<double *>(c->opt_pin) + kOptPinIn, *hl = part + npart;
   int *hi = reinterpret_cast<int *>(hl + 1);
-  HIP_TRY(c, hipMemcpyAsync(part, c->dgpart, npart * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipMemcpyAsync(hl, c->dlogml, sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipMemcpyAsync(hi, c->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(part, c->dgpart, (npart + 2) * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   *logml = *hl;
   *info = *hi;
