@@ -549,7 +549,23 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
 #else
 #define POTF2_LAP(x)
 #endif
-  for (int jb = 0; jb < NB; ++jb) {
+  // A ragged last tile (the window ends inside it) is factored on its live block rows only: rows and columns beyond
+  // the window are the identity (off-diagonal blocks exactly zero: the Gram tile pads so and the updates add zero rows), so
+  // every product that involves them is zero and every loop below runs over nbl instead of NB block rows.  What the
+  // skipped steps would have produced is written here once: identity diagonal blocks of L and of W, zero blocks of the
+  // W image.  (A window of 134 ticks used to pay a whole tile's factorisation for its six rows beyond 128.)
+  const int nbl = min(NB, (live + DB - 1) / DB);
+  if (nbl < NB) {
+    for (int e = nbl * DB * DB + tid; e < NB * DB * DB; e += 256) {
+      const int jb = e >> 8, c = (e >> 4) & 15, r = e & 15;
+      const T v = (r == c) ? T(1) : T(0);
+      At[(jb * DB + c) * LDP + jb * DB + r] = v;
+      Dv[e] = v;   // Dv[jb][r][c]: the identity either way
+    }
+    for (int i = nbl; i < NB; ++i)
+      for (int e = tid; e < i * DB * DB; e += 256) Wk[wimg_blk(i, e >> 8) + (e & 255)] = T(0);
+  }
+  for (int jb = 0; jb < nbl; ++jb) {
     const int j0 = jb * DB;
     // ---- F(jb)
     if (wave == 0) {
@@ -592,7 +608,7 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
 #endif
     } else {
       if (jb > 0) {
-        const int jp = jb - 1, nb = NB - 1 - jb;  // block columns jb+1 .. 7 still take panel jp
+        const int jp = jb - 1, nb = nbl - 1 - jb;  // block columns jb+1 .. nbl-1 still take panel jp
 #ifdef CGP_ABLATION
         long long h0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -622,7 +638,7 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
     lds_barrier();  // HBM stores of the helpers stay in flight
     POTF2_LAP(tF)
     // ---- P(jb): rows of block bi below the diagonal block, P[r][c] = sum_q A[r][q] Dinv[c][q]
-    for (int bi = jb + 1 + wave; bi < NB; bi += 4) {
+    for (int bi = jb + 1 + wave; bi < nbl; bi += 4) {
       acc_t acc = acc_t{0, 0, 0, 0};
       T fa[4], fb[4];
 #pragma unroll
@@ -638,13 +654,13 @@ __device__ __forceinline__ void potf2_tile(const FitArgs &p, T *At, T *Dv, T *Ts
     lds_barrier();
     POTF2_LAP(tP)
     // ---- U(jb): block column jb + 1 with panel jb
-    for (int bi = jb + 1 + wave; bi < NB; bi += 4) trailing_block(bi, jb + 1, jb);
+    for (int bi = jb + 1 + wave; bi < nbl; bi += 4) trailing_block(bi, jb + 1, jb);
     lds_barrier();
     POTF2_LAP(tU)
   }
-  // ---- tail: row 7 of W and the last column
-  for (int j = 0; j < NB - 1; ++j)
-    if (snake(j + 1, 4) == wave) inverse_block(NB - 1, j);   // offset 1: wave 0 comes out of the last factor block last
+  // ---- tail: the last live row of W and the last column
+  for (int j = 0; j < nbl - 1; ++j)
+    if (snake(j + 1, 4) == wave) inverse_block(nbl - 1, j);   // offset 1: wave 0 comes out of the last factor block last
   // L and the Dinv blocks of the image go to HBM once, here, by all four waves (16-byte stores: the tail is
   // store-issue-bound).  Spreading them over the last factor phases, where the helper waves have few trailing
   // blocks left, was measured: the phases grew by more than the tail shrank.  The strictly upper 16x16 blocks of
