@@ -156,11 +156,18 @@ struct Launcher {
 // schedule (tools/lat_crossover.sh, round 3: N = 2048 fp64 8 fits 1.87 vs 2.64 ms, 12 fits 2.72 vs 2.66; N = 1024 fp32
 // 20 fits 0.641 vs 0.672 ms, 24 fits 0.769 vs 0.712) is 11 fits in fp64 and 20 in fp32 (16 / 24 before the mid-size form).
 constexpr int LAT_FITS_F64 = 11, LAT_FITS_F32 = 20;
-// Short windows keep the latency schedule up to larger calls (tools/lat_crossover.sh at N = 256 / 512, end of round 3, ms per
-// call latency vs throughput: N = 256 fp64 32 fits 0.171 vs 0.240, 48 fits 0.225 vs 0.245; N = 256 fp32 32 fits 0.124 vs 0.133,
-// 48 fits 0.154 vs 0.138; N = 512 fp64 24 fits 0.376 vs 0.436, 32 fits 0.464 vs 0.534 (0.456 without the extra-row split), 48 fits
-// 0.653 vs 0.544): up to 32 fits for one or two block steps, up to 24 in fp64 for three or four.
-constexpr int LAT_FITS_SHORT = 32, LAT_FITS_F64_NT4 = 24;
+// The shorter the window, the larger the call the latency schedule still wins (tools/lat_crossover.sh by window length, end of
+// round 3, ms per call latency vs throughput).  fp64: N = 256 32 fits 0.171 vs 0.240, 48 fits 0.225 vs 0.245; N = 512 28 fits 0.417 vs
+// 0.422 (no extra-row split), 32 fits 0.464 vs 0.456; N = 768 20 fits 0.607 vs 0.657, 24 fits 0.681 vs 0.681; N = 1024 16 fits 0.835 vs
+// 0.920, 20 fits 1.010 vs 0.954; N = 1536 12 fits 1.487 vs 1.635, 16 fits 1.926 vs 1.682; N = 2048 11 (above).  fp32: N = 256 32 fits
+// 0.124 vs 0.133, 48 fits 0.154 vs 0.138; N = 512 24 fits 0.261 vs 0.272, 28 fits 0.290 vs 0.276; N = 768 20 fits 0.412 vs 0.414; N = 1024
+// 20 (above).  The slabs are sized for LAT_FITS_SHORT fits.
+constexpr int LAT_FITS_SHORT = 32;
+inline int lat_fits_by_steps(bool f64, int NT) {
+  if (NT <= 2) return LAT_FITS_SHORT;
+  if (f64) return NT <= 4 ? 28 : NT <= 6 ? 22 : NT <= 8 ? 18 : NT <= 12 ? 13 : LAT_FITS_F64;
+  return NT <= 4 ? 24 : LAT_FITS_F32;
+}
 constexpr int FUSED64_BELOW = 512;                // fp64 throughput schedule: diagonal tiles inside the panel launches below this batch
 // Calls too small to fill the chip (a launch then lasts as long as its longest workgroup chain): the next launch's
 // kind-A tile is pre-updated by a kind-C workgroup (k_panel), and fp32 takes the deep-prefetch loops (DEEP).
@@ -199,9 +206,7 @@ template <typename T> inline int lat_fits(int NT) {     // ablation build: CGP_L
     const char *e = getenv("CGP_LAT_FITS");
     if (e) return std::max(0, std::min(atoi(e), LAT_FITS_ALLOC));
   }
-  if (NT <= 2) return LAT_FITS_SHORT;
-  if (sizeof(T) == 8) return NT <= 4 ? LAT_FITS_F64_NT4 : LAT_FITS_F64;
-  return LAT_FITS_F32;
+  return lat_fits_by_steps(sizeof(T) == 8, NT);
 }
 
 inline size_t alpha_lds_bytes(int NT) { return (size_t)(NT * TS + TS) * sizeof(double); }
