@@ -8,8 +8,10 @@ from corenav_gp_amd import engine, synth
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 bad = 0
-for cfg, dtype, N in ((2, engine.F64, 2048), (2, engine.F64, 1000), (3, engine.F32, 1024)):
-    for B in (1, 3, 4, 13, 24):
+# short windows keep the schedule up to larger calls (32 fits at one or two block steps, 28 / 22 at four / six in fp64)
+for cfg, dtype, N in ((2, engine.F64, 2048), (2, engine.F64, 1000), (3, engine.F32, 1024), (2, engine.F64, 134), (2, engine.F64, 500),
+                      (2, engine.F64, 700), (3, engine.F32, 200), (3, engine.F32, 512)):
+    for B in ((1, 3, 4, 13, 24) if N > 800 else (1, 5, 22, 28, 32)):
         kid, X, y, Xs, th, _ = synth.config(cfg, batch=B, N=N)
         ctx = engine.Context(max_n=N, max_m=Xs.shape[1], max_d=X.shape[2], max_batch=B, dtype=dtype)
         ref = ctx.fit_predict_batch(X, y, Xs, th, kid)
