@@ -193,12 +193,16 @@ constexpr int kWinPackMinGroups = 512;       // ... and the chip still gets two 
 // N = 1536 36 fits 2.37 / 2.38, 48 fits 2.71 / 3.01; N = 1024 36 fits 1.27 / 1.17, 48 fits 1.29 / 1.31; N = 512 28 fits 0.52 / 0.42)
 constexpr int XSPLIT64_WORK = 480;
 constexpr int MID_FITS_ALLOC = kAbBuild ? 512 : (MID_FITS_F64 > MID_FITS_F32 ? MID_FITS_F64 : MID_FITS_F32);
-template <typename T> inline int mid_fits() {     // ablation build: CGP_MID_FITS moves the crossover (measurement)
+// fp64 by window length (tools/r3_mid_n2.sh, end of round 3, with the extra-row split by work; mid-size form off / on, ms per call):
+// N = 2048 64 fits 7.26 / 6.87, 96 fits 9.80 / 9.67; N = 1536 96 fits 5.14 / 4.95; N = 1024 96 fits 2.22 / 2.10; N = 768 64 fits 1.06 /
+// 1.01, 80 fits 1.16 / 1.16, 96 fits 1.27 / 1.28; N = 512 96 fits 0.645 / 0.663 -- up to 96 fits from eight block steps, 64 from six.
+template <typename T> inline int mid_fits(int NT) {     // ablation build: CGP_MID_FITS moves the crossover (measurement)
   if constexpr (kAbBuild) {
     const char *e = getenv("CGP_MID_FITS");
     if (e) return std::max(0, std::min(atoi(e), MID_FITS_ALLOC));
   }
-  return sizeof(T) == 8 ? MID_FITS_F64 : MID_FITS_F32;
+  if (sizeof(T) == 8) return NT >= 8 ? MID_FITS_F32 : NT >= 6 ? 64 : MID_FITS_F64;
+  return MID_FITS_F32;
 }
 constexpr int LAT_FITS_ALLOC = kAbBuild ? 64 : LAT_FITS_SHORT;  // slabs are sized for min(this, max_batch) fits
 template <typename T> inline int lat_fits(int NT) {     // ablation build: CGP_LAT_FITS moves the crossover (measurement)
@@ -377,7 +381,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // latency schedule: a handful of fits, windows long enough for splitting to pay and short enough for the
   // diagonal tile's pre-update images (N <= 2560); anything else takes the throughput schedule
   const bool latency = !sw.no_latency && batch <= std::min(lat_fits<T>(a.NT), c->lat_cap) && a.NT >= CGP_LAT_MIN_NT && lat_images(a.NT - 1) <= LAT_IMG_MAX;
-  const bool mid = batch <= std::min(mid_fits<T>(), c->mid_cap);  // the whole call (the images are indexed by fit)
+  const bool mid = batch <= std::min(mid_fits<T>(a.NT), c->mid_cap);  // the whole call (the images are indexed by fit)
   if (latency || mid) G = 1;  // a mid-size call has its own concurrency (factorisation || extra rows, below)
   std::vector<FitArgs> ga(G);
   std::vector<int> gb(G);

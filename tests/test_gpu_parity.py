@@ -293,7 +293,7 @@ def test_config3_as_sharded_64_fits_fp32(engine):
 
 @pytest.mark.parametrize("dtype_name,N,small,large", [("F32", 640, 64, 100), ("F32", 1024, 40, 97), ("F64", 640, 48, 52)])
 def test_mid_size_schedule_is_bitwise_the_full_schedule(engine, dtype_name, N, small, large):
-    """A mid-size call (<= 96 fits fp32 / 48 fp64) splits the chain tile of every block step over two launches
+    """A mid-size call (<= 96 fits fp32 / 48 fp64, 64 / 96 fp64 from six / eight block steps) splits the chain tile of every block step over two launches
     (kind C leaves a register image, kind A of the next launch adds the newest block column) and, in fp32, runs the
     deep-prefetch loops; a larger call computes every tile in one workgroup with the register-staged loop.  Same
     arithmetic in the same order: the first `small` fits of a `large`-fit call equal a `small`-fit call BITWISE in fp64
