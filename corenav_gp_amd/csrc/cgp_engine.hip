@@ -755,8 +755,18 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   c->alpha_stride = (size_t)c->NTmax * TS;
   const size_t B = max_batch;
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+  // Worker streams carry launches that must run BESIDE the caller's stream (the extra-row launches E(k) of a mid-size
+  // call, the groups of cgp_set_streams).  The runtime multiplexes HIP streams onto a few hardware queues per priority
+  // level, and two streams that land on one queue run in order: a 64-fit fp64 call took 8.34 instead of 6.87 ms whenever
+  // its worker stream shared the legacy default stream's queue -- which depended on how many streams the process had used
+  // before (tools/ctx_placement.py, profiles/r04_ctx_placement.txt: one throw-away stream created in between restored
+  // 6.89 ms; memory placement played no part).  Queues are pooled per priority, so the workers are created at the LOWEST
+  // priority: they never share a queue with a normal-priority caller stream, and the chain-bound factorisation launches
+  // on the caller's stream are dispatched ahead of the extra rows that fill in beside them.
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {
-    ok = ok && hipStreamCreateWithFlags(&c->wstream[i], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&c->wstream[i], hipStreamNonBlocking, prio_least) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
   }
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -835,6 +845,25 @@ int cgp_debug_read(cgp_ctx *c, long long out[CGP_DEBUG_SLOTS]) {
   HIP_TRY(c, hipDeviceSynchronize());
   HIP_TRY(c, hipMemcpy(out, c->ddbg, DBG_SLOTS * sizeof(long long), hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemset(c->ddbg, 0, DBG_SLOTS * sizeof(long long)));  // the sums restart
+  return CGP_OK;
+}
+
+int cgp_debug_buffers(cgp_ctx *c, unsigned long long out[2 * CGP_DEBUG_BUFFERS]) {
+  if (!c || !out) return CGP_EINVAL;
+  const size_t B = c->max_batch;
+  const void *p[CGP_DEBUG_BUFFERS] = {c->Lw, c->Winv, c->ddiagimg, c->dpanimg, c->dX, c->dmacc, c->dpart, c->dlatimg};
+  const size_t n[CGP_DEBUG_BUFFERS] = {B * c->lw_stride * c->esz,
+                                       B * c->winv_stride * c->esz,
+                                       B * 2 * DPART * c->esz,
+                                       (size_t)c->mid_cap * 2 * DPART * c->esz,
+                                       B * c->max_d * c->max_n * c->esz,
+                                       sizeof(double) * 2 * B * std::max(c->max_m, 1),
+                                       (size_t)c->lat_cap * c->sk_slots * SK_MAX * TS * TS * c->esz,
+                                       (size_t)c->lat_cap * 2 * LAT_IMG_MAX * DPART * c->esz};
+  for (int i = 0; i < CGP_DEBUG_BUFFERS; ++i) {
+    out[2 * i] = (unsigned long long)(uintptr_t)p[i];
+    out[2 * i + 1] = n[i];
+  }
   return CGP_OK;
 }
 

@@ -1,0 +1,514 @@
+// cgp_small.hpp -- the reference's own operating point in ONE launch.
+//
+// gp_slip_node.py:27-36 fits a window of at most 134 kept ticks and runs m.optimize() on it: a few dozen evaluations of
+// -logML and its gradient on a matrix that is 72 KB as a packed fp64 lower triangle -- it fits one CU's LDS.  Up to
+// round 3 every evaluation was seven launches of the large-window machinery (128 x 128 tiles, factor panel in HBM) and a
+// host round trip: 0.22 ms each, 5.9 ms per callback, all of it launch and PCIe latency.  Here one workgroup per
+// window does everything without leaving the CU:
+//
+//   Gram (RBF x Brownian, SE-iso, SE-ARD; + (sigma_n^2 + 1e-8 + jitter) I)          packed lower 16 x 16 blocks in LDS
+//   Cholesky + W = L^-1 in place (GPy: jitchol / dpotrf, dtrtri)                     factor_block16 on wave 0, MFMA
+//                                                                                    f64 16x16x4 panels / updates /
+//                                                                                    inverse rows on the other waves
+//   z = W y, alpha = W^T z, logML = -z'z/2 - sum log L_ii - N/2 log 2 pi              (GPy: dpotrs, the likelihood)
+//   Ky^-1 = W^T W block by block in registers, contracted with alpha alpha^T - Ky^-1 and dK/dtheta from the inputs
+//                                                                                    (GPy: dL_dK = (alpha alpha^T - Ky^-1)/2)
+//   GPy's jitter ladder (jitchol: mean(diag) 1e-6 10^k, k = 0..4) around the evaluation
+//   L-BFGS on the Logexp-transformed parameters (lbfgs_core.hpp, lane 0)             (paramz: m.optimize())
+//
+// so cgp_optimize / cgp_optimize_batch / cgp_nll_grad of a window of N <= 160 samples are one launch and one copy
+// back.  fp64 only (the reference's arithmetic; RBF x Brownian on raw ticks is not a single-precision problem).
+//
+// Block storage: block (bi, bj), bi >= bj, at sm_tri(bi, bj); element (r, c) of a block at c * 17 + r.  The odd column
+// stride makes BOTH orientations of an MFMA operand read conflict-free (lanes along r: contiguous; lanes along c: stride
+// 17 doubles = 34 banks, sixteen distinct even banks), which is what lets the inverse and W^T W read blocks transposed.
+// fp64 v_mfma_f64_16x16x4: lane (l15 = lane & 15, lq = lane >> 4) supplies A[m = l15][k = 4 ks + lq], B[k = 4 ks + lq][n = l15]
+// and holds D[m = lq + 4 reg][n = l15] -- register `reg` of D is exactly the B operand of k-step `reg`, so products chain
+// in registers.
+#pragma once
+#include "cgp_kernels.hpp"
+#include "lbfgs_core.hpp"
+
+namespace cgp {
+
+constexpr int SM_MAX_NB = 10;              // block rows at most: windows of up to 160 samples
+constexpr int SM_MAX_N = SM_MAX_NB * DB;
+constexpr int SM_LD = DB + 1;
+constexpr int SM_BLK = DB * SM_LD;         // elements per block
+constexpr int SM_THREADS = 512;
+constexpr int SM_WAVES = SM_THREADS / 64;
+constexpr int SM_OUT = 32;                 // doubles per window in SmallArgs::out
+enum { SM_MODE_EVAL = 0, SM_MODE_OPT = 1 };
+// out[]: 0 logML (at theta / at the optimum), 1 evaluations, 2 L-BFGS status, 3 iterations, 4 info (first non-positive
+// pivot after the jitter ladder, 0 = ok), 5 jitter of the last evaluation, 8.. d(-logML)/dtheta (natural parameters)
+enum { SMO_LOGML = 0, SMO_EVALS = 1, SMO_STATUS = 2, SMO_ITERS = 3, SMO_INFO = 4, SMO_JITTER = 5, SMO_GRAD = 8 };
+
+__host__ __device__ __forceinline__ constexpr int sm_tri(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * SM_BLK; }
+
+struct SmallArgs {
+  const double *X;   // [windows][d][N]
+  const double *y;   // [windows][N]
+  double *theta;     // [windows][MAX_THETA] natural parameters: evaluation point (EVAL) / start in, optimum out (OPT)
+  double *out;       // [windows][SM_OUT]
+  int N, d, kernel_id, nth, mode, max_evals;
+  double pgtol, factr;
+};
+
+// dynamic LDS of k_small for a window of NB block rows and d input dimensions
+__host__ __device__ __forceinline__ constexpr size_t small_lds_bytes(int NB, int d) {
+  return sizeof(double) * ((size_t)NB * (NB + 1) / 2 * SM_BLK + (size_t)(d + 4) * NB * DB + SM_WAVES * GRAD_N + 64) +
+         sizeof(corenav::LbfgsCore) + 256;
+}
+
+struct SmallLds {
+  double *Bk;    // packed blocks
+  double *xr;    // [d][NP] raw inputs
+  double *yv, *zv, *al, *ldg;   // [NP] each: y, z = W y, alpha, diag(L)
+  double *red;   // [SM_WAVES][GRAD_N]
+  double *sc;    // 64 scalars: [0..9] theta, [10..17] 1/ell_q, 18 amp, 19 amp_b, 20 diag add, 21 jitter, 22 logML, 23 mean |x|,
+                 //             [24..35] gradient sums, 36 f, [40..49] gradient wrt x
+  corenav::LbfgsCore *lb;
+  int *flag;     // [0] first non-positive pivot of the running evaluation, [1] optimiser finished, [2] ladder attempt
+};
+
+// K_ij of two window points (no noise term); DQ: also the length-scaled squared differences the gradient needs
+template <bool DQ>
+__device__ __forceinline__ double sm_kval(const SmallLds &s, int kid, int d, int NP, int gi, int gj, const ExpC &ec, double (&dq2)[MAXD]) {
+  if (kid == K_RBF_BROWNIAN) {
+    // GPy: r^2 = -2 x x' + (x^2 + x'^2), clipped at 0, forced 0 on the diagonal; Brownian: sigma_b^2 min(|x|, |x'|) where the signs agree
+    const double x = s.xr[gi], xp = s.xr[gj];
+    double r2 = (gi == gj) ? 0.0 : (-2.0 * x * xp + (x * x + xp * xp));
+    r2 = r2 < 0.0 ? 0.0 : r2;
+    const double rr = __builtin_sqrt(r2) * s.sc[10];
+    const int sx = (x > 0.0) - (x < 0.0), sp = (xp > 0.0) - (xp < 0.0);
+    const double ax = __builtin_fabs(x), ap = __builtin_fabs(xp);
+    const double kb = (sx == sp) ? s.sc[19] * (ax < ap ? ax : ap) : 0.0;
+    if (DQ) {
+#pragma unroll
+      for (int q = 0; q < MAXD; ++q) dq2[q] = 0.0;
+      dq2[0] = rr * rr;
+    }
+    return s.sc[18] * exp_nonpos(-0.5 * rr * rr, ec) * kb;
+  }
+  double d2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < MAXD; ++q) {
+    double v = 0.0;
+    if (q < d) {
+      const double df = (s.xr[q * NP + gi] - s.xr[q * NP + gj]) * s.sc[10 + q];
+      v = df * df;
+    }
+    if (DQ) dq2[q] = v;
+    d2 += v;
+  }
+  return s.sc[18] * exp_nonpos(-0.5 * d2, ec);
+}
+
+// One evaluation at the natural parameters in s.sc[0..9] with jitter s.sc[21]: on return (after the final barrier)
+// s.flag[0] = first non-positive pivot (0 = positive definite), s.sc[22] = logML, s.sc[24..35] = gradient sums (k_grad's
+// layout: [0] amplitude, [1..8] length-scales, [9] noise).  Every thread of the workgroup calls it.
+__device__ __forceinline__ void sm_eval(const SmallLds &s, int kid, int d, int N, int NB, int tid) {
+  using P = Prec<double>;
+  using acc_t = P::acc_t;
+  const int NP = NB * DB, nblk = NB * (NB + 1) / 2;
+  const int lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double *Bk = s.Bk;
+  ExpC ec;
+  ec.load();
+  // ---- derived constants (every thread reads them from LDS afterwards)
+  if (tid == 0) {
+    const double *th = s.sc;
+    const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
+    for (int q = 0; q < MAXD; ++q) s.sc[10 + q] = q < d ? ((kid == K_SE_ARD) ? 1.0 / th[1 + q] : 1.0 / th[1]) : 0.0;
+    s.sc[18] = th[0];
+    s.sc[19] = (kid == K_RBF_BROWNIAN) ? th[2] : 0.0;
+    s.sc[20] = th[nth - 1] + 1e-8 + s.sc[21];
+    s.flag[0] = 0;
+  }
+  __syncthreads();
+  // ---- Gram: two blocks per pass, one entry per thread
+  {
+    const double diag_add = s.sc[20];
+    const int e = tid & 255, r = e & 15, c = e >> 4;
+    double dq2[MAXD];
+    for (int b0 = 0; b0 < nblk; b0 += 2) {
+      const int blk = b0 + (tid >> 8);
+      if (blk < nblk) {
+        int bi = 0, rem = blk;
+        while (rem > bi) {
+          rem -= bi + 1;
+          ++bi;
+        }
+        const int bj = rem, gi = bi * DB + r, gj = bj * DB + c;
+        double g;
+        if (gi < N && gj < N) {
+          g = sm_kval<false>(s, kid, d, NP, gi, gj, ec, dq2);
+          if (gi == gj) g += diag_add;
+        } else g = (gi == gj) ? 1.0 : 0.0;   // identity padding keeps the factor well defined
+        Bk[blk * SM_BLK + c * SM_LD + r] = g;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- Cholesky and W = L^-1 in place, organised around the one serial chain (the NB diagonal blocks on wave 0):
+  //   F(jb)  wave 0: factor + invert diagonal block jb in registers
+  //          the other waves, meanwhile: row jb-1 of W (W_ij = -Dinv_i sum_{j <= q < i} L_iq W_qj; kept in registers
+  //          until the barrier: it overwrites L_ij, which other blocks of the row still read) and the trailing update
+  //          with panel jb-1 of the block columns >= jb+1
+  //   P(jb)  panel L(i,jb) = A(i,jb) Dinv_jb^T;  U(jb)  update of block column jb+1 only with panel jb
+  // Wave 4 shares wave 0's SIMD and stays idle during F so the chain issues alone.
+  auto inverse_block = [&](int i, int j) -> acc_t {   // W(i, j), i > j, returned in the accumulator layout
+    acc_t t0 = acc_t{0, 0, 0, 0}, t1 = t0;
+    for (int q = j; q < i; ++q) {
+      const double *lb = Bk + sm_tri(i, q), *wb = Bk + sm_tri(q, j);
+      double fa[4], fb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        fa[ks] = lb[(4 * ks + lq) * SM_LD + l15];   // L(i,q)[m = l15][k]
+        fb[ks] = wb[l15 * SM_LD + 4 * ks + lq];     // W(q,j)[k][n = l15]  (q = j: Dinv_j)
+      }
+      if ((q - j) & 1) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) t1 = P::mfma(fa[ks], fb[ks], t1);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) t0 = P::mfma(fa[ks], fb[ks], t0);
+      }
+    }
+    const double *di = Bk + sm_tri(i, i);
+    double ga[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ga[ks] = -di[(4 * ks + lq) * SM_LD + l15];   // -Dinv_i[m = l15][k]
+    acc_t w = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w = P::mfma(ga[ks], t0[ks] + t1[ks], w);      // T's register ks IS the B operand of k-step ks
+    return w;
+  };
+  auto store_acc = [&](double *blk, const acc_t &a) {   // block[row = lq + 4 reg][col = l15]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) blk[l15 * SM_LD + lq + 4 * r] = a[r];
+  };
+  auto trailing_block = [&](int bi, int bj, int jp) {   // C(bi,bj) -= L(bi,jp) L(bj,jp)^T
+    double *cb = Bk + sm_tri(bi, bj);
+    const double *la = Bk + sm_tri(bj, jp), *lb = Bk + sm_tri(bi, jp);
+    acc_t acc;
+    double fa[4], fb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = cb[(lq + 4 * r) * SM_LD + l15];        // C[row = l15][col = lq + 4 r]
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fa[ks] = -la[(4 * ks + lq) * SM_LD + l15];
+      fb[ks] = lb[(4 * ks + lq) * SM_LD + l15];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cb[(lq + 4 * r) * SM_LD + l15] = acc[r];
+  };
+  constexpr int NH = SM_WAVES - 2;                       // helpers during F: every wave but 0 and its SIMD partner 4
+  const int helper = wave == 0 || wave == 4 ? -1 : (wave < 4 ? wave - 1 : wave - 2);
+  for (int jb = 0; jb < NB; ++jb) {
+    acc_t wres[2];
+    int wj[2] = {-1, -1};
+    if (wave == 0) {
+      double *dblk = Bk + sm_tri(jb, jb);
+      double a[DB], w[DB];
+      int bad = 0;
+#pragma unroll
+      for (int c = 0; c < DB; ++c) a[c] = dblk[c * SM_LD + l15];
+      factor_block16<double>(a, w, bad, jb * DB, l15, [&] {
+#pragma unroll
+        for (int c = 0; c < DB; ++c) a[c] = dblk[c * SM_LD + l15];
+      });
+      if (lane < DB) {
+        double dg = 1.0;
+#pragma unroll
+        for (int c = 0; c < DB; ++c) dg = (c == l15) ? a[c] : dg;
+        s.ldg[jb * DB + l15] = dg;
+#pragma unroll
+        for (int i = 0; i < DB; ++i) dblk[l15 * SM_LD + i] = w[i];   // Dinv_jb[i][l15] replaces the diagonal block
+      }
+      if (bad != 0 && lane == 0 && s.flag[0] == 0) s.flag[0] = bad;
+    } else if (helper >= 0 && jb > 0) {
+      const int jp = jb - 1, nb = NB - 1 - jb;
+      int it = 0;
+      for (int j = 0; j < jp; ++j, ++it)                 // row jp of W: the costliest items first
+        if (it % NH == helper) {
+          const int slot = wj[0] < 0 ? 0 : 1;
+          wres[slot] = inverse_block(jp, j);
+          wj[slot] = j;
+        }
+      for (int bi = jb + 1; bi < NB; ++bi)
+        for (int bj = jb + 1; bj <= bi; ++bj, ++it)
+          if (it % NH == helper) trailing_block(bi, bj, jp);
+      (void)nb;
+    }
+    lds_barrier();
+    if (wj[0] >= 0) store_acc(Bk + sm_tri(jb - 1, wj[0]), wres[0]);
+    if (wj[1] >= 0) store_acc(Bk + sm_tri(jb - 1, wj[1]), wres[1]);
+    // ---- P(jb)
+    for (int bi = jb + 1 + wave; bi < NB; bi += SM_WAVES) {
+      const double *dj = Bk + sm_tri(jb, jb);
+      double *ab = Bk + sm_tri(bi, jb);
+      double fa[4], fb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        fa[ks] = dj[(4 * ks + lq) * SM_LD + l15];        // Dinv_jb[m = l15][k]
+        fb[ks] = ab[(4 * ks + lq) * SM_LD + l15];        // A(bi,jb)[n = l15][k]
+      }
+      acc_t acc = acc_t{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ab[(lq + 4 * r) * SM_LD + l15] = acc[r];   // L(bi,jb)[row = l15][col = lq + 4 r]
+    }
+    lds_barrier();
+    // ---- U(jb): block column jb + 1
+    for (int bi = jb + 1 + wave; bi < NB; bi += SM_WAVES) trailing_block(bi, jb + 1, jb);
+    lds_barrier();
+  }
+  {  // the last row of W
+    acc_t wres[2];
+    int wj[2] = {-1, -1};
+    for (int j = wave; j < NB - 1; j += SM_WAVES) {
+      const int slot = wj[0] < 0 ? 0 : 1;
+      wres[slot] = inverse_block(NB - 1, j);
+      wj[slot] = j;
+    }
+    lds_barrier();
+    if (wj[0] >= 0) store_acc(Bk + sm_tri(NB - 1, wj[0]), wres[0]);
+    if (wj[1] >= 0) store_acc(Bk + sm_tri(NB - 1, wj[1]), wres[1]);
+  }
+  __syncthreads();
+
+  // ---- z = W y, alpha = W^T z, logML
+  if (tid < NP) {
+    const int bi = tid >> 4, r = tid & 15;
+    double z = 0.0;
+    for (int bj = 0; bj <= bi; ++bj) {
+      const double *wb = Bk + sm_tri(bi, bj) + r;
+#pragma unroll
+      for (int c = 0; c < DB; ++c) z = __builtin_fma(wb[c * SM_LD], s.yv[bj * DB + c], z);
+    }
+    s.zv[tid] = z;
+  }
+  __syncthreads();
+  double lsum = 0.0;
+  if (tid < NP) {
+    const int bj = tid >> 4, c = tid & 15;
+    double a = 0.0;
+    for (int bi = bj; bi < NB; ++bi) {
+      const double *wb = Bk + sm_tri(bi, bj) + c * SM_LD;
+#pragma unroll
+      for (int r = 0; r < DB; ++r) a = __builtin_fma(wb[r], s.zv[bi * DB + r], a);
+    }
+    s.al[tid] = a;
+    const double z = s.zv[tid];
+    lsum = -0.5 * z * z - (tid < N ? log(s.ldg[tid]) : 0.0);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+  if (lane == 0) s.red[wave * GRAD_N] = lsum;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < SM_WAVES; ++w) t += s.red[w * GRAD_N];
+    s.sc[22] = t - 0.5 * (double)N * 1.8378770664093453;
+  }
+  __syncthreads();
+
+  // ---- gradient sums: Ky^-1(bi,bj) = sum_{k >= bi} W(k,bi)^T W(k,bj) in registers, contracted on the spot
+  double s_amp = 0.0, s_noise = 0.0, s_ell[MAXD];
+#pragma unroll
+  for (int q = 0; q < MAXD; ++q) s_ell[q] = 0.0;
+  for (int blk = wave; blk < nblk; blk += SM_WAVES) {
+    int bi = 0, rem = blk;
+    while (rem > bi) {
+      rem -= bi + 1;
+      ++bi;
+    }
+    const int bj = rem;
+    acc_t a0 = acc_t{0, 0, 0, 0}, a1 = a0;
+    for (int k = bi; k < NB; ++k) {
+      const double *wa = Bk + sm_tri(k, bi), *wb = Bk + sm_tri(k, bj);
+      double fa[4], fb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        fa[ks] = wa[l15 * SM_LD + 4 * ks + lq];   // W(k,bi)[kk][m = l15]
+        fb[ks] = wb[l15 * SM_LD + 4 * ks + lq];   // W(k,bj)[kk][n = l15]
+      }
+      if ((k - bi) & 1) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a1 = P::mfma(fa[ks], fb[ks], a1);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a0 = P::mfma(fa[ks], fb[ks], a0);
+      }
+    }
+    const double wgt = (bi == bj) ? 1.0 : 2.0;
+    const int gj = bj * DB + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = bi * DB + lq + 4 * r;
+      if (gi < N && gj < N) {
+        double dq2[MAXD];
+        const double kv = sm_kval<true>(s, kid, d, NP, gi, gj, ec, dq2);
+        const double w = s.al[gi] * s.al[gj] - (a0[r] + a1[r]);
+        const double wk = wgt * w * kv;
+        s_amp += wk;
+#pragma unroll
+        for (int q = 0; q < MAXD; ++q) s_ell[q] += wk * dq2[q];
+        if (gi == gj) s_noise += w;
+      }
+    }
+  }
+  {
+    double vals[GRAD_N];
+    vals[0] = s_amp;
+#pragma unroll
+    for (int q = 0; q < MAXD; ++q) vals[1 + q] = s_ell[q];
+    vals[9] = s_noise;
+    vals[10] = vals[11] = 0.0;
+#pragma unroll
+    for (int i = 0; i < GRAD_N; ++i) {
+      double v = vals[i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) s.red[wave * GRAD_N + i] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < GRAD_N) {
+    double t = 0.0;
+    for (int w = 0; w < SM_WAVES; ++w) t += s.red[w * GRAD_N + tid];   // fixed order
+    s.sc[24 + tid] = t;
+  }
+  __syncthreads();
+}
+
+// d(-logML)/dtheta (natural parameters) from the sums; the host twin is grad_from_sums (cgp_engine.hip)
+__device__ __forceinline__ void sm_grad_from_sums(int kid, int d, const double *theta, const double *sums, double *grad) {
+  if (kid == K_SE_ISO) {
+    double se = 0;
+    for (int q = 0; q < d; ++q) se += sums[1 + q];
+    grad[0] = -0.5 * sums[0] / theta[0];
+    grad[1] = -0.5 * se / theta[1];
+    grad[2] = -0.5 * sums[9];
+  } else if (kid == K_SE_ARD) {
+    grad[0] = -0.5 * sums[0] / theta[0];
+    for (int q = 0; q < d; ++q) grad[1 + q] = -0.5 * sums[1 + q] / theta[1 + q];
+    grad[d + 1] = -0.5 * sums[9];
+  } else {
+    grad[0] = -0.5 * sums[0] / theta[0];
+    grad[1] = -0.5 * sums[1] / theta[1];
+    grad[2] = -0.5 * sums[0] / theta[2];
+    grad[3] = -0.5 * sums[9];
+  }
+}
+
+__global__ __launch_bounds__(SM_THREADS) void k_small(SmallArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int N = p.N, d = p.d, kid = p.kernel_id, nth = p.nth;
+  const int NB = (N + DB - 1) / DB, NP = NB * DB;
+  SmallLds s;
+  s.Bk = reinterpret_cast<double *>(smem_raw);
+  s.xr = s.Bk + (size_t)NB * (NB + 1) / 2 * SM_BLK;
+  s.yv = s.xr + (size_t)d * NP;
+  s.zv = s.yv + NP;
+  s.al = s.zv + NP;
+  s.ldg = s.al + NP;
+  s.red = s.ldg + NP;
+  s.sc = s.red + SM_WAVES * GRAD_N;
+  s.lb = reinterpret_cast<corenav::LbfgsCore *>(s.sc + 64);
+  s.flag = reinterpret_cast<int *>(reinterpret_cast<char *>(s.lb) + sizeof(corenav::LbfgsCore));
+  const double *Xb = p.X + (size_t)b * d * N, *yb = p.y + (size_t)b * N;
+  double *thb = p.theta + (size_t)b * MAX_THETA, *ob = p.out + (size_t)b * SM_OUT;
+  for (int i = tid; i < d * NP; i += SM_THREADS) {
+    const int q = i / NP, r = i - q * NP;
+    s.xr[i] = r < N ? Xb[(size_t)q * N + r] : 0.0;
+  }
+  for (int i = tid; i < NP; i += SM_THREADS) s.yv[i] = i < N ? yb[i] : 0.0;
+  __syncthreads();
+  // Logexp (GPy paramz.transformations.Logexp): theta = log(1 + exp(x))
+  auto to_theta = [](double x) { return x > 35.0 ? x : log1p(exp(x)); };
+  auto to_x = [](double th) { return th > 35.0 ? th : log(expm1(th)); };
+  if (tid == 0) {
+    double sa = 0.0;   // mean |x| of the first input: jitchol's mean(diag) for the Brownian factor
+    for (int i = 0; i < N; ++i) sa += fabs(s.xr[i]);
+    s.sc[23] = sa / (double)N;
+    s.flag[1] = 0;
+    if (p.mode == SM_MODE_OPT) {
+      double x0[corenav::LB_N];
+      for (int i = 0; i < nth; ++i) x0[i] = to_x(thb[i]);
+      s.lb->init(x0, nth, p.max_evals, p.pgtol, p.factr);
+    }
+  }
+  __syncthreads();
+  const int max_rounds = p.mode == SM_MODE_OPT ? p.max_evals + 64 : 1;
+  for (int round = 0; round < max_rounds; ++round) {
+    if (tid == 0) {
+      for (int i = 0; i < MAX_THETA; ++i) {
+        double th = 0.0;
+        if (i < nth) th = p.mode == SM_MODE_OPT ? fmax(to_theta(s.lb->xn[i]), 1e-300) : thb[i];
+        s.sc[i] = th;
+      }
+      s.sc[21] = 0.0;
+      s.flag[2] = 0;
+    }
+    __syncthreads();
+    // GPy jitchol: retry a matrix that is not positive definite with jitter mean(diag) 1e-6 10^k, k = 0..4
+    for (;;) {
+      sm_eval(s, kid, d, N, NB, tid);
+      const int bad = s.flag[0];
+      const int attempt = s.flag[2];
+      if (bad == 0 || attempt >= 5) break;
+      __syncthreads();
+      if (tid == 0) {
+        const double noise = s.sc[nth - 1] + 1e-8;
+        const double md = kid == K_RBF_BROWNIAN ? s.sc[0] * s.sc[2] * s.sc[23] + noise : s.sc[0] + noise;
+        s.sc[21] = attempt == 0 ? md * 1e-6 : s.sc[21] * 10.0;
+        s.flag[2] = attempt + 1;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const bool ok = s.flag[0] == 0;
+      double g[MAX_THETA];
+      for (int i = 0; i < MAX_THETA; ++i) g[i] = 0.0;
+      if (ok) sm_grad_from_sums(kid, d, s.sc, s.sc + 24, g);
+      if (p.mode == SM_MODE_OPT) {
+        double gx[corenav::LB_N];
+        for (int i = 0; i < nth; ++i) gx[i] = g[i] * (s.lb->xn[i] > 35.0 ? 1.0 : -expm1(-s.sc[i]));   // dtheta/dx = 1 - exp(-theta)
+        s.lb->tell(ok ? -s.sc[22] : INFINITY, gx);
+        s.flag[1] = s.lb->done() ? 1 : 0;
+      } else {
+        ob[SMO_LOGML] = s.sc[22];
+        ob[SMO_EVALS] = 1.0;
+        ob[SMO_STATUS] = 0.0;
+        ob[SMO_ITERS] = 0.0;
+        ob[SMO_INFO] = (double)s.flag[0];
+        ob[SMO_JITTER] = ok ? s.sc[21] : 0.0;
+        for (int i = 0; i < MAX_THETA; ++i) ob[SMO_GRAD + i] = g[i];
+        s.flag[1] = 1;
+      }
+    }
+    __syncthreads();
+    if (s.flag[1]) break;
+  }
+  if (tid == 0 && p.mode == SM_MODE_OPT) {
+    const corenav::LbfgsCore &lb = *s.lb;
+    for (int i = 0; i < MAX_THETA; ++i) thb[i] = i < nth ? to_theta(lb.x[i]) : 0.0;
+    ob[SMO_LOGML] = -lb.f;
+    ob[SMO_EVALS] = (double)lb.evals;
+    ob[SMO_STATUS] = (double)(lb.done() ? lb.status : 2);
+    ob[SMO_ITERS] = (double)lb.iters;
+    ob[SMO_INFO] = __builtin_isfinite(lb.f) ? 0.0 : 1.0;
+    ob[SMO_JITTER] = 0.0;
+    for (int i = 0; i < MAX_THETA; ++i) ob[SMO_GRAD + i] = i < nth ? lb.g[i] : 0.0;   // wrt x, at the optimum
+  }
+}
+
+}  // namespace cgp

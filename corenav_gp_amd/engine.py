@@ -63,6 +63,7 @@ _SIGS = {
     "cgp_window_state": (ctypes.c_int, [_vp, ctypes.c_int, _ip, _ip]),
     "cgp_set_streams": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cgp_debug_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong)]),
+    "cgp_debug_buffers": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_ulonglong)]),
     "cgp_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cgp_profile_read": (ctypes.c_int, [_vp, _dp, _dp, ctypes.POINTER(ctypes.c_longlong)]),
     "cgp_llh_to_enu": (ctypes.c_int, [ctypes.c_double] * 3 + [_dp, _dp, _dp]),
@@ -319,6 +320,12 @@ class Context:
         out = np.zeros(DEBUG_SLOTS, dtype=np.int64)
         self._chk(self.lib.cgp_debug_read(self.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
         return out
+
+    def debug_buffers(self):
+        """[(address, bytes)] of the context's large device buffers (include/corenav_gp.h: cgp_debug_buffers)."""
+        out = np.zeros(16, dtype=np.uint64)
+        self._chk(self.lib.cgp_debug_buffers(self.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong))))
+        return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(8)]
 
     def set_streams(self, n):
         self._chk(self.lib.cgp_set_streams(self.h, int(n)))

@@ -196,6 +196,12 @@ int cgp_set_streams(cgp_ctx *ctx, int n);
  * over all workgroups, slot 7 of each group = workgroup count (CGP_DBG & 1024).  Reading resets them. */
 #define CGP_DEBUG_SLOTS 512
 int cgp_debug_read(cgp_ctx *ctx, long long out[CGP_DEBUG_SLOTS]);
+/* Development aid: device addresses and byte sizes of the context's large buffers, as pairs
+ * out[2 i] = address, out[2 i + 1] = bytes for i = 0 factor panels (Lw), 1 W images (Winv), 2 diagonal-tile images,
+ * 3 panel-tile images, 4 inputs X, 5 running predictive sums, 6 latency partial tiles, 7 latency images
+ * (tools/ctx_placement.py prints them next to the timings of a context). */
+#define CGP_DEBUG_BUFFERS 8
+int cgp_debug_buffers(cgp_ctx *ctx, unsigned long long out[2 * CGP_DEBUG_BUFFERS]);
 
 /* ---- online sliding-window GP (BASELINE configs[3]; not reference behaviour) -------------------
  * `nwin` independent windows of at most N samples each live on the device.  cgp_window_push feeds
