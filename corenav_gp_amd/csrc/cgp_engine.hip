@@ -6,6 +6,7 @@
 #include "cgp_kernels_fused.hpp"
 #include "cgp_window.hpp"
 #include "cgp_lookahead.hpp"
+#include "cgp_small.hpp"
 #include "gp_predictor_core.hpp"
 #include "gp_predictor.h"
 #include "lbfgs.hpp"
@@ -26,6 +27,7 @@ using namespace cgp;
 static_assert(CGP_MAX_D == MAXD, "header / kernel MAXD mismatch");
 static_assert(CGP_DEBUG_SLOTS == DBG_SLOTS, "header / kernel debug slot mismatch");
 static_assert(CGP_MAX_THETA == MAX_THETA, "header / kernel MAX_THETA mismatch");
+static_assert(CGP_SMALL_OUT == SM_OUT, "header / kernel short-window record mismatch");
 
 namespace {
 
@@ -91,9 +93,13 @@ struct cgp_ctx {
   void *opt_pin = nullptr;
   size_t opt_pin_cap = 0;
   int *dinfo = nullptr;
+  double *dsmall = nullptr;   // [max_batch][SM_OUT] results of the one-launch short-window kernel (k_small, fp64 contexts)
   size_t lw_stride = 0, winv_stride = 0, alpha_stride = 0;
   // state of the last single fit (cgp_fit -> cgp_predict)
   bool have_fit = false;
+  bool lazy_fit = false;      // the window, theta and jitter of the last short-window evaluation are on the device but the factor
+                              // panel is not: cgp_predict / cgp_get_alpha / cgp_get_factor run the fit schedule first (ensure_fitted)
+  double f_meandiag_x = 0.0;  // mean |x| of that window's first input (GPy jitchol's mean(diag) for the Brownian factor)
   int fN = 0, fd = 0, fkernel = 0;
   double ftheta[CGP_MAX_THETA] = {0};
   double fjitter = 0.0;
@@ -108,6 +114,8 @@ struct cgp_ctx {
 };
 
 namespace {
+
+int ensure_fitted(cgp_ctx *c);   // below, with the short-window paths
 
 inline int ntheta(int kid, int d) { return kid == CGP_KERNEL_SE_ISO ? 3 : (kid == CGP_KERNEL_SE_ARD ? d + 2 : 4); }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -249,6 +257,25 @@ template <typename T> int set_lds_attrs(int device) {
   ok = ok && set(reinterpret_cast<const void *>(&k_diag<T>), tile);
 #endif
   if (!ok) return -1;
+  if (device >= 0 && device < 64) done[device] = true;
+  return 0;
+}
+
+// k_small<BROWN, DMAX>: the reference's kernel, and SE kernels compiled for d <= 1 / 3 / 8 (the smallest that fits is launched)
+template <typename F> int for_each_small_kernel(F &&f) {
+  int rc = f(reinterpret_cast<const void *>(&k_small<true, 1>));
+  if (rc == 0) rc = f(reinterpret_cast<const void *>(&k_small<false, 1>));
+  if (rc == 0) rc = f(reinterpret_cast<const void *>(&k_small<false, 3>));
+  if (rc == 0) rc = f(reinterpret_cast<const void *>(&k_small<false, 8>));
+  return rc;
+}
+int set_small_attr(int device) {
+  static bool done[64] = {false};
+  if (device >= 0 && device < 64 && done[device]) return 0;
+  const int rc = for_each_small_kernel([](const void *fn) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(SM_MAX_NB, MAXD)) == hipSuccess ? 0 : -1;
+  });
+  if (rc != 0) return -1;
   if (device >= 0 && device < 64) done[device] = true;
   return 0;
 }
@@ -798,6 +825,10 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc((void **)&c->dprep, B * PREP_N * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dlogml, B * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dinfo, B * sizeof(int)) == hipSuccess;
+  if (dtype == CGP_F64) {
+    ok = ok && hipMalloc((void **)&c->dsmall, B * SM_OUT * sizeof(double)) == hipSuccess;
+    ok = ok && set_small_attr(device) == 0;
+  }
   if (!ok) {
     cgp_destroy(c);
     return nullptr;
@@ -814,7 +845,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg, c->dpanimg};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg, c->dpanimg, c->dsmall};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {
@@ -864,6 +895,15 @@ int cgp_debug_buffers(cgp_ctx *c, unsigned long long out[2 * CGP_DEBUG_BUFFERS])
     out[2 * i] = (unsigned long long)(uintptr_t)p[i];
     out[2 * i + 1] = n[i];
   }
+  return CGP_OK;
+}
+
+int cgp_debug_small(cgp_ctx *c, double out[CGP_SMALL_OUT]) {
+  if (!c || !out) return CGP_EINVAL;
+  if (!c->dsmall) return CGP_ESTATE;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());
+  HIP_TRY(c, hipMemcpy(out, c->dsmall, SM_OUT * sizeof(double), hipMemcpyDeviceToHost));
   return CGP_OK;
 }
 
@@ -944,6 +984,7 @@ int cgp_fit_predict_batch_device(cgp_ctx *c, int batch, int N, int d, int M, int
   a.logml = dlogml;
   a.info = dinfo;
   c->have_fit = false;
+  c->lazy_fit = false;
   return run(c, a, batch, true, false, pick_stream(c, hip_stream));
 }
 
@@ -1131,6 +1172,7 @@ int cgp_predict(cgp_ctx *c, const double *Xs, int M, int include_noise, double *
   if (!c->have_fit) return CGP_ESTATE;
   if (M > c->max_m) return CGP_ECAPACITY;
   HIP_TRY(c, hipSetDevice(c->device));
+  if (int fr = ensure_fitted(c)) return fr;
   hipStream_t s = c->stream;
   const size_t esz = c->esz;
   std::vector<char> hxs((size_t)c->fd * M * esz);
@@ -1161,6 +1203,7 @@ int cgp_get_alpha(cgp_ctx *c, double *alpha) {
   if (!c || !alpha) return CGP_EINVAL;
   if (!c->have_fit) return CGP_ESTATE;
   HIP_TRY(c, hipSetDevice(c->device));
+  if (int fr = ensure_fitted(c)) return fr;
   hipStream_t s = c->stream;
   // z is the y row of the factor panel; it sits at extra row index M of the LAST run.  Re-run the
   // y row alone (M = 0) so its position is known, then back-substitute.
@@ -1187,6 +1230,7 @@ int cgp_get_factor(cgp_ctx *c, double *L) {
   if (!c || !L) return CGP_EINVAL;
   if (!c->have_fit) return CGP_ESTATE;
   HIP_TRY(c, hipSetDevice(c->device));
+  if (int fr = ensure_fitted(c)) return fr;
   const int N = c->fN;
   std::vector<char> h((size_t)N * N * c->esz);
   // columns 0..N-1, rows 0..N-1 of the column-major panel -> dense (N x N) column-major staging
@@ -1373,12 +1417,166 @@ int nll_grad_resident(cgp_ctx *c, const double *X, int N, int d, int kid, const 
 }
 }  // namespace
 
+
+// ---- short windows (N <= SM_MAX_N, fp64): one launch per evaluation / per whole optimisation (cgp_small.hpp) -------------
+namespace {
+bool small_enabled() {   // CGP_SMALL=off: the large-window machinery for every size (A/B, and the tests that cover it at small N)
+  static const bool off = [] {
+    const char *e = getenv("CGP_SMALL");
+    return e && std::string(e) == "off";
+  }();
+  return !off;
+}
+inline bool small_ok(const cgp_ctx *c, int N) { return c->dtype == CGP_F64 && N <= SM_MAX_N && c->dsmall && small_enabled(); }
+
+double mean_abs_first(const double *X, int N, int d) {
+  double s = 0;
+  for (int i = 0; i < N; ++i) s += std::fabs(X[(size_t)i * d]);
+  return s / N;
+}
+double mean_diag_from(int kid, const double *theta, int d, double meanabs) {   // mean_diag with the window's mean |x| precomputed
+  const double noise = theta[ntheta(kid, d) - 1] + 1e-8;
+  return kid == CGP_KERNEL_RBF_BROWNIAN ? theta[0] * theta[2] * meanabs + noise : theta[0] + noise;
+}
+
+// ONE window (X (N, d) row-major, y, theta) to slot 0: staged in the pinned block, one H2D, one unpack launch
+int small_stage_window(cgp_ctx *c, const double *X, const double *y, int N, int d, const double *theta, int nth, hipStream_t s) {
+  const size_t nX = (size_t)N * d, in_bytes = (nX + N + CGP_MAX_THETA) * sizeof(double);
+  if (!grow_pinned(c->pin_in, c->pin_in_cap, in_bytes) || !grow_device(c->draw, c->draw_cap, in_bytes)) return CGP_ENOMEM;
+  double *hin = static_cast<double *>(c->pin_in);
+  memcpy(hin, X, nX * sizeof(double));
+  memcpy(hin + nX, y, (size_t)N * sizeof(double));
+  for (int q = 0; q < CGP_MAX_THETA; ++q) hin[nX + N + q] = q < nth ? theta[q] : 0.0;
+  HIP_TRY(c, hipMemcpyAsync(c->draw, hin, in_bytes, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_pack_call<double>, dim3(std::min(64, cdiv(N * d, 256)), 1), dim3(256), 0, s, static_cast<const double *>(c->draw),
+                     static_cast<double *>(c->dX), static_cast<double *>(c->dy), static_cast<double *>(c->dXs), c->dtheta, c->djitter, 1, N, d, 0);
+  return CGP_OK;
+}
+
+int small_launch(cgp_ctx *c, int batch, int N, int d, int kid, int mode, int max_evals, hipStream_t s) {
+  SmallArgs a{};
+  a.X = static_cast<const double *>(c->dX);
+  a.y = static_cast<const double *>(c->dy);
+  a.theta = c->dtheta;
+  a.out = c->dsmall;
+  a.N = N;
+  a.d = d;
+  a.kernel_id = kid;
+  a.nth = ntheta(kid, d);
+  a.mode = mode;
+  a.max_evals = max_evals > 0 ? max_evals : 1000;
+  a.pgtol = 1e-5;   // scipy fmin_l_bfgs_b as paramz calls it: pgtol 1e-5, factr 1e7
+  a.factr = 1e7;
+  const size_t lds = small_lds_bytes(cdiv(N, DB), d);
+  if (kid == CGP_KERNEL_RBF_BROWNIAN) hipLaunchKernelGGL((k_small<true, 1>), dim3(batch), dim3(SM_THREADS), lds, s, a);
+  else if (d <= 1) hipLaunchKernelGGL((k_small<false, 1>), dim3(batch), dim3(SM_THREADS), lds, s, a);
+  else if (d <= 3) hipLaunchKernelGGL((k_small<false, 3>), dim3(batch), dim3(SM_THREADS), lds, s, a);
+  else hipLaunchKernelGGL((k_small<false, 8>), dim3(batch), dim3(SM_THREADS), lds, s, a);
+  HIP_TRY(c, hipGetLastError());
+  return CGP_OK;
+}
+
+// results of slot 0 -> the pinned block (behind its input part) -> host; one synchronisation
+int small_read_one(cgp_ctx *c, double out[SM_OUT], hipStream_t s) {
+  if (!grow_pinned(c->opt_pin, c->opt_pin_cap, (kOptPinIn + 64 + SM_OUT) * sizeof(double))) return CGP_ENOMEM;
+  double *h = static_cast<double *>(c->opt_pin) + kOptPinIn;
+  HIP_TRY(c, hipMemcpyAsync(h, c->dsmall, SM_OUT * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  memcpy(out, h, SM_OUT * sizeof(double));
+  return CGP_OK;
+}
+
+void small_mark_fitted(cgp_ctx *c, const double *X, int N, int d, int kid, const double *theta, double jitter, bool ok) {
+  c->have_fit = ok;
+  c->lazy_fit = ok;
+  c->f_meandiag_x = mean_abs_first(X, N, d);
+  c->fjitter = ok ? jitter : 0.0;
+  c->fN = N;
+  c->fd = d;
+  c->fkernel = kid;
+  memcpy(c->ftheta, theta, sizeof(double) * ntheta(kid, d));
+}
+
+// cgp_predict / cgp_get_alpha / cgp_get_factor after a short-window evaluation: the window, theta (and the jitter the
+// evaluation needed) are on the device, the factor panel is not -- run the fit schedule once, GPy's jitter ladder around it
+int ensure_fitted(cgp_ctx *c) {
+  if (!c->lazy_fit) return CGP_OK;
+  c->lazy_fit = false;
+  hipStream_t s = c->stream;
+  FitArgs a = base_args(c, c->fN, c->fd, 0, c->fkernel, 0);
+  a.X = c->dX;
+  a.Xs = c->dXs;
+  a.y = c->dy;
+  a.theta = c->dtheta;
+  a.jitter = c->djitter;
+  a.mean = c->dmean;
+  a.var = c->dvar;
+  a.logml = c->dlogml;
+  a.info = c->dinfo;
+  double jit = c->fjitter;
+  int info = 0;
+  for (int attempt = 0; attempt <= 5; ++attempt) {
+    HIP_TRY(c, hipMemcpyAsync(c->djitter, &jit, sizeof(double), hipMemcpyHostToDevice, s));
+    int rc = run(c, a, 1, true, false, s);
+    if (rc != CGP_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(&info, c->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (info == 0) break;
+    jit = jit == 0.0 ? mean_diag_from(c->fkernel, c->ftheta, c->fd, c->f_meandiag_x) * 1e-6 : jit * 10.0;
+  }
+  c->have_fit = info == 0;
+  c->fjitter = info == 0 ? jit : 0.0;
+  return info;
+}
+
+int small_nll_grad(cgp_ctx *c, const double *X, const double *y, int N, int d, int kid, const double *theta, double *nll, double *grad) {
+  hipStream_t s = c->stream;
+  const int nth = ntheta(kid, d);
+  int rc = small_stage_window(c, X, y, N, d, theta, nth, s);
+  if (rc == CGP_OK) rc = small_launch(c, 1, N, d, kid, SM_MODE_EVAL, 1, s);
+  double out[SM_OUT];
+  if (rc == CGP_OK) rc = small_read_one(c, out, s);
+  if (rc != CGP_OK) return rc;
+  const int info = (int)out[SMO_INFO];
+  small_mark_fitted(c, X, N, d, kid, theta, out[SMO_JITTER], info == 0);
+  if (info != 0) return info;
+  *nll = -out[SMO_LOGML];
+  for (int i = 0; i < nth; ++i) grad[i] = out[SMO_GRAD + i];
+  return CGP_OK;
+}
+
+// m.optimize() of ONE short window: stage, one launch (the L-BFGS loop runs on the device), one copy back
+int small_optimize(cgp_ctx *c, const double *X, const double *y, int N, int d, int kid, double *theta, int max_evals, double *logml,
+                   int *n_evals) {
+  hipStream_t s = c->stream;
+  const int nth = ntheta(kid, d);
+  for (int i = 0; i < nth; ++i)
+    if (!(theta[i] > 0.0)) return CGP_EINVAL;
+  int rc = small_stage_window(c, X, y, N, d, theta, nth, s);
+  if (rc == CGP_OK) rc = small_launch(c, 1, N, d, kid, SM_MODE_OPT, max_evals, s);
+  double out[SM_OUT];
+  if (rc == CGP_OK) rc = small_read_one(c, out, s);
+  if (rc != CGP_OK) return rc;
+  if (out[SMO_INFO] != 0.0) {   // the start itself is not positive definite even with the jitter ladder
+    c->have_fit = false;
+    return 1;
+  }
+  for (int i = 0; i < nth; ++i) theta[i] = out[SMO_THETA + i];
+  small_mark_fitted(c, X, N, d, kid, theta, 0.0, true);
+  if (logml) *logml = out[SMO_LOGML];
+  if (n_evals) *n_evals = (int)out[SMO_EVALS];
+  return CGP_OK;
+}
+}  // namespace
+
 extern "C" int cgp_nll_grad(cgp_ctx *c, const double *X, const double *y, int N, int d, int kid, const double *theta,
                             double *nll, double *grad) {
   int rc = check_shape(c, 1, N, d, N, kid);
   if (rc != CGP_OK) return rc;
   if (!X || !y || !theta || !nll || !grad) return CGP_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
+  if (small_ok(c, N)) return small_nll_grad(c, X, y, N, d, kid, theta, nll, grad);
+  c->lazy_fit = false;
   rc = upload_window(c, X, y, N, d, c->stream);
   if (rc != CGP_OK) return rc;
   return nll_grad_resident(c, X, N, d, kid, theta, nll, grad);
@@ -1400,6 +1598,8 @@ extern "C" int cgp_optimize(cgp_ctx *c, const double *X, const double *y, int N,
   }
   int hard_error = CGP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
+  if (small_ok(c, N)) return small_optimize(c, X, y, N, d, kid, theta, max_evals, logml, n_evals);
+  c->lazy_fit = false;
   rc = upload_window(c, X, y, N, d, c->stream);   // the window does not change between evaluations: only theta travels
   if (rc != CGP_OK) return rc;
   auto fg = [&](const std::vector<double> &xx, std::vector<double> &gx) -> double {
@@ -1827,6 +2027,28 @@ extern "C" int cgp_optimize_batch(cgp_ctx *c, int batch, int N, int d, int kid, 
   }
   HIP_TRY(c, hipMemcpyAsync(c->dX, hx.data(), hx.size(), hipMemcpyHostToDevice, s));
   HIP_TRY(c, hipMemcpyAsync(c->dy, hy.data(), hy.size(), hipMemcpyHostToDevice, s));
+  c->lazy_fit = false;
+  if (small_ok(c, N)) {
+    // short windows: ONE launch, one workgroup per window, each running its own L-BFGS loop on the device (cgp_small.hpp)
+    for (int b = 0; b < batch; ++b)
+      for (int i = 0; i < nth; ++i)
+        if (!(theta[(size_t)b * theta_stride + i] > 0.0)) return CGP_EINVAL;
+    std::vector<double> hth;
+    rc = upload_theta(c, theta, theta_stride, nth, batch, s, hth);
+    if (rc == CGP_OK) rc = small_launch(c, batch, N, d, kid, SM_MODE_OPT, max_evals, s);
+    if (rc != CGP_OK) return rc;
+    std::vector<double> out((size_t)batch * SM_OUT);
+    HIP_TRY(c, hipMemcpyAsync(out.data(), c->dsmall, out.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->have_fit = false;
+    for (int b = 0; b < batch; ++b) {
+      const double *ob = out.data() + (size_t)b * SM_OUT;
+      for (int i = 0; i < nth; ++i) theta[(size_t)b * theta_stride + i] = ob[SMO_THETA + i];
+      if (logml_out) logml_out[b] = ob[SMO_LOGML];
+      if (n_evals) n_evals[b] = (int)ob[SMO_EVALS];
+    }
+    return CGP_OK;
+  }
   auto to_theta = [](double x) { return x > 35.0 ? x : std::log1p(std::exp(x)); };
   auto to_x = [](double th) { return th > 35.0 ? th : std::log(std::expm1(th)); };
   std::vector<corenav::LbfgsStepper> st;

@@ -37,11 +37,14 @@ constexpr int SM_LD = DB + 1;
 constexpr int SM_BLK = DB * SM_LD;         // elements per block
 constexpr int SM_THREADS = 512;
 constexpr int SM_WAVES = SM_THREADS / 64;
-constexpr int SM_OUT = 32;                 // doubles per window in SmallArgs::out
+constexpr int SM_NH = SM_WAVES - 2;        // helper waves beside the factor chain (every wave but 0 and its SIMD partner 4)
+constexpr int SM_DEAL = 12;                // entries of a helper's work list: count + at most 11 items
+constexpr int SM_OUT = 48;                 // doubles per window in SmallArgs::out ([32, 48): phase clocks of a -DCGP_ABLATION build)
 enum { SM_MODE_EVAL = 0, SM_MODE_OPT = 1 };
 // out[]: 0 logML (at theta / at the optimum), 1 evaluations, 2 L-BFGS status, 3 iterations, 4 info (first non-positive
-// pivot after the jitter ladder, 0 = ok), 5 jitter of the last evaluation, 8.. d(-logML)/dtheta (natural parameters)
-enum { SMO_LOGML = 0, SMO_EVALS = 1, SMO_STATUS = 2, SMO_ITERS = 3, SMO_INFO = 4, SMO_JITTER = 5, SMO_GRAD = 8 };
+// pivot after the jitter ladder, 0 = ok), 5 jitter of the last evaluation, 8.. d(-logML)/dtheta (natural parameters; OPT: wrt
+// the Logexp variables, at the optimum), 20.. theta (OPT: the optimum)
+enum { SMO_LOGML = 0, SMO_EVALS = 1, SMO_STATUS = 2, SMO_ITERS = 3, SMO_INFO = 4, SMO_JITTER = 5, SMO_GRAD = 8, SMO_THETA = 20 };
 
 __host__ __device__ __forceinline__ constexpr int sm_tri(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * SM_BLK; }
 
@@ -56,58 +59,109 @@ struct SmallArgs {
 
 // dynamic LDS of k_small for a window of NB block rows and d input dimensions
 __host__ __device__ __forceinline__ constexpr size_t small_lds_bytes(int NB, int d) {
-  return sizeof(double) * ((size_t)NB * (NB + 1) / 2 * SM_BLK + (size_t)(d + 4) * NB * DB + SM_WAVES * GRAD_N + 64) +
-         sizeof(corenav::LbfgsCore) + 256;
+  return sizeof(double) * ((size_t)NB * (NB + 1) / 2 * SM_BLK + (size_t)(d + 7) * NB * DB + SM_WAVES * GRAD_N + 64) +
+         sizeof(corenav::LbfgsCore) + sizeof(int) * (8 + NB * (NB + 1) / 2) + 2 * (size_t)NB * SM_NH * SM_DEAL + 64;
 }
 
 struct SmallLds {
   double *Bk;    // packed blocks
   double *xr;    // [d][NP] raw inputs
   double *yv, *zv, *al, *ldg;   // [NP] each: y, z = W y, alpha, diag(L)
-  double *red;   // [SM_WAVES][GRAD_N]
+  double *tmp;   // [3][NP] partial sums of z / alpha
+  double *red;   // [SM_WAVES][GRAD_N] reductions; between evaluations lane 0's gradient vectors
   double *sc;    // 64 scalars: [0..9] theta, [10..17] 1/ell_q, 18 amp, 19 amp_b, 20 diag add, 21 jitter, 22 logML, 23 mean |x|,
-                 //             [24..35] gradient sums, 36 f, [40..49] gradient wrt x
+                 //             [24..35] gradient sums, [36..45] dtheta/dx of the Logexp transform, [48..63] phase clocks
   corenav::LbfgsCore *lb;
   int *flag;     // [0] first non-positive pivot of the running evaluation, [1] optimiser finished, [2] ladder attempt
+  int *tb;       // [blocks] packed block index -> block row | block column << 8
+  unsigned short *deal;   // [NB][SM_NH][SM_DEAL] helper work lists (sm_build_deal)
 };
 
-// K_ij of two window points (no noise term); DQ: also the length-scaled squared differences the gradient needs
-template <bool DQ>
-__device__ __forceinline__ double sm_kval(const SmallLds &s, int kid, int d, int NP, int gi, int gj, const ExpC &ec, double (&dq2)[MAXD]) {
-  if (kid == K_RBF_BROWNIAN) {
-    // GPy: r^2 = -2 x x' + (x^2 + x'^2), clipped at 0, forced 0 on the diagonal; Brownian: sigma_b^2 min(|x|, |x'|) where the signs agree
-    const double x = s.xr[gi], xp = s.xr[gj];
-    double r2 = (gi == gj) ? 0.0 : (-2.0 * x * xp + (x * x + xp * xp));
-    r2 = r2 < 0.0 ? 0.0 : r2;
-    const double rr = __builtin_sqrt(r2) * s.sc[10];
-    const int sx = (x > 0.0) - (x < 0.0), sp = (xp > 0.0) - (xp < 0.0);
-    const double ax = __builtin_fabs(x), ap = __builtin_fabs(xp);
-    const double kb = (sx == sp) ? s.sc[19] * (ax < ap ? ax : ap) : 0.0;
-    if (DQ) {
-#pragma unroll
-      for (int q = 0; q < MAXD; ++q) dq2[q] = 0.0;
-      dq2[0] = rr * rr;
-    }
-    return s.sc[18] * exp_nonpos(-0.5 * rr * rr, ec) * kb;
+// Phase clocks (-DCGP_ABLATION builds only): lane 0 adds the s_memtime ticks since the previous lap to sc[48 + slot]; k_small
+// copies them to out[32..].  Slots: 0 constants, 1 Gram, 2 F phases, 3 P, 4 U, 5 last row of W, 6 z / alpha / logML, 7 gradient
+// sums, 8 lane-0 step (gradient, L-BFGS), 9 evaluations.  tools/small_phases.py.
+struct SmClock {
+#ifdef CGP_ABLATION
+  long long t;
+  __device__ __forceinline__ void start() { t = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void lap(const double *sc_, int slot, int tid) {
+    const long long n = __builtin_amdgcn_s_memtime();
+    if (tid == 0) const_cast<double *>(sc_)[48 + slot] += (double)(n - t);
+    t = n;
   }
-  double d2 = 0.0;
-#pragma unroll
-  for (int q = 0; q < MAXD; ++q) {
-    double v = 0.0;
-    if (q < d) {
-      const double df = (s.xr[q * NP + gi] - s.xr[q * NP + gj]) * s.sc[10 + q];
-      v = df * df;
-    }
-    if (DQ) dq2[q] = v;
-    d2 += v;
-  }
-  return s.sc[18] * exp_nonpos(-0.5 * d2, ec);
+#else
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void lap(const double *, int, int) {}
+#endif
+};
+
+// Who does what beside the factor chain (sm_eval, phase F): for every step jb the items -- blocks (jp, j) of row jp = jb - 1
+// of W, cost jp - j + 1 products, code 0x100 | j; trailing blocks (bi, bj) with panel jp, one product, code bi << 4 | bj --
+// are dealt to the SM_NH helper waves longest first, each to the helper with the least work so far.  Lists
+// deal[jb][helper] = {count, items...}; depends on the number of block rows only, built once per launch by thread jb.
+__device__ __forceinline__ void sm_build_deal(unsigned short *deal, int NB, int jb) {
+  int load[SM_NH], cnt[SM_NH];
+  for (int h = 0; h < SM_NH; ++h) load[h] = cnt[h] = 0;
+  unsigned short *base = deal + jb * SM_NH * SM_DEAL;
+  auto give = [&](int code, int cost) {
+    int h = 0;
+    for (int hh = 1; hh < SM_NH; ++hh) h = load[hh] < load[h] ? hh : h;
+    load[h] += cost;
+    if (cnt[h] < SM_DEAL - 1) base[h * SM_DEAL + 1 + cnt[h]++] = (unsigned short)code;
+  };
+  const int jp = jb - 1;
+  for (int j = 0; j < jp; ++j) give(0x100 | j, jp - j + 1);
+  for (int bi = jb + 1; bi < NB; ++bi)
+    for (int bj = jb + 1; bj <= bi; ++bj) give(bi << 4 | bj, 1);
+  for (int h = 0; h < SM_NH; ++h) base[h * SM_DEAL] = (unsigned short)cnt[h];
 }
 
-// One evaluation at the natural parameters in s.sc[0..9] with jitter s.sc[21]: on return (after the final barrier)
-// s.flag[0] = first non-positive pivot (0 = positive definite), s.sc[22] = logML, s.sc[24..35] = gradient sums (k_grad's
-// layout: [0] amplitude, [1..8] length-scales, [9] noise).  Every thread of the workgroup calls it.
-__device__ __forceinline__ void sm_eval(const SmallLds &s, int kid, int d, int N, int NB, int tid) {
+// K_ij of two window points (no noise term) with the per-evaluation constants in registers.  BROWN: the reference's
+// RBF(1) x Brownian(1) (gp_slip_node.py:31) in GPy's form -- r^2 = -2 x x' + (x^2 + x'^2), clipped at 0, forced 0 on the
+// diagonal; sigma_b^2 min(|x|, |x'|) where the signs agree -- else SE-iso / SE-ARD over d <= DMAX length-scaled
+// differences.  dq2[q] = the length-scaled squared difference of coordinate q (what dK/d ell_q multiplies K by, up to 1 / ell_q).
+template <bool BROWN, int DMAX> struct SmKern {
+  double amp, amp_b, iell[DMAX];
+  __device__ __forceinline__ void load(const double *sc) {
+    amp = sc[18];
+    amp_b = sc[19];
+#pragma unroll
+    for (int q = 0; q < DMAX; ++q) iell[q] = sc[10 + q];
+  }
+  __device__ __forceinline__ double eval(const double *xr, int d, int NP, int gi, int gj, const ExpC &ec, double (&dq2)[DMAX]) const {
+    if constexpr (BROWN) {
+      const double x = xr[gi], xp = xr[gj];
+      double r2 = (gi == gj) ? 0.0 : (-2.0 * x * xp + (x * x + xp * xp));
+      r2 = r2 < 0.0 ? 0.0 : r2;
+      const double q2 = r2 * (iell[0] * iell[0]);
+      const bool same = (x > 0.0 && xp > 0.0) || (x < 0.0 && xp < 0.0) || (x == 0.0 && xp == 0.0);
+      const double ax = __builtin_fabs(x), ap = __builtin_fabs(xp);
+      const double kb = same ? amp_b * (ax < ap ? ax : ap) : 0.0;
+      dq2[0] = q2;
+      return amp * exp_nonpos(-0.5 * q2, ec) * kb;
+    } else {
+      double d2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < DMAX; ++q) {
+        double v = 0.0;
+        if (q < d) {
+          const double df = (xr[q * NP + gi] - xr[q * NP + gj]) * iell[q];
+          v = df * df;
+        }
+        dq2[q] = v;
+        d2 += v;
+      }
+      return amp * exp_nonpos(-0.5 * d2, ec);
+    }
+  }
+};
+
+// One evaluation at the natural parameters in s.sc[0..9] with jitter s.sc[21] (1 / ell_q, amplitudes and the diagonal
+// addend already in s.sc[10..20]: sm_prepare): on return (after the final barrier) s.flag[0] = first non-positive
+// pivot (0 = positive definite), s.sc[22] = logML, s.sc[24..35] = gradient sums (k_grad's layout: [0] amplitude,
+// [1..8] length-scales, [9] noise).  Every thread of the workgroup calls it.
+template <bool BROWN, int DMAX>
+__device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB, int tid) {
   using P = Prec<double>;
   using acc_t = P::acc_t;
   const int NP = NB * DB, nblk = NB * (NB + 1) / 2;
@@ -116,34 +170,23 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int kid, int d, int N
   double *Bk = s.Bk;
   ExpC ec;
   ec.load();
-  // ---- derived constants (every thread reads them from LDS afterwards)
-  if (tid == 0) {
-    const double *th = s.sc;
-    const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
-    for (int q = 0; q < MAXD; ++q) s.sc[10 + q] = q < d ? ((kid == K_SE_ARD) ? 1.0 / th[1 + q] : 1.0 / th[1]) : 0.0;
-    s.sc[18] = th[0];
-    s.sc[19] = (kid == K_RBF_BROWNIAN) ? th[2] : 0.0;
-    s.sc[20] = th[nth - 1] + 1e-8 + s.sc[21];
-    s.flag[0] = 0;
-  }
-  __syncthreads();
+  SmClock ck;
+  ck.start();
+  SmKern<BROWN, DMAX> kern;
+  kern.load(s.sc);
   // ---- Gram: two blocks per pass, one entry per thread
   {
     const double diag_add = s.sc[20];
     const int e = tid & 255, r = e & 15, c = e >> 4;
-    double dq2[MAXD];
+    double dq2[DMAX];
     for (int b0 = 0; b0 < nblk; b0 += 2) {
       const int blk = b0 + (tid >> 8);
       if (blk < nblk) {
-        int bi = 0, rem = blk;
-        while (rem > bi) {
-          rem -= bi + 1;
-          ++bi;
-        }
-        const int bj = rem, gi = bi * DB + r, gj = bj * DB + c;
+        const int t = s.tb[blk], bi = t & 255, bj = t >> 8;
+        const int gi = bi * DB + r, gj = bj * DB + c;
         double g;
         if (gi < N && gj < N) {
-          g = sm_kval<false>(s, kid, d, NP, gi, gj, ec, dq2);
+          g = kern.eval(s.xr, d, NP, gi, gj, ec, dq2);
           if (gi == gj) g += diag_add;
         } else g = (gi == gj) ? 1.0 : 0.0;   // identity padding keeps the factor well defined
         Bk[blk * SM_BLK + c * SM_LD + r] = g;
@@ -151,6 +194,7 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int kid, int d, int N
     }
   }
   __syncthreads();
+  ck.lap(s.sc, 1, tid);
 
   // ---- Cholesky and W = L^-1 in place, organised around the one serial chain (the NB diagonal blocks on wave 0):
   //   F(jb)  wave 0: factor + invert diagonal block jb in registers
@@ -161,21 +205,33 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int kid, int d, int N
   // Wave 4 shares wave 0's SIMD and stays idle during F so the chain issues alone.
   auto inverse_block = [&](int i, int j) -> acc_t {   // W(i, j), i > j, returned in the accumulator layout
     acc_t t0 = acc_t{0, 0, 0, 0}, t1 = t0;
-    for (int q = j; q < i; ++q) {
-      const double *lb = Bk + sm_tri(i, q), *wb = Bk + sm_tri(q, j);
+    int q = j;
+    for (; q + 1 < i; q += 2) {   // two products per trip, every operand read before the first MFMA, two accumulator chains
+      const double *la = Bk + sm_tri(i, q), *wa = Bk + sm_tri(q, j), *lb = Bk + sm_tri(i, q + 1), *wb = Bk + sm_tri(q + 1, j);
+      double fa[4], fb[4], ga[4], gb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        fa[ks] = la[(4 * ks + lq) * SM_LD + l15];   // L(i,q)[m = l15][k]
+        fb[ks] = wa[l15 * SM_LD + 4 * ks + lq];     // W(q,j)[k][n = l15]  (q = j: Dinv_j)
+        ga[ks] = lb[(4 * ks + lq) * SM_LD + l15];
+        gb[ks] = wb[l15 * SM_LD + 4 * ks + lq];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        t0 = P::mfma(fa[ks], fb[ks], t0);
+        t1 = P::mfma(ga[ks], gb[ks], t1);
+      }
+    }
+    if (q < i) {
+      const double *la = Bk + sm_tri(i, q), *wa = Bk + sm_tri(q, j);
       double fa[4], fb[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        fa[ks] = lb[(4 * ks + lq) * SM_LD + l15];   // L(i,q)[m = l15][k]
-        fb[ks] = wb[l15 * SM_LD + 4 * ks + lq];     // W(q,j)[k][n = l15]  (q = j: Dinv_j)
+        fa[ks] = la[(4 * ks + lq) * SM_LD + l15];
+        fb[ks] = wa[l15 * SM_LD + 4 * ks + lq];
       }
-      if ((q - j) & 1) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) t1 = P::mfma(fa[ks], fb[ks], t1);
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) t0 = P::mfma(fa[ks], fb[ks], t0);
-      }
+      for (int ks = 0; ks < 4; ++ks) t0 = P::mfma(fa[ks], fb[ks], t0);
     }
     const double *di = Bk + sm_tri(i, i);
     double ga[4];
@@ -207,13 +263,35 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int kid, int d, int N
 #pragma unroll
     for (int r = 0; r < 4; ++r) cb[(lq + 4 * r) * SM_LD + l15] = acc[r];
   };
-  constexpr int NH = SM_WAVES - 2;                       // helpers during F: every wave but 0 and its SIMD partner 4
+  // P[n = l15][col lq + 4 reg] of  P = A(bi,jb) Dinv_jb^T  (block bi of panel jb), in the accumulator layout
+  auto panel_block = [&](int bi, int jb) -> acc_t {
+    const double *dj = Bk + sm_tri(jb, jb), *ab = Bk + sm_tri(bi, jb);
+    double fa[4], fb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fa[ks] = dj[(4 * ks + lq) * SM_LD + l15];        // Dinv_jb[m = l15][k]
+      fb[ks] = ab[(4 * ks + lq) * SM_LD + l15];        // A(bi,jb)[n = l15][k]
+    }
+    acc_t acc = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
+    return acc;
+  };
+  // Helpers during F: every wave but 0 and its SIMD partner 4 (the chain issues alone on its SIMD).  What each of them does in
+  // step jb comes from a list built once per launch (sm_build_deal): the blocks (jp, j) of row jp = jb - 1 of W cost
+  // jp - j + 1 products each, the trailing blocks one each.
   const int helper = wave == 0 || wave == 4 ? -1 : (wave < 4 ? wave - 1 : wave - 2);
+  acc_t pend = acc_t{0, 0, 0, 0};   // wave 0: L(jb, jb-1), formed in the previous step's panel phase (see there)
   for (int jb = 0; jb < NB; ++jb) {
     acc_t wres[2];
     int wj[2] = {-1, -1};
     if (wave == 0) {
       double *dblk = Bk + sm_tri(jb, jb);
+      if (jb > 0) {
+        double *ab = Bk + sm_tri(jb, jb - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ab[(lq + 4 * r) * SM_LD + l15] = pend[r];
+      }
       double a[DB], w[DB];
       int bad = 0;
 #pragma unroll
@@ -231,43 +309,52 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int kid, int d, int N
         for (int i = 0; i < DB; ++i) dblk[l15 * SM_LD + i] = w[i];   // Dinv_jb[i][l15] replaces the diagonal block
       }
       if (bad != 0 && lane == 0 && s.flag[0] == 0) s.flag[0] = bad;
+#ifdef CGP_ABLATION
+      if (tid == 0) s.sc[48 + 10] += (double)(__builtin_amdgcn_s_memtime() - ck.t);   // the chain alone, without the wait for the helpers
+#endif
     } else if (helper >= 0 && jb > 0) {
-      const int jp = jb - 1, nb = NB - 1 - jb;
-      int it = 0;
-      for (int j = 0; j < jp; ++j, ++it)                 // row jp of W: the costliest items first
-        if (it % NH == helper) {
+      const int jp = jb - 1;
+      const unsigned short *lst = s.deal + (jb * SM_NH + helper) * SM_DEAL;
+      const int n = lst[0];
+      for (int k = 1; k <= n; ++k) {
+        const int it = lst[k];
+        if (it & 0x100) {
           const int slot = wj[0] < 0 ? 0 : 1;
-          wres[slot] = inverse_block(jp, j);
-          wj[slot] = j;
-        }
-      for (int bi = jb + 1; bi < NB; ++bi)
-        for (int bj = jb + 1; bj <= bi; ++bj, ++it)
-          if (it % NH == helper) trailing_block(bi, bj, jp);
-      (void)nb;
+          wres[slot] = inverse_block(jp, it & 0xff);
+          wj[slot] = it & 0xff;
+        } else trailing_block(it >> 4, it & 15, jp);
+      }
     }
     lds_barrier();
+    ck.lap(s.sc, 2, tid);
     if (wj[0] >= 0) store_acc(Bk + sm_tri(jb - 1, wj[0]), wres[0]);
     if (wj[1] >= 0) store_acc(Bk + sm_tri(jb - 1, wj[1]), wres[1]);
-    // ---- P(jb)
-    for (int bi = jb + 1 + wave; bi < NB; bi += SM_WAVES) {
-      const double *dj = Bk + sm_tri(jb, jb);
-      double *ab = Bk + sm_tri(bi, jb);
-      double fa[4], fb[4];
+    // ---- P(jb) and U(jb) in one phase: a wave forms L(bi,jb) = A(bi,jb) Dinv_jb^T for its block rows AND (again, in
+    // registers) L(jb+1,jb), stores the former and updates C(bi, jb+1) -= L(bi,jb) L(jb+1,jb)^T straight from the two
+    // accumulators -- register `reg` of a product is the operand of k-step `reg` of the next (file header).  Block
+    // (jb+1, jb) itself is read by every wave in this phase, so its owner (wave 0) keeps L(jb+1,jb) in registers and
+    // stores it after the barrier, at the top of the next step (nobody reads it before step jb + 2).
+    if (jb + 1 < NB) {
+      const acc_t pj = panel_block(jb + 1, jb);
+      for (int bi = jb + 1 + wave; bi < NB; bi += SM_WAVES) {
+        const acc_t pb = bi == jb + 1 ? pj : panel_block(bi, jb);
+        double *ab = Bk + sm_tri(bi, jb), *cb = Bk + sm_tri(bi, jb + 1);
+        acc_t acc;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        fa[ks] = dj[(4 * ks + lq) * SM_LD + l15];        // Dinv_jb[m = l15][k]
-        fb[ks] = ab[(4 * ks + lq) * SM_LD + l15];        // A(bi,jb)[n = l15][k]
+        for (int r = 0; r < 4; ++r) acc[r] = cb[(lq + 4 * r) * SM_LD + l15];     // C[row = l15][col = lq + 4 r]
+        if (bi == jb + 1) pend = pb;
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ab[(lq + 4 * r) * SM_LD + l15] = pb[r];    // L(bi,jb)[row = l15][col = lq + 4 r]
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = P::mfma(-pj[ks], pb[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cb[(lq + 4 * r) * SM_LD + l15] = acc[r];
       }
-      acc_t acc = acc_t{0, 0, 0, 0};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ab[(lq + 4 * r) * SM_LD + l15] = acc[r];   // L(bi,jb)[row = l15][col = lq + 4 r]
     }
     lds_barrier();
-    // ---- U(jb): block column jb + 1
-    for (int bi = jb + 1 + wave; bi < NB; bi += SM_WAVES) trailing_block(bi, jb + 1, jb);
-    lds_barrier();
+    ck.lap(s.sc, 3, tid);
   }
   {  // the last row of W
     acc_t wres[2];
@@ -282,29 +369,39 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int kid, int d, int N
     if (wj[1] >= 0) store_acc(Bk + sm_tri(NB - 1, wj[1]), wres[1]);
   }
   __syncthreads();
+  ck.lap(s.sc, 5, tid);
 
-  // ---- z = W y, alpha = W^T z, logML
-  if (tid < NP) {
-    const int bi = tid >> 4, r = tid & 15;
-    double z = 0.0;
-    for (int bj = 0; bj <= bi; ++bj) {
-      const double *wb = Bk + sm_tri(bi, bj) + r;
+  // ---- z = W y, alpha = W^T z, logML: a row's (column's) blocks dealt over three threads, partial sums added in fixed order
+  {
+    const int part = tid / NP, i = tid - part * NP;
+    if (part < 3) {
+      const int bi = i >> 4, r = i & 15;
+      double z = 0.0;
+      for (int bj = part; bj <= bi; bj += 3) {
+        const double *wb = Bk + sm_tri(bi, bj) + r;
 #pragma unroll
-      for (int c = 0; c < DB; ++c) z = __builtin_fma(wb[c * SM_LD], s.yv[bj * DB + c], z);
+        for (int c = 0; c < DB; ++c) z = __builtin_fma(wb[c * SM_LD], s.yv[bj * DB + c], z);
+      }
+      s.tmp[part * NP + i] = z;
     }
-    s.zv[tid] = z;
+    __syncthreads();
+    if (tid < NP) s.zv[tid] = (s.tmp[tid] + s.tmp[NP + tid]) + s.tmp[2 * NP + tid];
+    __syncthreads();
+    if (part < 3) {
+      const int bj = i >> 4, c = i & 15;
+      double a = 0.0;
+      for (int bi = bj + part; bi < NB; bi += 3) {
+        const double *wb = Bk + sm_tri(bi, bj) + c * SM_LD;
+#pragma unroll
+        for (int r = 0; r < DB; ++r) a = __builtin_fma(wb[r], s.zv[bi * DB + r], a);
+      }
+      s.tmp[part * NP + i] = a;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   double lsum = 0.0;
   if (tid < NP) {
-    const int bj = tid >> 4, c = tid & 15;
-    double a = 0.0;
-    for (int bi = bj; bi < NB; ++bi) {
-      const double *wb = Bk + sm_tri(bi, bj) + c * SM_LD;
-#pragma unroll
-      for (int r = 0; r < DB; ++r) a = __builtin_fma(wb[r], s.zv[bi * DB + r], a);
-    }
-    s.al[tid] = a;
+    s.al[tid] = (s.tmp[tid] + s.tmp[NP + tid]) + s.tmp[2 * NP + tid];
     const double z = s.zv[tid];
     lsum = -0.5 * z * z - (tid < N ? log(s.ldg[tid]) : 0.0);
   }
@@ -318,18 +415,14 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int kid, int d, int N
     s.sc[22] = t - 0.5 * (double)N * 1.8378770664093453;
   }
   __syncthreads();
+  ck.lap(s.sc, 6, tid);
 
   // ---- gradient sums: Ky^-1(bi,bj) = sum_{k >= bi} W(k,bi)^T W(k,bj) in registers, contracted on the spot
-  double s_amp = 0.0, s_noise = 0.0, s_ell[MAXD];
+  double s_amp = 0.0, s_noise = 0.0, s_ell[DMAX];
 #pragma unroll
-  for (int q = 0; q < MAXD; ++q) s_ell[q] = 0.0;
+  for (int q = 0; q < DMAX; ++q) s_ell[q] = 0.0;
   for (int blk = wave; blk < nblk; blk += SM_WAVES) {
-    int bi = 0, rem = blk;
-    while (rem > bi) {
-      rem -= bi + 1;
-      ++bi;
-    }
-    const int bj = rem;
+    const int t = s.tb[blk], bi = t & 255, bj = t >> 8;
     acc_t a0 = acc_t{0, 0, 0, 0}, a1 = a0;
     for (int k = bi; k < NB; ++k) {
       const double *wa = Bk + sm_tri(k, bi), *wb = Bk + sm_tri(k, bj);
@@ -349,17 +442,18 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int kid, int d, int N
     }
     const double wgt = (bi == bj) ? 1.0 : 2.0;
     const int gj = bj * DB + l15;
+    const double alj = s.al[gj];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gi = bi * DB + lq + 4 * r;
       if (gi < N && gj < N) {
-        double dq2[MAXD];
-        const double kv = sm_kval<true>(s, kid, d, NP, gi, gj, ec, dq2);
-        const double w = s.al[gi] * s.al[gj] - (a0[r] + a1[r]);
+        double dq2[DMAX];
+        const double kv = kern.eval(s.xr, d, NP, gi, gj, ec, dq2);
+        const double w = s.al[gi] * alj - (a0[r] + a1[r]);
         const double wk = wgt * w * kv;
         s_amp += wk;
 #pragma unroll
-        for (int q = 0; q < MAXD; ++q) s_ell[q] += wk * dq2[q];
+        for (int q = 0; q < DMAX; ++q) s_ell[q] += wk * dq2[q];
         if (gi == gj) s_noise += w;
       }
     }
@@ -368,7 +462,7 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int kid, int d, int N
     double vals[GRAD_N];
     vals[0] = s_amp;
 #pragma unroll
-    for (int q = 0; q < MAXD; ++q) vals[1 + q] = s_ell[q];
+    for (int q = 0; q < MAXD; ++q) vals[1 + q] = q < DMAX ? s_ell[q < DMAX ? q : 0] : 0.0;
     vals[9] = s_noise;
     vals[10] = vals[11] = 0.0;
 #pragma unroll
@@ -386,6 +480,10 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int kid, int d, int N
     s.sc[24 + tid] = t;
   }
   __syncthreads();
+  ck.lap(s.sc, 7, tid);
+#ifdef CGP_ABLATION
+  if (tid == 0) s.sc[48 + 9] += 1.0;
+#endif
 }
 
 // d(-logML)/dtheta (natural parameters) from the sums; the host twin is grad_from_sums (cgp_engine.hip)
@@ -408,22 +506,93 @@ __device__ __forceinline__ void sm_grad_from_sums(int kid, int d, const double *
   }
 }
 
+// Logexp (GPy paramz.transformations.Logexp): theta = log(1 + exp(x))
+__device__ __forceinline__ double sm_to_theta(double x) { return x > 35.0 ? x : log1p(exp(x)); }
+__device__ __forceinline__ double sm_to_x(double th) { return th > 35.0 ? th : log(expm1(th)); }
+
+// Before an evaluation, one lane per parameter (the transcendental functions of the Logexp transform are a few hundred
+// instructions each: in parallel they cost one of them, on lane 0 they cost nth of them): theta from the trial point
+// (OPT) or as given (EVAL) -> sc[0..9], dtheta/dx = 1 - exp(-theta) -> sc[36..45]; the jitter ladder starts over.
+__device__ __forceinline__ void sm_trial_point(const SmallLds &s, const SmallArgs &p, int nth, const double *thb, int tid) {
+  if (tid < MAX_THETA) {
+    double th = 0.0, dth = 0.0;
+    if (tid < nth) {
+      if (p.mode == SM_MODE_OPT) {
+        const double x = s.lb->xn[tid];
+        th = fmax(sm_to_theta(x), 1e-300);
+        dth = x > 35.0 ? 1.0 : -expm1(-th);
+      } else {
+        th = thb[tid];
+        dth = 1.0;
+      }
+    }
+    s.sc[tid] = th;
+    s.sc[36 + tid] = dth;
+  }
+  if (tid == 0) {
+    s.sc[21] = 0.0;
+    s.flag[2] = 0;
+  }
+}
+
+// The per-evaluation constants from theta and the jitter: 1 / ell_q (one lane per dimension), amplitudes, diagonal addend
+__device__ __forceinline__ void sm_constants(const SmallLds &s, int kid, int d, int nth, int tid) {
+  if (tid < MAXD) s.sc[10 + tid] = tid < d ? ((kid == K_SE_ARD) ? 1.0 / s.sc[1 + tid] : 1.0 / s.sc[1]) : 0.0;
+  if (tid == 64) {
+    s.sc[18] = s.sc[0];
+    s.sc[19] = (kid == K_RBF_BROWNIAN) ? s.sc[2] : 0.0;
+    s.sc[20] = s.sc[nth - 1] + 1e-8 + s.sc[21];
+    s.flag[0] = 0;
+  }
+}
+
+// lane 0 after an evaluation: gradient from the sums, then either the L-BFGS step (OPT) or the outputs (EVAL).  Out of
+// line (its registers must not weigh on the evaluation's); its vectors live in LDS (s.red), not in scratch memory.
+__device__ __attribute__((noinline)) void sm_lane0_tell(const SmallLds &s, const SmallArgs &p, int kid, int d, int nth, double *ob) {
+  const bool ok = s.flag[0] == 0;
+  double *g = s.red, *gx = s.red + 16;   // [MAX_THETA] natural gradient, [LB_N] gradient wrt the Logexp variables
+  for (int i = 0; i < MAX_THETA; ++i) g[i] = 0.0;
+  if (ok) sm_grad_from_sums(kid, d, s.sc, s.sc + 24, g);
+  if (p.mode == SM_MODE_OPT) {
+    for (int i = 0; i < nth; ++i) gx[i] = g[i] * s.sc[36 + i];
+    s.lb->tell(ok ? -s.sc[22] : INFINITY, gx);
+    s.flag[1] = s.lb->done() ? 1 : 0;
+  } else {
+    ob[SMO_LOGML] = s.sc[22];
+    ob[SMO_EVALS] = 1.0;
+    ob[SMO_STATUS] = 0.0;
+    ob[SMO_ITERS] = 0.0;
+    ob[SMO_INFO] = (double)s.flag[0];
+    ob[SMO_JITTER] = ok ? s.sc[21] : 0.0;
+    for (int i = 0; i < MAX_THETA; ++i) {
+      ob[SMO_GRAD + i] = g[i];
+      ob[SMO_THETA + i] = s.sc[i];
+    }
+    s.flag[1] = 1;
+  }
+}
+
+// BROWN: RBF x Brownian (d = 1); otherwise SE-iso / SE-ARD with d <= DMAX (the host picks the smallest build that fits)
+template <bool BROWN, int DMAX>
 __global__ __launch_bounds__(SM_THREADS) void k_small(SmallArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, b = blockIdx.x;
   const int N = p.N, d = p.d, kid = p.kernel_id, nth = p.nth;
-  const int NB = (N + DB - 1) / DB, NP = NB * DB;
+  const int NB = (N + DB - 1) / DB, NP = NB * DB, nblk = NB * (NB + 1) / 2;
   SmallLds s;
   s.Bk = reinterpret_cast<double *>(smem_raw);
-  s.xr = s.Bk + (size_t)NB * (NB + 1) / 2 * SM_BLK;
+  s.xr = s.Bk + (size_t)nblk * SM_BLK;
   s.yv = s.xr + (size_t)d * NP;
   s.zv = s.yv + NP;
   s.al = s.zv + NP;
   s.ldg = s.al + NP;
-  s.red = s.ldg + NP;
+  s.tmp = s.ldg + NP;
+  s.red = s.tmp + 3 * NP;
   s.sc = s.red + SM_WAVES * GRAD_N;
   s.lb = reinterpret_cast<corenav::LbfgsCore *>(s.sc + 64);
   s.flag = reinterpret_cast<int *>(reinterpret_cast<char *>(s.lb) + sizeof(corenav::LbfgsCore));
+  s.tb = s.flag + 8;
+  s.deal = reinterpret_cast<unsigned short *>(s.tb + nblk);
   const double *Xb = p.X + (size_t)b * d * N, *yb = p.y + (size_t)b * N;
   double *thb = p.theta + (size_t)b * MAX_THETA, *ob = p.out + (size_t)b * SM_OUT;
   for (int i = tid; i < d * NP; i += SM_THREADS) {
@@ -431,83 +600,76 @@ __global__ __launch_bounds__(SM_THREADS) void k_small(SmallArgs p) {
     s.xr[i] = r < N ? Xb[(size_t)q * N + r] : 0.0;
   }
   for (int i = tid; i < NP; i += SM_THREADS) s.yv[i] = i < N ? yb[i] : 0.0;
+  for (int i = tid; i < nblk; i += SM_THREADS) {   // packed index -> (block row, block column)
+    int bi = 0, rem = i;
+    while (rem > bi) {
+      rem -= bi + 1;
+      ++bi;
+    }
+    s.tb[i] = bi | (rem << 8);
+  }
+  if (tid >= 64 && tid < 64 + NB) sm_build_deal(s.deal, NB, tid - 64);
   __syncthreads();
-  // Logexp (GPy paramz.transformations.Logexp): theta = log(1 + exp(x))
-  auto to_theta = [](double x) { return x > 35.0 ? x : log1p(exp(x)); };
-  auto to_x = [](double th) { return th > 35.0 ? th : log(expm1(th)); };
   if (tid == 0) {
     double sa = 0.0;   // mean |x| of the first input: jitchol's mean(diag) for the Brownian factor
     for (int i = 0; i < N; ++i) sa += fabs(s.xr[i]);
     s.sc[23] = sa / (double)N;
     s.flag[1] = 0;
+    for (int i = 0; i < 16; ++i) s.sc[48 + i] = 0.0;
     if (p.mode == SM_MODE_OPT) {
-      double x0[corenav::LB_N];
-      for (int i = 0; i < nth; ++i) x0[i] = to_x(thb[i]);
+      double *x0 = s.red;
+      for (int i = 0; i < nth; ++i) x0[i] = sm_to_x(thb[i]);
       s.lb->init(x0, nth, p.max_evals, p.pgtol, p.factr);
     }
   }
   __syncthreads();
   const int max_rounds = p.mode == SM_MODE_OPT ? p.max_evals + 64 : 1;
   for (int round = 0; round < max_rounds; ++round) {
-    if (tid == 0) {
-      for (int i = 0; i < MAX_THETA; ++i) {
-        double th = 0.0;
-        if (i < nth) th = p.mode == SM_MODE_OPT ? fmax(to_theta(s.lb->xn[i]), 1e-300) : thb[i];
-        s.sc[i] = th;
-      }
-      s.sc[21] = 0.0;
-      s.flag[2] = 0;
-    }
+    SmClock ck;
+    ck.start();
+    sm_trial_point(s, p, nth, thb, tid);
     __syncthreads();
     // GPy jitchol: retry a matrix that is not positive definite with jitter mean(diag) 1e-6 10^k, k = 0..4
     for (;;) {
-      sm_eval(s, kid, d, N, NB, tid);
+      sm_constants(s, kid, d, nth, tid);
+      __syncthreads();
+      ck.lap(s.sc, 0, tid);
+      sm_eval<BROWN, DMAX>(s, d, N, NB, tid);
       const int bad = s.flag[0];
       const int attempt = s.flag[2];
       if (bad == 0 || attempt >= 5) break;
       __syncthreads();
       if (tid == 0) {
         const double noise = s.sc[nth - 1] + 1e-8;
-        const double md = kid == K_RBF_BROWNIAN ? s.sc[0] * s.sc[2] * s.sc[23] + noise : s.sc[0] + noise;
+        const double md = BROWN ? s.sc[0] * s.sc[2] * s.sc[23] + noise : s.sc[0] + noise;
         s.sc[21] = attempt == 0 ? md * 1e-6 : s.sc[21] * 10.0;
         s.flag[2] = attempt + 1;
       }
       __syncthreads();
+      ck.start();
     }
-    if (tid == 0) {
-      const bool ok = s.flag[0] == 0;
-      double g[MAX_THETA];
-      for (int i = 0; i < MAX_THETA; ++i) g[i] = 0.0;
-      if (ok) sm_grad_from_sums(kid, d, s.sc, s.sc + 24, g);
-      if (p.mode == SM_MODE_OPT) {
-        double gx[corenav::LB_N];
-        for (int i = 0; i < nth; ++i) gx[i] = g[i] * (s.lb->xn[i] > 35.0 ? 1.0 : -expm1(-s.sc[i]));   // dtheta/dx = 1 - exp(-theta)
-        s.lb->tell(ok ? -s.sc[22] : INFINITY, gx);
-        s.flag[1] = s.lb->done() ? 1 : 0;
-      } else {
-        ob[SMO_LOGML] = s.sc[22];
-        ob[SMO_EVALS] = 1.0;
-        ob[SMO_STATUS] = 0.0;
-        ob[SMO_ITERS] = 0.0;
-        ob[SMO_INFO] = (double)s.flag[0];
-        ob[SMO_JITTER] = ok ? s.sc[21] : 0.0;
-        for (int i = 0; i < MAX_THETA; ++i) ob[SMO_GRAD + i] = g[i];
-        s.flag[1] = 1;
-      }
-    }
+    ck.start();
+    if (tid == 0) sm_lane0_tell(s, p, kid, d, nth, ob);
+    ck.lap(s.sc, 8, tid);
     __syncthreads();
     if (s.flag[1]) break;
   }
-  if (tid == 0 && p.mode == SM_MODE_OPT) {
+#ifdef CGP_ABLATION
+  if (tid == 0)
+    for (int i = 0; i < 16; ++i) ob[32 + i] = s.sc[48 + i];
+#endif
+  if (p.mode == SM_MODE_OPT) {
     const corenav::LbfgsCore &lb = *s.lb;
-    for (int i = 0; i < MAX_THETA; ++i) thb[i] = i < nth ? to_theta(lb.x[i]) : 0.0;
-    ob[SMO_LOGML] = -lb.f;
-    ob[SMO_EVALS] = (double)lb.evals;
-    ob[SMO_STATUS] = (double)(lb.done() ? lb.status : 2);
-    ob[SMO_ITERS] = (double)lb.iters;
-    ob[SMO_INFO] = __builtin_isfinite(lb.f) ? 0.0 : 1.0;
-    ob[SMO_JITTER] = 0.0;
-    for (int i = 0; i < MAX_THETA; ++i) ob[SMO_GRAD + i] = i < nth ? lb.g[i] : 0.0;   // wrt x, at the optimum
+    if (tid < MAX_THETA) ob[SMO_THETA + tid] = thb[tid] = tid < nth ? sm_to_theta(lb.x[tid]) : 0.0;
+    if (tid == 0) {
+      ob[SMO_LOGML] = -lb.f;
+      ob[SMO_EVALS] = (double)lb.evals;
+      ob[SMO_STATUS] = (double)(lb.done() ? lb.status : 2);
+      ob[SMO_ITERS] = (double)lb.iters;
+      ob[SMO_INFO] = __builtin_isfinite(lb.f) ? 0.0 : 1.0;
+      ob[SMO_JITTER] = 0.0;
+      for (int i = 0; i < MAX_THETA; ++i) ob[SMO_GRAD + i] = i < nth ? lb.g[i] : 0.0;   // wrt x, at the optimum
+    }
   }
 }
 

@@ -25,6 +25,7 @@ struct LbfgsCore {
   double pgtol, ftol;
   double x[LB_N], g[LB_N], xn[LB_N], gn[LB_N], dir[LB_N];
   double S[LB_M][LB_N], Y[LB_M][LB_N], rho[LB_M];
+  double wa[LB_M], ws[LB_N], wy[LB_N];  // work vectors (members, so that on the device they live with the state in LDS, not in scratch memory)
   double f, fn, dg0, t, t_lo, f_lo, dg_lo, t_hi, f_hi, t_prev, f_prev;
 
   CGP_HD void init(const double *x0, int n_, int max_evals_, double pgtol_, double factr) {
@@ -88,7 +89,7 @@ struct LbfgsCore {
     if (evals >= max_evals) return finish(2);
     for (int j = 0; j < n; ++j) dir[j] = g[j];  // two-loop recursion
     const int k = hist;
-    double a[LB_M];
+    double *a = wa;
     for (int i = k - 1; i >= 0; --i) {
       a[i] = rho[i] * dot(S[i], dir);
       for (int j = 0; j < n; ++j) dir[j] -= a[i] * Y[i][j];
@@ -182,7 +183,7 @@ struct LbfgsCore {
       else return finish(evals >= max_evals ? 2 : 3);
     }
     // accept the step
-    double s[LB_N], yv[LB_N];
+    double *s = ws, *yv = wy;
     for (int j = 0; j < n; ++j) {
       s[j] = xn[j] - x[j];
       yv[j] = gn[j] - g[j];

@@ -64,6 +64,7 @@ _SIGS = {
     "cgp_set_streams": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cgp_debug_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong)]),
     "cgp_debug_buffers": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_ulonglong)]),
+    "cgp_debug_small": (ctypes.c_int, [_vp, _dp]),
     "cgp_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cgp_profile_read": (ctypes.c_int, [_vp, _dp, _dp, ctypes.POINTER(ctypes.c_longlong)]),
     "cgp_llh_to_enu": (ctypes.c_int, [ctypes.c_double] * 3 + [_dp, _dp, _dp]),
@@ -326,6 +327,12 @@ class Context:
         out = np.zeros(16, dtype=np.uint64)
         self._chk(self.lib.cgp_debug_buffers(self.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong))))
         return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(8)]
+
+    def debug_small(self):
+        """Raw result record of the last short-window launch (include/corenav_gp.h: cgp_debug_small)."""
+        out = np.zeros(48)
+        self._chk(self.lib.cgp_debug_small(self.h, _p(out)))
+        return out
 
     def set_streams(self, n):
         self._chk(self.lib.cgp_set_streams(self.h, int(n)))

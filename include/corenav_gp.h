@@ -200,6 +200,12 @@ int cgp_debug_read(cgp_ctx *ctx, long long out[CGP_DEBUG_SLOTS]);
  * out[2 i] = address, out[2 i + 1] = bytes for i = 0 factor panels (Lw), 1 W images (Winv), 2 diagonal-tile images,
  * 3 panel-tile images, 4 inputs X, 5 running predictive sums, 6 latency partial tiles, 7 latency images
  * (tools/ctx_placement.py prints them next to the timings of a context). */
+/* Development aid: the raw result record of the last short-window launch (cgp_nll_grad / cgp_optimize* of a window of at
+ * most 160 samples in an fp64 context, csrc/cgp_small.hpp): [0] logML, [1] evaluations, [2] L-BFGS status, [3] iterations,
+ * [4] info, [5] jitter, [8..18) gradient, [20..30) theta, [32..48) per-phase s_memtime sums (-DCGP_ABLATION builds; zero
+ * otherwise: tools/small_phases.py). */
+#define CGP_SMALL_OUT 48
+int cgp_debug_small(cgp_ctx *ctx, double out[CGP_SMALL_OUT]);
 #define CGP_DEBUG_BUFFERS 8
 int cgp_debug_buffers(cgp_ctx *ctx, unsigned long long out[2 * CGP_DEBUG_BUFFERS]);
 
