@@ -1623,10 +1623,75 @@ extern "C" int cgp_optimize(cgp_ctx *c, const double *X, const double *y, int N,
   return CGP_OK;
 }
 
+
+namespace {
+// The reference node's whole callback (gp_slip_node.py:16-63) for a short window in ONE host round trip: stage the window,
+// the 599 prediction ticks and the start values, then queue  unpack -> k_small (m.optimize() on the device, optimum left in
+// the context's theta slot) -> the fixed-theta fit + predict schedule reading that slot -> results, and synchronise once.
+int node_callback_opt_fused(cgp_ctx *c, const double *time_array, const double *slip_array, int n, int kid, double *theta,
+                            int max_evals, double *mean, double *sigma, int cap, int *m_out) {
+  const int ntr = (int)(0.9 * (double)n);  // gp_slip_node.py:27-29
+  if (ntr < 1 || !small_ok(c, ntr) || check_shape(c, 1, ntr, 1, ntr, kid) != CGP_OK) return CGP_ESTATE;
+  const int nth = ntheta(kid, 1);
+  for (int i = 0; i < nth; ++i)
+    if (!(theta[i] > 0.0)) return CGP_EINVAL;
+  double xmin = time_array[0], xmax = time_array[0];   // gp_slip_node.py:45  X_ = np.arange(X.min(), X.max() + 600, 1)
+  for (int i = 1; i < n; ++i) {
+    xmin = std::min(xmin, time_array[i]);
+    xmax = std::max(xmax, time_array[i]);
+  }
+  const long long glen = (long long)std::ceil((xmax + 600.0 - xmin) / 1.0);
+  const long long mo = std::max(0LL, glen - n);         // gp_slip_node.py:59-61  means[len(X):]
+  if (m_out) *m_out = (int)mo;
+  const int M = (int)std::min<long long>(mo, cap);
+  if (M == 0 || M > c->max_m) return CGP_ESTATE;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t nX = ntr, nin = 2 * nX + M + CGP_MAX_THETA, in_bytes = nin * sizeof(double);
+  const size_t nout = 2 * (size_t)M + 2 + SM_OUT, out_bytes = nout * sizeof(double);   // mean, var, logML, info (as a double slot), k_small record
+  if (!grow_pinned(c->pin_in, c->pin_in_cap, in_bytes) || !grow_pinned(c->pin_out, c->pin_out_cap, out_bytes) ||
+      !grow_device(c->draw, c->draw_cap, in_bytes))
+    return CGP_ENOMEM;
+  double *hin = static_cast<double *>(c->pin_in);
+  memcpy(hin, time_array, nX * sizeof(double));
+  memcpy(hin + nX, slip_array, nX * sizeof(double));
+  for (int m = 0; m < M; ++m) hin[2 * nX + m] = xmin + (double)(n + m);
+  for (int q = 0; q < CGP_MAX_THETA; ++q) hin[2 * nX + M + q] = q < nth ? theta[q] : 0.0;
+  HIP_TRY(c, hipMemcpyAsync(c->draw, hin, in_bytes, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_pack_call<double>, dim3(std::min(64, cdiv(std::max(ntr, M), 256)), 1), dim3(256), 0, s, static_cast<const double *>(c->draw),
+                     static_cast<double *>(c->dX), static_cast<double *>(c->dy), static_cast<double *>(c->dXs), c->dtheta, c->djitter, 1, ntr, 1, M);
+  int rc = small_launch(c, 1, ntr, 1, kid, SM_MODE_OPT, max_evals, s);
+  if (rc != CGP_OK) return rc;
+  rc = cgp_fit_predict_batch_device(c, 1, ntr, 1, M, kid, c->dX, c->dy, c->dXs, c->dtheta, c->djitter, 1, c->dmean, c->dvar, c->dlogml,
+                                    c->dinfo, CGP_STREAM_CTX);
+  if (rc != CGP_OK) return rc;
+  double *hout = static_cast<double *>(c->pin_out);
+  int *hinfo = reinterpret_cast<int *>(hout + 2 * (size_t)M + 1);
+  HIP_TRY(c, hipMemcpyAsync(hout, c->dmean, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(hout + M, c->dvar, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(hout + 2 * (size_t)M, c->dlogml, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(hinfo, c->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(hout + 2 * (size_t)M + 2, c->dsmall, SM_OUT * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  const double *so = hout + 2 * (size_t)M + 2;
+  if (so[SMO_INFO] != 0.0) return 1;   // the start values themselves are not positive definite even with the jitter ladder
+  for (int i = 0; i < nth; ++i) theta[i] = so[SMO_THETA + i];
+  if (*hinfo != 0) return CGP_ESTATE;  // the fit at the optimum needs GPy's jitter ladder: the caller's two-call path runs it (theta is the optimum already)
+  memcpy(mean, hout, (size_t)M * sizeof(double));
+  for (int m = 0; m < M; ++m) sigma[m] = 2.0 * std::sqrt(hout[M + m]);   // gp_slip_node.py:61
+  c->fjitter = 0.0;
+  return CGP_OK;
+}
+}  // namespace
+
 extern "C" int cgp_slip_node_callback_opt(cgp_ctx *c, const double *time_array, const double *slip_array, int n,
                                           int kid, double *theta, int max_evals, double *mean, double *sigma, int cap,
                                           int *m_out) {
   if (!c || !time_array || !slip_array || !theta || n < 2) return CGP_EINVAL;
+  if (max_evals > 0 && mean && sigma && cap >= 0) {
+    const int rc = node_callback_opt_fused(c, time_array, slip_array, n, kid, theta, max_evals, mean, sigma, cap, m_out);
+    if (rc != CGP_ESTATE) return rc;   // CGP_ESTATE: not a short fp64 window (or its fit needs the jitter ladder) -- the two-call path below
+  }
   if (max_evals > 0) {
     const int ntr = (int)(0.9 * (double)n);  // gp_slip_node.py:27-29
     int rc = cgp_optimize(c, time_array, slip_array, ntr, 1, kid, theta, max_evals, nullptr, nullptr);  // :36

@@ -174,23 +174,28 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
   ck.start();
   SmKern<BROWN, DMAX> kern;
   kern.load(s.sc);
-  // ---- Gram: two blocks per pass, one entry per thread
+  // ---- Gram: two blocks per pass, one entry per thread; two passes per trip with every LDS read (block table, inputs) of
+  // both ahead of the arithmetic -- the compiler cannot move a table read above the previous pass's store on its own
   {
     const double diag_add = s.sc[20];
-    const int e = tid & 255, r = e & 15, c = e >> 4;
-    double dq2[DMAX];
-    for (int b0 = 0; b0 < nblk; b0 += 2) {
-      const int blk = b0 + (tid >> 8);
-      if (blk < nblk) {
-        const int t = s.tb[blk], bi = t & 255, bj = t >> 8;
-        const int gi = bi * DB + r, gj = bj * DB + c;
-        double g;
-        if (gi < N && gj < N) {
-          g = kern.eval(s.xr, d, NP, gi, gj, ec, dq2);
-          if (gi == gj) g += diag_add;
-        } else g = (gi == gj) ? 1.0 : 0.0;   // identity padding keeps the factor well defined
-        Bk[blk * SM_BLK + c * SM_LD + r] = g;
-      }
+    const int e = tid & 255, r = e & 15, c = e >> 4, half = tid >> 8;
+    auto entry = [&](int gi, int gj) -> double {
+      double dq2[DMAX];
+      double g;
+      if (gi < N && gj < N) {
+        g = kern.eval(s.xr, d, NP, gi, gj, ec, dq2);
+        if (gi == gj) g += diag_add;
+      } else g = (gi == gj) ? 1.0 : 0.0;   // identity padding keeps the factor well defined
+      return g;
+    };
+    for (int b0 = 0; b0 < nblk; b0 += 4) {
+      const int blk0 = b0 + half, blk1 = b0 + 2 + half;
+      const bool on0 = blk0 < nblk, on1 = blk1 < nblk;
+      const int t0 = s.tb[on0 ? blk0 : 0], t1 = s.tb[on1 ? blk1 : 0];
+      const double g0 = entry((t0 & 255) * DB + r, (t0 >> 8) * DB + c);
+      const double g1 = entry((t1 & 255) * DB + r, (t1 >> 8) * DB + c);
+      if (on0) Bk[blk0 * SM_BLK + c * SM_LD + r] = g0;
+      if (on1) Bk[blk1 * SM_BLK + c * SM_LD + r] = g1;
     }
   }
   __syncthreads();
@@ -335,22 +340,52 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
     // (jb+1, jb) itself is read by every wave in this phase, so its owner (wave 0) keeps L(jb+1,jb) in registers and
     // stores it after the barrier, at the top of the next step (nobody reads it before step jb + 2).
     if (jb + 1 < NB) {
-      const acc_t pj = panel_block(jb + 1, jb);
-      for (int bi = jb + 1 + wave; bi < NB; bi += SM_WAVES) {
-        const acc_t pb = bi == jb + 1 ? pj : panel_block(bi, jb);
-        double *ab = Bk + sm_tri(bi, jb), *cb = Bk + sm_tri(bi, jb + 1);
-        acc_t acc;
+      // every operand of the three products is requested before the first MFMA; the two panel products are independent chains
+      const double *dj = Bk + sm_tri(jb, jb), *aj = Bk + sm_tri(jb + 1, jb);
+      int bi = jb + 1 + wave;
+      const bool mine = bi < NB;
+      double *ab = Bk + sm_tri(mine ? bi : jb + 1, jb), *cb = Bk + sm_tri(mine ? bi : jb + 1, jb + 1);
+      double fd[4], fj[4], fb[4];
+      acc_t acc = acc_t{0, 0, 0, 0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = cb[(lq + 4 * r) * SM_LD + l15];     // C[row = l15][col = lq + 4 r]
+      for (int ks = 0; ks < 4; ++ks) {
+        fd[ks] = dj[(4 * ks + lq) * SM_LD + l15];        // Dinv_jb[m = l15][k]
+        fj[ks] = aj[(4 * ks + lq) * SM_LD + l15];        // A(jb+1,jb)[n = l15][k]
+        fb[ks] = ab[(4 * ks + lq) * SM_LD + l15];        // A(bi,jb)[n = l15][k]
+      }
+      if (mine) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = cb[(lq + 4 * r) * SM_LD + l15];   // C(bi,jb+1)[row = l15][col = lq + 4 r]
+      }
+      acc_t pj = acc_t{0, 0, 0, 0}, pb = pj;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        pj = P::mfma(fd[ks], fj[ks], pj);
+        pb = P::mfma(fd[ks], fb[ks], pb);
+      }
+      if (mine) {
         if (bi == jb + 1) pend = pb;
         else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ab[(lq + 4 * r) * SM_LD + l15] = pb[r];    // L(bi,jb)[row = l15][col = lq + 4 r]
+          for (int r = 0; r < 4; ++r) ab[(lq + 4 * r) * SM_LD + l15] = pb[r];  // L(bi,jb)[row = l15][col = lq + 4 r]
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) acc = P::mfma(-pj[ks], pb[ks], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) cb[(lq + 4 * r) * SM_LD + l15] = acc[r];
+      }
+      for (bi += SM_WAVES; bi < NB; bi += SM_WAVES) {   // more block rows than waves (ten block rows, first step)
+        const acc_t p2 = panel_block(bi, jb);
+        double *a2 = Bk + sm_tri(bi, jb), *c2 = Bk + sm_tri(bi, jb + 1);
+        acc_t ac2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ac2[r] = c2[(lq + 4 * r) * SM_LD + l15];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a2[(lq + 4 * r) * SM_LD + l15] = p2[r];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ac2 = P::mfma(-pj[ks], p2[ks], ac2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c2[(lq + 4 * r) * SM_LD + l15] = ac2[r];
       }
     }
     lds_barrier();
@@ -424,21 +459,36 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
   for (int blk = wave; blk < nblk; blk += SM_WAVES) {
     const int t = s.tb[blk], bi = t & 255, bj = t >> 8;
     acc_t a0 = acc_t{0, 0, 0, 0}, a1 = a0;
-    for (int k = bi; k < NB; ++k) {
-      const double *wa = Bk + sm_tri(k, bi), *wb = Bk + sm_tri(k, bj);
-      double fa[4], fb[4];
+    int k = bi;
+#if defined(SM_PROBE) && SM_PROBE == 2   // timing probe (wrong results): no W^T W products in the gradient phase
+    k = NB;
+#endif
+    for (; k + 1 < NB; k += 2) {   // two products per trip, operands read before the first MFMA, two accumulator chains
+      const double *wa = Bk + sm_tri(k, bi), *wb = Bk + sm_tri(k, bj), *wc = Bk + sm_tri(k + 1, bi), *wd = Bk + sm_tri(k + 1, bj);
+      double fa[4], fb[4], fc[4], fd[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         fa[ks] = wa[l15 * SM_LD + 4 * ks + lq];   // W(k,bi)[kk][m = l15]
         fb[ks] = wb[l15 * SM_LD + 4 * ks + lq];   // W(k,bj)[kk][n = l15]
+        fc[ks] = wc[l15 * SM_LD + 4 * ks + lq];
+        fd[ks] = wd[l15 * SM_LD + 4 * ks + lq];
       }
-      if ((k - bi) & 1) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) a1 = P::mfma(fa[ks], fb[ks], a1);
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) a0 = P::mfma(fa[ks], fb[ks], a0);
+      for (int ks = 0; ks < 4; ++ks) {
+        a0 = P::mfma(fa[ks], fb[ks], a0);
+        a1 = P::mfma(fc[ks], fd[ks], a1);
       }
+    }
+    if (k < NB) {
+      const double *wa = Bk + sm_tri(k, bi), *wb = Bk + sm_tri(k, bj);
+      double fa[4], fb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        fa[ks] = wa[l15 * SM_LD + 4 * ks + lq];
+        fb[ks] = wb[l15 * SM_LD + 4 * ks + lq];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a0 = P::mfma(fa[ks], fb[ks], a0);
     }
     const double wgt = (bi == bj) ? 1.0 : 2.0;
     const int gj = bj * DB + l15;
@@ -448,7 +498,12 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
       const int gi = bi * DB + lq + 4 * r;
       if (gi < N && gj < N) {
         double dq2[DMAX];
+#if defined(SM_PROBE) && SM_PROBE == 1   // timing probe (wrong results): no kernel evaluation in the gradient phase
+        double kv = s.xr[gi];
+        for (int q = 0; q < DMAX; ++q) dq2[q] = kv;
+#else
         const double kv = kern.eval(s.xr, d, NP, gi, gj, ec, dq2);
+#endif
         const double w = s.al[gi] * alj - (a0[r] + a1[r]);
         const double wk = wgt * w * kv;
         s_amp += wk;
@@ -484,26 +539,6 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
 #ifdef CGP_ABLATION
   if (tid == 0) s.sc[48 + 9] += 1.0;
 #endif
-}
-
-// d(-logML)/dtheta (natural parameters) from the sums; the host twin is grad_from_sums (cgp_engine.hip)
-__device__ __forceinline__ void sm_grad_from_sums(int kid, int d, const double *theta, const double *sums, double *grad) {
-  if (kid == K_SE_ISO) {
-    double se = 0;
-    for (int q = 0; q < d; ++q) se += sums[1 + q];
-    grad[0] = -0.5 * sums[0] / theta[0];
-    grad[1] = -0.5 * se / theta[1];
-    grad[2] = -0.5 * sums[9];
-  } else if (kid == K_SE_ARD) {
-    grad[0] = -0.5 * sums[0] / theta[0];
-    for (int q = 0; q < d; ++q) grad[1 + q] = -0.5 * sums[1 + q] / theta[1 + q];
-    grad[d + 1] = -0.5 * sums[9];
-  } else {
-    grad[0] = -0.5 * sums[0] / theta[0];
-    grad[1] = -0.5 * sums[1] / theta[1];
-    grad[2] = -0.5 * sums[0] / theta[2];
-    grad[3] = -0.5 * sums[9];
-  }
 }
 
 // Logexp (GPy paramz.transformations.Logexp): theta = log(1 + exp(x))
@@ -546,29 +581,271 @@ __device__ __forceinline__ void sm_constants(const SmallLds &s, int kid, int d, 
   }
 }
 
-// lane 0 after an evaluation: gradient from the sums, then either the L-BFGS step (OPT) or the outputs (EVAL).  Out of
-// line (its registers must not weigh on the evaluation's); its vectors live in LDS (s.red), not in scratch memory.
-__device__ __attribute__((noinline)) void sm_lane0_tell(const SmallLds &s, const SmallArgs &p, int kid, int d, int nth, double *ob) {
-  const bool ok = s.flag[0] == 0;
-  double *g = s.red, *gx = s.red + 16;   // [MAX_THETA] natural gradient, [LB_N] gradient wrt the Logexp variables
-  for (int i = 0; i < MAX_THETA; ++i) g[i] = 0.0;
-  if (ok) sm_grad_from_sums(kid, d, s.sc, s.sc + 24, g);
-  if (p.mode == SM_MODE_OPT) {
-    for (int i = 0; i < nth; ++i) gx[i] = g[i] * s.sc[36 + i];
-    s.lb->tell(ok ? -s.sc[22] : INFINITY, gx);
-    s.flag[1] = s.lb->done() ? 1 : 0;
+// ---- L-BFGS step on wave 0, one lane per parameter -------------------------------------------------------------------
+// lbfgs_core.hpp's state machine (same decisions, same state struct in LDS) with the vectors spread over the lanes:
+// lane j holds component j of x, g, the trial point and the direction in registers, dot products are four row-local
+// shuffles, and the history pairs are read from LDS once per pair instead of once per component.  On one lane the same
+// step was ~24 k cycles of dependent LDS round trips per evaluation; the decisions are wave-uniform (they derive from
+// the reduced scalars), so there is no divergence.  Sums run as a tree over the lanes instead of left to right: results
+// agree with the host stepper to rounding, not bitwise.
+__device__ __forceinline__ double lb_dot(double a, double b, bool on) {
+  double p = on ? a * b : 0.0;
+  p += __shfl_xor(p, 8);
+  p += __shfl_xor(p, 4);
+  p += __shfl_xor(p, 2);
+  p += __shfl_xor(p, 1);
+  return p;
+}
+__device__ __forceinline__ double lb_amax(double a, bool on) {
+  double p = on ? __builtin_fabs(a) : 0.0;
+  p = __builtin_fmax(p, __shfl_xor(p, 8));
+  p = __builtin_fmax(p, __shfl_xor(p, 4));
+  p = __builtin_fmax(p, __shfl_xor(p, 2));
+  p = __builtin_fmax(p, __shfl_xor(p, 1));
+  return p;
+}
+
+__device__ __attribute__((noinline)) void sm_lbfgs_tell_wave(corenav::LbfgsCore &c, double fv, double gv, int lane) {
+  using corenav::LB_M;
+  const int j = lane & 15, n = c.n;
+  const bool on = j < n, wr = lane < 16;
+  double xj = c.x[j], gj = c.g[j], xnj = c.xn[j], gnj = c.gn[j], dj = c.dir[j];
+  double f = c.f, fn = c.fn, dg0 = c.dg0, t = c.t, t_lo = c.t_lo, f_lo = c.f_lo, dg_lo = c.dg_lo, t_hi = c.t_hi, f_hi = c.f_hi,
+         t_prev = c.t_prev, f_prev = c.f_prev;
+  int hist = c.hist, ls = c.ls, iters = c.iters, have_hi = c.have_hi, first = c.first;
+  const int evals = c.evals + 1, max_evals = c.max_evals;
+  const double pgtol = c.pgtol, ftol = c.ftol;
+  bool do_start = false;
+  int fin = -1;
+  if (!__builtin_isfinite(fv)) fv = INFINITY;
+  if (first) {
+    first = 0;
+    f = fv;
+    gj = gv;
+    if (!__builtin_isfinite(f)) fin = 3;
+    else do_start = true;
   } else {
-    ob[SMO_LOGML] = s.sc[22];
-    ob[SMO_EVALS] = 1.0;
-    ob[SMO_STATUS] = 0.0;
-    ob[SMO_ITERS] = 0.0;
-    ob[SMO_INFO] = (double)s.flag[0];
-    ob[SMO_JITTER] = ok ? s.sc[21] : 0.0;
-    for (int i = 0; i < MAX_THETA; ++i) {
-      ob[SMO_GRAD + i] = g[i];
-      ob[SMO_THETA + i] = s.sc[i];
+    fn = fv;
+    gnj = gv;
+    // line search step (Nocedal & Wright alg. 3.5 / 3.6, c1 = 1e-4, c2 = 0.9)
+    const double c1 = 1e-4, c2 = 0.9;
+    const double tt = t;
+    const double dgn = __builtin_isfinite(fn) ? lb_dot(gnj, dj, on) : 0.0;
+    bool ok = false, give_up = false, again = false;
+    double tnew = 0.0;
+    if (!have_hi) {
+      if (fn > f + c1 * tt * dg0 || (ls > 0 && fn >= f_prev)) {
+        t_lo = t_prev;
+        f_lo = f_prev;
+        t_hi = tt;
+        f_hi = fn;
+        have_hi = 1;
+      } else if (__builtin_fabs(dgn) <= -c2 * dg0) {
+        ok = true;
+      } else if (dgn >= 0) {
+        t_hi = t_prev;
+        f_hi = f_prev;
+        t_lo = tt;
+        f_lo = fn;
+        dg_lo = dgn;
+        have_hi = 1;
+      } else {
+        t_prev = tt;
+        f_prev = fn;
+        dg_lo = dgn;
+        ++ls;
+        if (ls >= 30 || evals >= max_evals) give_up = true;
+        else {
+          again = true;
+          tnew = 2.0 * tt;
+        }
+      }
+    } else {
+      if (fn > f + c1 * tt * dg0 || fn >= f_lo) {
+        t_hi = tt;
+        f_hi = fn;
+      } else {
+        if (__builtin_fabs(dgn) <= -c2 * dg0) ok = true;
+        else {
+          if (dgn * (t_hi - t_lo) >= 0) {
+            t_hi = t_lo;
+            f_hi = f_lo;
+          }
+          t_lo = tt;
+          f_lo = fn;
+          dg_lo = dgn;
+        }
+      }
     }
-    s.flag[1] = 1;
+    if (!again && !ok && !give_up) {
+      ++ls;
+      const double lo = t_lo < t_hi ? t_lo : t_hi, hi = t_lo < t_hi ? t_hi : t_lo;
+      if (ls >= 30 || evals >= max_evals || __builtin_fabs(hi - lo) < 1e-16 * __builtin_fmax(1.0, __builtin_fabs(lo))) give_up = true;
+      else {
+        const double dt = t_hi - t_lo;  // quadratic interpolation, safeguarded by bisection
+        double tq = t_lo - 0.5 * dg_lo * dt * dt / (f_hi - f_lo - dg_lo * dt);
+        if (!__builtin_isfinite(tq) || tq <= lo + 0.1 * (hi - lo) || tq >= hi - 0.1 * (hi - lo)) tq = 0.5 * (lo + hi);
+        again = true;
+        tnew = tq;
+      }
+    }
+    if (again) {
+      t = tnew;
+      xnj = xj + tnew * dj;
+    } else {
+      if (!ok) {  // accept a sufficient-decrease point if the last trial is one, else stop
+        if (__builtin_isfinite(fn) && fn <= f + c1 * tt * dg0 && fn < f) ok = true;
+        else fin = evals >= max_evals ? 2 : 3;
+      }
+      if (ok) {   // accept the step
+        const double sj = xnj - xj, yj = gnj - gj;
+        const double sy = lb_dot(sj, yj, on), yy = lb_dot(yj, yj, on), fold = f;
+        xj = xnj;
+        gj = gnj;
+        f = fn;
+        ++iters;
+        if (sy > 1e-10 * yy) {
+          if (hist == LB_M) {  // drop the oldest pair
+            if (wr) {
+#pragma unroll
+              for (int i = 1; i < LB_M; ++i) {
+                c.S[i - 1][j] = c.S[i][j];
+                c.Y[i - 1][j] = c.Y[i][j];
+              }
+            }
+            if (lane == 0) {
+#pragma unroll
+              for (int i = 1; i < LB_M; ++i) c.rho[i - 1] = c.rho[i];
+            }
+            --hist;
+          }
+          if (wr) {
+            c.S[hist][j] = sj;
+            c.Y[hist][j] = yj;
+          }
+          if (lane == 0) c.rho[hist] = 1.0 / sy;
+          ++hist;
+        }
+        if ((fold - f) <= ftol * __builtin_fmax(__builtin_fmax(__builtin_fabs(fold), __builtin_fabs(f)), 1.0)) fin = 1;
+        else do_start = true;
+      }
+    }
+  }
+  if (do_start) {
+    if (lb_amax(gj, on) <= pgtol) fin = 0;
+    else if (evals >= max_evals) fin = 2;
+    else {
+      double q = gj, al[LB_M], sv[LB_M], yv[LB_M], rh[LB_M];   // two-loop recursion; every pair read from LDS once
+#pragma unroll
+      for (int i = 0; i < LB_M; ++i) {
+        const bool live = i < hist;
+        sv[i] = live ? c.S[i][j] : 0.0;
+        yv[i] = live ? c.Y[i][j] : 0.0;
+        rh[i] = live ? c.rho[i] : 0.0;
+      }
+#pragma unroll
+      for (int i = LB_M - 1; i >= 0; --i) {
+        if (i < hist) {
+          al[i] = rh[i] * lb_dot(sv[i], q, on);
+          q -= al[i] * yv[i];
+        } else al[i] = 0.0;
+      }
+      if (hist > 0) {
+        double sl = 0.0, yl = 0.0;
+#pragma unroll
+        for (int i = 0; i < LB_M; ++i) {
+          sl = (i == hist - 1) ? sv[i] : sl;
+          yl = (i == hist - 1) ? yv[i] : yl;
+        }
+        q *= lb_dot(sl, yl, on) / lb_dot(yl, yl, on);
+      }
+#pragma unroll
+      for (int i = 0; i < LB_M; ++i) {
+        if (i < hist) {
+          const double be = rh[i] * lb_dot(yv[i], q, on);
+          q += sv[i] * (al[i] - be);
+        }
+      }
+      dj = -q;
+      dg0 = lb_dot(gj, dj, on);
+      if (!(dg0 < 0)) {  // not a descent direction: restart from steepest descent
+        hist = 0;
+        dj = -gj;
+        dg0 = lb_dot(gj, dj, on);
+      }
+      t_lo = 0;
+      f_lo = f;
+      dg_lo = dg0;
+      t_hi = f_hi = 0;
+      have_hi = 0;
+      t_prev = 0;
+      f_prev = f;
+      ls = 0;
+      const double gm = lb_amax(gj, on);
+      t = iters == 0 ? __builtin_fmin(1.0, 1.0 / __builtin_fmax(gm, 1e-300)) : 1.0;
+      xnj = xj + t * dj;
+    }
+  }
+  if (fin >= 0) xnj = xj;
+  if (wr) {
+    c.x[j] = xj;
+    c.g[j] = gj;
+    c.xn[j] = xnj;
+    c.gn[j] = gnj;
+    c.dir[j] = dj;
+  }
+  if (lane == 0) {
+    c.f = f; c.fn = fn; c.dg0 = dg0; c.t = t; c.t_lo = t_lo; c.f_lo = f_lo; c.dg_lo = dg_lo; c.t_hi = t_hi; c.f_hi = f_hi;
+    c.t_prev = t_prev; c.f_prev = f_prev;
+    c.hist = hist; c.ls = ls; c.iters = iters; c.have_hi = have_hi; c.first = first; c.evals = evals;
+    if (fin >= 0) {
+      c.status = fin;
+      c.finished = 1;
+    }
+  }
+}
+
+// Wave 0 after an evaluation, one lane per parameter: the gradient component from the sums (the host twin is
+// grad_from_sums, cgp_engine.hip), then either the L-BFGS step (OPT) or the outputs (EVAL).
+__device__ __forceinline__ void sm_wave0_tell(const SmallLds &s, const SmallArgs &p, int kid, int d, int nth, double *ob, int lane) {
+  const bool ok = s.flag[0] == 0;
+  const int j = lane & 15;
+  const double *sums = s.sc + 24;
+  double num = 0.0, den = 1.0;   // d(-logML)/dtheta_j = -0.5 num / den
+  if (j < nth) {
+    if (j == nth - 1) num = sums[9];
+    else if (j == 0) {
+      num = sums[0];
+      den = s.sc[0];
+    } else if (kid == K_SE_ISO) {
+      for (int q = 0; q < d; ++q) num += sums[1 + q];
+      den = s.sc[1];
+    } else if (kid == K_SE_ARD) {
+      num = sums[j];
+      den = s.sc[j];
+    } else {   // RBF x Brownian: theta = (sigma_r^2, ell, sigma_b^2, sigma_n^2); both amplitudes scale K
+      num = j == 1 ? sums[1] : sums[0];
+      den = s.sc[j];
+    }
+  }
+  const double g = ok && j < nth ? -0.5 * num / den : 0.0;
+  if (p.mode == SM_MODE_OPT) {
+    sm_lbfgs_tell_wave(*s.lb, ok ? -s.sc[22] : INFINITY, g * s.sc[36 + j], lane);
+    if (lane == 0) s.flag[1] = s.lb->finished ? 1 : 0;
+  } else {
+    if (lane < MAX_THETA) {
+      ob[SMO_GRAD + lane] = g;
+      ob[SMO_THETA + lane] = s.sc[lane];
+    }
+    if (lane == 0) {
+      ob[SMO_LOGML] = s.sc[22];
+      ob[SMO_EVALS] = 1.0;
+      ob[SMO_STATUS] = 0.0;
+      ob[SMO_ITERS] = 0.0;
+      ob[SMO_INFO] = (double)s.flag[0];
+      ob[SMO_JITTER] = ok ? s.sc[21] : 0.0;
+      s.flag[1] = 1;
+    }
   }
 }
 
@@ -649,7 +926,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small(SmallArgs p) {
       ck.start();
     }
     ck.start();
-    if (tid == 0) sm_lane0_tell(s, p, kid, d, nth, ob);
+    if (tid < 64) sm_wave0_tell(s, p, kid, d, nth, ob, tid);
     ck.lap(s.sc, 8, tid);
     __syncthreads();
     if (s.flag[1]) break;

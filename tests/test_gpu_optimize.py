@@ -152,3 +152,44 @@ def test_gradient_mode_on_the_mid_size_schedule(engine, B):
     for b in (0, B - 1):
         t1, l1, n1 = one.optimize(X[b], y[b], 1, th[b], max_evals=6)
         assert lml2[b] == pytest.approx(l1, rel=1e-8) and np.allclose(th2[b], t1, rtol=1e-6)
+
+
+def test_short_window_kernel_matches_the_large_window_machinery(engine):
+    """Windows of at most 160 samples take the one-launch kernel (csrc/cgp_small.hpp: Gram, Cholesky, inverse, gradient
+    sums, jitter ladder and the L-BFGS loop inside one workgroup); CGP_SMALL=off keeps the large-window machinery for them
+    (seven launches per evaluation, L-BFGS on the host).  Same objective, same optimiser, different summation orders: the
+    two must agree far inside the parity bar on an evaluation and to the optimiser's own tolerance on the optimum."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import json, numpy as np, torch\n"
+        "import corenav_gp_amd.engine as e\n"
+        "from tests.conftest import load_golden\n"
+        "from oracle import gp_oracle as go\n"
+        "g = load_golden('slipval_window_rbfbrownian')\n"
+        "X, Y, xtr, ytr = go.slip_node_split(g['time_array'], g['slip_array'])\n"
+        "ctx = e.Context(max_n=256, max_m=1024, max_d=1)\n"
+        "nll, gr = ctx.nll_grad(xtr, ytr[:, 0], 2, np.array([0.7, 12.0, 0.03, 0.02]))\n"
+        "th, lml, nev = ctx.optimize(xtr, ytr[:, 0], 2, np.ones(4))\n"
+        "m, s, th2 = ctx.slip_node_callback_opt(g['time_array'], g['slip_array'], np.ones(4))\n"
+        "print(json.dumps({'nll': nll, 'grad': gr.tolist(), 'theta': th.tolist(), 'lml': lml, 'nev': nev, 'mean': m.tolist(),"
+        " 'sigma': s.tolist(), 'theta2': th2.tolist()}))\n")
+    out = {}
+    for mode in ("on", "off"):
+        env = dict(os.environ, CGP_SMALL=mode, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mode] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = out["on"], out["off"]
+    assert a["nll"] == pytest.approx(b["nll"], rel=1e-10)
+    np.testing.assert_allclose(a["grad"], b["grad"], rtol=1e-7, atol=1e-9 * np.max(np.abs(b["grad"])))
+    # the optimum: both stop on the same criteria; theta agrees to the optimiser's resolution, logML much tighter
+    assert a["lml"] == pytest.approx(b["lml"], rel=1e-7)
+    np.testing.assert_allclose(a["theta"], b["theta"], rtol=2e-3)
+    np.testing.assert_allclose(a["theta2"], a["theta"], rtol=1e-12)      # the fused callback runs the same optimisation
+    np.testing.assert_allclose(a["mean"], b["mean"], rtol=0, atol=2e-3 * np.max(np.abs(b["mean"])))
+    np.testing.assert_allclose(a["sigma"], b["sigma"], rtol=2e-3)
+    assert abs(a["nev"] - b["nev"]) <= 6
