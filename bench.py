@@ -58,7 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="contexts (slab sets) the steps are dealt over, one HIP stream each, so that successive calls too small "
-                         "to fill the chip overlap on the GPU; 0 = auto: 2 for --scaling strong with <= 128 fits per rank, else 1")
+                         "to fill the chip overlap on the GPU (cross-sweep overlap: a throughput-of-repeated-sweeps figure, not the "
+                         "speed-up of one sweep); 0 = 1, the single-context figure")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch fits per GPU and step; strong: --batch fits per step over ALL ranks (contiguous shards)")
     return ap.parse_args(argv)
@@ -197,7 +198,7 @@ def run_rank(args):
     _, N, d = X.shape
     peak = FP64_MFMA_PEAK_TFLOPS if dts == "f64" else FP32_MFMA_PEAK_TFLOPS
     ablation = False
-    depth = args.pipeline if args.pipeline > 0 else (2 if strong and B <= 128 else 1)
+    depth = args.pipeline if args.pipeline > 0 else 1
     if not dry:
         W = Workload(engine, torch, dev, local, kid, X, y, Xs, th, dts, args.streams)
         ablation = bool(engine.load().cgp_build_flags() & engine.BUILD_ABLATION) and bool(os.environ.get("CGP_DBG"))
@@ -264,6 +265,13 @@ def run_rank(args):
     ens = sharding.ensemble_stats(table)
     assert table.shape[0] == B_total
 
+    # A plain `bench.py --gpus N` (weak scaling of the headline) also carries BASELINE configs[2] AS WRITTEN -- 512 x N=1024
+    # fp32 fits cut into contiguous per-rank shards, ONE context per GPU -- so that a driver-run scaling sweep shows the
+    # strong-scaling curve of the sharded batch next to the weak-scaling headline (config.extra.cfg3_strong).
+    cfg3_strong = None
+    if world > 1 and not strong and not args.no_extra and args.config == 2:
+        cfg3_strong = cfg3_strong_line(args, dry, world, rank, local, dev, cdev, use_dist, sync)
+
     if rank == 0:
         fits = B_total * args.steps
         f_chol, f_fit = fit_flops(N, d, M_TEST)
@@ -285,6 +293,8 @@ def run_rank(args):
         }
         if dry:
             out["dry_run"] = True
+            if cfg3_strong is not None:
+                out["config"].setdefault("extra", {})["cfg3_strong"] = cfg3_strong
         if ablation:
             out["ablation_build"] = True   # CGP_DBG in a -DCGP_ABLATION library: NOT a measurement of the product
         if not dry:
@@ -302,6 +312,8 @@ def run_rank(args):
                     ex3["cfg3_cpu_baseline"] = {k: cb3[k] for k in ("value", "unit", "cores", "kind", "sample")}
                     ex3["cfg3_max_rel_err_vs_oracle"] = cb3["gpu_vs_oracle_max_rel_err"]
                 out["config"]["extra"].update(ex3)
+            if cfg3_strong is not None:
+                out["config"].setdefault("extra", {})["cfg3_strong"] = cfg3_strong
             if world == 1 and not args.no_pmc and not ablation:
                 live = pmc_traffic_live(args)      # last: everything above is already measured if a pass misbehaves
                 if live is not None:
@@ -311,6 +323,51 @@ def run_rank(args):
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cfg3_strong_line(args, dry, world, rank, local, dev, cdev, use_dist, sync, total=512, steps=20):
+    """BASELINE configs[2] as written on the ranks of this job: `total` N=1024 fp32 fits per step in contiguous per-rank
+    shards (sharding.shard_range), one context per GPU, steps back to back, barrier + synchronise either side, MAX over
+    ranks.  Returned by every rank; rank 0 reports it."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import corenav_gp_amd.synth as synth
+    from corenav_gp_amd import sharding
+    b0, b1 = sharding.shard_range(total, rank, world)
+    B = b1 - b0
+    if dry:
+        def step():
+            time.sleep(0.001)
+    else:
+        import corenav_gp_amd.engine as engine
+        kid, X, y, Xs, th, dts = synth.config(3, batch=B, M=M_TEST, first=b0)
+        W3 = Workload(engine, torch, dev, local, kid, X, y, Xs, th, dts, 1)
+        step = W3.step
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.1:   # working clock
+            step()
+            sync()
+    if use_dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if use_dist:
+        dist.barrier()
+    sync()
+    dt = torch.tensor([time.perf_counter() - t0], device=cdev, dtype=torch.float64)
+    if use_dist:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if not dry:
+        assert int(W3.dinfo.abs().sum().item()) == 0
+    el = float(dt.item()) / steps
+    return {"fits_per_s": total / el, "ms_per_step": el * 1e3, "fits_per_step_all_ranks": total, "fits_per_gpu_per_call": total / world,
+            "n_gpus": world, "scaling": "strong", "pipeline_depth": 1, "steps": steps,
+            "workload": f"BASELINE configs[2] as written: {total} x N=1024 d=6 SE-ARD fp32, M={M_TEST}, sharded over {world} ranks, "
+                        "one context per GPU; divide by config.extra.cfg3_fits_per_s of the --gpus 1 line for the speed-up"}
 
 
 class Workload:
@@ -549,6 +606,10 @@ def extras_cfg3(engine, torch, dev, local, W):
             ex["cfg3_roofline_frac"] = rf["frac"]
             ex["cfg3_kernel_ms_per_step"] = kms
             ex["cfg3_workload"] = "BASELINE configs[2]: 512 x N=1024 d=6 SE-ARD fp32, M=599, one GPU's view of the sweep"
+            ex["cfg3_strong"] = {"fits_per_s": 512 / el, "ms_per_step": el * 1e3, "fits_per_step_all_ranks": 512, "fits_per_gpu_per_call": 512,
+                                 "n_gpus": 1, "scaling": "strong", "pipeline_depth": 1, "steps": 5,
+                                 "workload": "BASELINE configs[2] as written on ONE rank (the denominator of the strong-scaling curve; "
+                                             "`bench.py --gpus N` reports the same key over N ranks)"}
             # configs[2] AS WRITTEN shards the 512 fits over 8 GPUs: 64 fits per GPU and call.  The same engine on the
             # first 64 windows (its mid-size schedule), and what 8 such GPUs would make of the 1-GPU rate above -- a
             # projection from this GPU's two rates (no collective on the data path), not a measurement of 8 GPUs.
@@ -588,6 +649,8 @@ def extras_cfg3(engine, torch, dev, local, W):
             assert torch.equal(W64.dmean, W64b.dmean) and torch.equal(W64.dlogml, W64b.dlogml)
             ex["cfg3_fits_per_s_at_64_pipelined2"] = 64 / el64p
             ex["cfg3_strong_scaling_projection_8gpu_pipelined2"] = 8 * (64 / el64p) / (512 / el)
+            ex["cfg3_pipelined2_note"] = ("two successive sweeps' 64-fit calls overlapped on two contexts per GPU: throughput of REPEATED sweeps "
+                                          "(cross-sweep overlap), not the speed-up of one 512-fit sweep -- that is cfg3_strong_scaling_projection_8gpu")
             del W64, W64b
             # for the CPU leg (the only place of this program that may run the oracle): inputs and the timed outputs
             ex["_cpu_leg"] = (kid, X, y, Xs, th, W3.dmean, W3.dvar, W3.dlogml, fit_flops(1024, 6, M_TEST)[1])

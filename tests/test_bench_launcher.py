@@ -32,6 +32,10 @@ def test_gpus2_spawns_two_ranks():
     assert j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
     # whole-job value = fits of all ranks / max-over-ranks time
     assert j["value"] <= sum(j["config"]["per_rank_fits_per_s"]) * 1.001
+    # a plain multi-rank run also carries BASELINE configs[2] as written (strong scaling, one context per GPU)
+    c3 = j["config"]["extra"]["cfg3_strong"]
+    assert c3["n_gpus"] == 2 and c3["scaling"] == "strong" and c3["pipeline_depth"] == 1 and c3["fits_per_step_all_ranks"] == 512
+    assert c3["fits_per_gpu_per_call"] == 256 and c3["fits_per_s"] > 0
 
 
 def test_world_size_must_match_gpus():
@@ -53,6 +57,7 @@ def test_strong_scaling_shards_the_total():
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["config"]["ensemble"]["n"] == 9
+    assert j["config"]["pipeline_depth"] == 1      # the single-context figure is the default; --pipeline 2 is cross-sweep overlap
     assert j["config"]["fits_per_step_all_ranks"] == 9 and j["config"]["fits_per_gpu_per_step"] == 4.5
     # per-rank rates are in the ratio of the shard sizes (5 : 4) up to timing noise, and sum to about the whole-job value
     a, b = j["config"]["per_rank_fits_per_s"]

@@ -53,6 +53,7 @@ def test_bench_extra_lines():
     assert 0 < ex["node_callback_us"] < 5000 and 0 < ex["node_callback_opt_ms"] < 500   # the reference node's own work item
     # configs[2] as written (64 fits per GPU at 8 GPUs): the 64-fit call rate and the projection from this GPU's two rates
     assert ex["cfg3_fits_per_s_at_64"] > 0 and 0 < ex["cfg3_strong_scaling_projection_8gpu"] <= 8.5
+    assert ex["cfg3_strong"]["n_gpus"] == 1 and ex["cfg3_strong"]["fits_per_s"] == ex["cfg3_fits_per_s"]
 
 
 def test_bench_live_pmc_traffic():
@@ -87,6 +88,8 @@ def test_bench_gpus2_on_one_gpu():
     assert j["n_gpus"] == 2 and j["config"]["ranks"] == 2 and len(j["config"]["per_rank_fits_per_s"]) == 2
     assert j["config"]["ensemble"]["n"] == 32 and j["config"]["ensemble"]["n_failed"] == 0
     assert "cpu_baseline" not in j and j["roofline"]["frac"] > 0
+    c3 = j["config"]["extra"]["cfg3_strong"]   # BASELINE configs[2] as written over the same ranks (256 fits per rank and call here)
+    assert c3["n_gpus"] == 2 and c3["fits_per_gpu_per_call"] == 256 and c3["pipeline_depth"] == 1 and c3["fits_per_s"] > 0
 
 
 def test_bench_strong_scaling_two_ranks_on_one_gpu():
