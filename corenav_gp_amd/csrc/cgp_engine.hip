@@ -73,6 +73,10 @@ struct cgp_ctx {
   void *ddiagimg = nullptr;  // [max_batch][2][DPART] pre-updated diagonal tiles (throughput schedule, diag_next)
   void *dpanimg = nullptr;   // [min(max_batch, mid cap)][2][DPART] pre-updated kind-A panel tiles (k_panel kind C)
   int mid_cap = 0;
+  // one-launch schedule of a mid-size call (k_sched): task list of the last (fits, NT, ET) shape, flag words, one image slot per tile index
+  void *dsched_tasks = nullptr, *dsched_flags = nullptr, *dsched_bimg = nullptr, *dsched_cimg = nullptr;
+  size_t sched_tasks_cap = 0, sched_flags_cap = 0, sched_bimg_cap = 0, sched_cimg_cap = 0;
+  int sched_key[3] = {0, 0, 0}, sched_ntasks = 0, sched_grid = 0, n_cu = 0;
   // cgp_fit_predict_batch staging, grown on demand and kept: pinned host buffers (hipHostMalloc) so the
   // H2D / D2H copies are real asynchronous DMA, and a raw fp64 device buffer the pack kernels read
   void *pin_in = nullptr, *pin_out = nullptr, *draw = nullptr;
@@ -116,6 +120,8 @@ struct cgp_ctx {
 namespace {
 
 int ensure_fitted(cgp_ctx *c);   // below, with the short-window paths
+bool grow_pinned(void *&p, size_t &cap, size_t bytes);
+bool grow_device(void *&p, size_t &cap, size_t bytes);
 
 inline int ntheta(int kid, int d) { return kid == CGP_KERNEL_SE_ISO ? 3 : (kid == CGP_KERNEL_SE_ARD ? d + 2 : 4); }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -251,6 +257,9 @@ template <typename T> int set_lds_attrs(int device) {
   ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T>), paneldiag_lds_bytes<T>());
   ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true>), paneldiag_lds_bytes<T>());
   ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, true>), paneldiag_mid_lds_bytes<T>());
+#ifdef CGP_AB
+  ok = ok && set(reinterpret_cast<const void *>(&k_sched<T>), paneldiag_mid_lds_bytes<T>());
+#endif
   if constexpr (mid_fat<T, true>()) ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T, true>), paneldiag_mid_lds_bytes<T>());
   if constexpr (CGP_F32_FULL_DEEP && sizeof(T) == 4) ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, false>), paneldiag_lds_bytes<T>());
 #ifdef CGP_AB
@@ -393,6 +402,83 @@ template <typename T> void launch_diag(const FitArgs &a, int nfits, int k, bool 
   hipLaunchKernelGGL(k_diag_lean<T>, dim3(nfits), dim3(256), paneldiag_lds_bytes<T>(), s, a, k);
 }
 
+// A mid-size fit call as ONE persistent launch (k_sched, cgp_kernels_fused.hpp): the tile programs of the NT + 1 launches
+// become tasks of a list ordered by block step; per-fit progress counters replace the launch boundaries.  Bitwise the
+// launches' results; measured slower than them (round 4), so it exists in the -DCGP_AB library only.
+bool sched_enabled() {   // measurement builds only (-DCGP_AB), CGP_SCHED=onelaunch: as measured it does not beat the launches
+  if constexpr (!kAbBuild) return false;
+  static const bool on = [] {
+    const char *e = getenv("CGP_SCHED");
+    return e && std::string(e) == "onelaunch";
+  }();
+  return on;
+}
+#ifdef CGP_AB
+template <typename T>
+int run_sched(cgp_ctx *c, FitArgs a, int batch, hipStream_t s) {
+  const int NT = a.NT, ET = a.ET;
+  if (c->sched_key[0] != batch || c->sched_key[1] != NT || c->sched_key[2] != ET) {
+    std::vector<int4> tasks;
+    auto put = [&](int kind, int k, int b, int rt) { tasks.push_back(make_int4(kind, k, b, rt)); };
+    // Order: by block step; inside a step the chain first (A, then the pre-updates C and B), then the matrix rows' tiles (the
+    // next step's chain reads them), and only then the EXTRA rows' tiles of the step BEFORE -- they feed nothing but their own
+    // next block column, so they lag one step behind and fill in beside the chain.  CGP_SCHED_LAG=0: no lag (measurement).
+    static const int lag = [] { const char *e = getenv("CGP_SCHED_LAG"); return e ? atoi(e) : 1; }();
+    auto extra = [&](int k) {
+      for (int e = 0; e < ET; ++e)
+        for (int b = 0; b < batch; ++b) put(SCHED_T, k, b, NT + e);
+    };
+    for (int k = 0; k < NT; ++k) {
+      if (k + 1 < NT) for (int b = 0; b < batch; ++b) put(SCHED_A, k, b, k + 1);
+      if (k + 2 < NT) for (int b = 0; b < batch; ++b) put(SCHED_C, k, b, k + 2);
+      if (k + 2 < NT && k >= 1) for (int b = 0; b < batch; ++b) put(SCHED_B, k, b, k + 2);
+      for (int rt = k + 2; rt < NT; ++rt)
+        for (int b = 0; b < batch; ++b) put(SCHED_T, k, b, rt);
+      if (k - lag >= 0) extra(k - lag);
+    }
+    for (int k = std::max(0, NT - lag); k < NT; ++k) extra(k);
+    if (!grow_device(c->dsched_tasks, c->sched_tasks_cap, tasks.size() * sizeof(int4))) return CGP_ENOMEM;
+    HIP_TRY(c, hipMemcpyAsync(c->dsched_tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));   // `tasks` is a local (once per shape)
+    c->sched_ntasks = (int)tasks.size();
+    c->sched_key[0] = batch;
+    c->sched_key[1] = NT;
+    c->sched_key[2] = ET;
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_sched<T>, 256, paneldiag_mid_lds_bytes<T>()));
+    c->sched_grid = std::max(1, std::min(c->sched_ntasks, std::max(1, occ) * std::max(1, c->n_cu)));
+  }
+  const int pstride = c->NTmax + c->ETmax, fstride = c->NTmax + 2;
+  const size_t nflag = 2 + (size_t)batch * (pstride + 1 + 2 * fstride);
+  const size_t img_bytes = (size_t)batch * c->NTmax * DPART * sizeof(T);
+  if (!grow_device(c->dsched_flags, c->sched_flags_cap, nflag * sizeof(int)) || !grow_device(c->dsched_bimg, c->sched_bimg_cap, img_bytes) ||
+      !grow_device(c->dsched_cimg, c->sched_cimg_cap, img_bytes))
+    return CGP_ENOMEM;
+  HIP_TRY(c, hipMemsetAsync(c->dsched_flags, 0, nflag * sizeof(int), s));
+  int *fl = static_cast<int *>(c->dsched_flags);
+  SchedArgs q{};
+  q.tasks = static_cast<const int4 *>(c->dsched_tasks);
+  q.ntasks = c->sched_ntasks;
+  q.head = fl;
+  q.abort = fl + 1;
+  q.prog = fl + 2;
+  q.prog_stride = pstride;
+  q.wdone = q.prog + (size_t)batch * pstride;
+  q.bflag = q.wdone + batch;
+  q.cflag = q.bflag + (size_t)batch * fstride;
+  q.flag_stride = fstride;
+  a.dpart = c->dsched_bimg;
+  a.pimg = c->dsched_cimg;
+  a.img_slots = c->NTmax;
+  a.diag_slots = 0;
+  a.diag_stride = 0;
+  hipLaunchKernelGGL(k_sched<T>, dim3(c->sched_grid), dim3(256), paneldiag_mid_lds_bytes<T>(), s, a, q);
+  return CGP_OK;
+}
+#else
+template <typename T> int run_sched(cgp_ctx *, FitArgs, int, hipStream_t) { return CGP_EINVAL; }
+#endif
+
 // Enqueue the whole schedule for `batch` fits.  The batch is cut into up to c->nstreams contiguous
 // groups, one worker stream each, forked from / joined to the caller's stream `s` with events; the
 // launches are issued step-interleaved so every stream always has work queued.
@@ -409,7 +495,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // diagonal tile's pre-update images (N <= 2560); anything else takes the throughput schedule
   const bool latency = !sw.no_latency && batch <= std::min(lat_fits<T>(a.NT), c->lat_cap) && a.NT >= CGP_LAT_MIN_NT && lat_images(a.NT - 1) <= LAT_IMG_MAX;
   const bool mid = batch <= std::min(mid_fits<T>(a.NT), c->mid_cap);  // the whole call (the images are indexed by fit)
-  if (latency || mid) G = 1;  // a mid-size call has its own concurrency (factorisation || extra rows, below)
+  if (latency || (mid && !(kAbBuild && getenv("CGP_MID_GROUPS")))) G = 1;  // a mid-size call has its own concurrency (factorisation || extra rows, below); -DCGP_AB + CGP_MID_GROUPS: measurement
   std::vector<FitArgs> ga(G);
   std::vector<int> gb(G);
   std::vector<hipStream_t> gs(G);
@@ -441,6 +527,15 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     }
   }
   const int panel_lds = panel_lds_bytes<T>();
+  if (mid && !latency && in_rows && !c->prof && a.NT >= 2 && sched_enabled() && !sw.split_diag && !sw.overlap) {
+    launch_diag<T>(ga[0], batch, 0, sw.fat_diag, s, true);   // diagonal tile 0: nothing to run beside it yet
+    int rc = run_sched<T>(c, ga[0], batch, s);
+    if (rc != CGP_OK) return rc;
+    hipLaunchKernelGGL((k_finalize<T, 64>), dim3(cdiv(a.M, 64) + 1, batch), dim3(256), 0, s, ga[0], 1);
+    if (want_alpha) hipLaunchKernelGGL(k_alpha<T>, dim3(batch), dim3(256), alpha_lds_bytes(a.NT), s, ga[0]);
+    HIP_TRY(c, hipGetLastError());
+    return CGP_OK;
+  }
 #ifdef CGP_AB
   if (sw.overlap && in_rows && G == 1 && !c->prof && a.NT >= 2) {
     // Look-ahead schedule on two streams: the panel launch of step k is cut into P1 = the tile right
@@ -767,6 +862,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) return nullptr;
   if ((dtype == CGP_F64 ? set_lds_attrs<double>(device) : set_lds_attrs<float>(device)) != 0) return nullptr;
   cgp_ctx *c = new cgp_ctx();
+  c->n_cu = prop.multiProcessorCount;
   c->device = device;
   c->dtype = dtype;
   c->esz = dtype == CGP_F64 ? 8 : 4;
@@ -866,6 +962,8 @@ void cgp_destroy(cgp_ctx *c) {
   if (c->pin_in) (void)hipHostFree(c->pin_in);
   if (c->pin_out) (void)hipHostFree(c->pin_out);
   if (c->draw) (void)hipFree(c->draw);
+  for (void *sb : {c->dsched_tasks, c->dsched_flags, c->dsched_bimg, c->dsched_cimg})
+    if (sb) (void)hipFree(sb);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -73,6 +73,7 @@ struct FitArgs {
   int diag_slots;        // k_panel<T, true>: 1 = the launch finishes diagonal tile k+1, 2 = pre-updates tile k+2,
                          // 4 = pre-updates the next launch's kind-A tile (k+2, k+1), 8 = kind A starts from that image
   int diag_stride;       // k_panel<T, true>: workgroups per CU (one block of 256 ids in `stride` holds the finishers)
+  int img_slots;         // register-image slots per fit in dpart / pimg: 0 = 2 (by parity of the tile index), else one per tile index (k_sched)
   int xid;               // 1: the M (= N) "test rows" are the identity, so the extra block becomes (L^-1)^T (gradient mode)
   double *gpart;         // [batch][pairs][GRAD_N] per-tile-pair partial sums of k_grad
   long long *dbgbuf;     // 64 slots of s_memtime stamps / per-phase cycle sums (-DCGP_ABLATION builds)

@@ -768,6 +768,10 @@ __device__ __forceinline__ void diag_factor_packed(const FitArgs &p, T *__restri
 // so every dependency of the diagonal tile crosses a launch boundary except the workgroup's own tile,
 // which it fences.  DIAG_FULL is the whole thing in one go (k_diag_lean: step 0, A/B schedules).
 enum { DIAG_FULL = 0, DIAG_PARTIAL = 1, DIAG_FINISH = 2 };
+// Register images of pre-updated tiles are kept by parity of the tile index (2 slots per fit: a slot is rewritten two
+// launches after it was read, the launch boundaries order that) -- or, one-launch schedule (k_sched), one slot per tile
+// index: every address is then written once per call.
+__device__ __forceinline__ int img_slots(const FitArgs &p) { return p.img_slots > 0 ? p.img_slots : 2; }
 constexpr bool kTriDiag = true;  // diagonal tile: only its lower 16x16 blocks are updated (9 of 16 MFMA tiles per k-step)
 constexpr int DPART = 2 * NCB * 4 * 256;  // elements of one register image: 64 accumulator values x 256 threads
 
@@ -819,7 +823,7 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
   const int c_last = (MODE == DIAG_PARTIAL ? kn - 2 : kn) * (TS / KT);
   const int nchunk = c_last - c_first;
   const T *gR = Lw + (size_t)kn * TS + (size_t)c_first * KT * ld;
-  T *img = reinterpret_cast<T *>(p.dpart) + ((size_t)b * 2 + (kn & 1)) * DPART;
+  T *img = reinterpret_cast<T *>(p.dpart) + ((size_t)b * img_slots(p) + kn % img_slots(p)) * DPART;
   {
     GramPre<T> gp;
     if (!from_image) gram_prefetch<T>(p, b, kn, kn, tid, gp);
@@ -1030,7 +1034,108 @@ __device__ __forceinline__ void panel_partial(const FitArgs &p, typename Prec<T>
     gram_apply<T>(p, acc, smem + CH2, b, kc, rt, tid, gp);
     mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
   }
-  acc_image<T, false, true>(acc, reinterpret_cast<T *>(p.pimg) + ((size_t)b * 2 + (kc & 1)) * DPART, tid);
+  acc_image<T, false, true>(acc, reinterpret_cast<T *>(p.pimg) + ((size_t)b * img_slots(p) + kc % img_slots(p)) * DPART, tid);
+}
+
+template <typename T, bool MID> constexpr bool mid_fat() { return MID && sizeof(T) == 4; }
+// One tile of block step k: L(rt, k) = (G(rt,k) - sum_{c_first*16 <= col < 128 k} L(rt,:) L(k,:)^T [+ image]) W_k^T, stored; then, kind A
+// (finish_next), the next diagonal tile.  The body of k_panel after its role decode -- also what a tile task of the
+// one-launch schedule (k_sched) runs.
+template <typename T, bool DIAGNEXT, bool DEEP, bool MID>
+__device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, int rt, int c_first, bool finish_next, bool from_image,
+                                                T *smem, int tid) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
+  acc_t acc[NCB][2];
+  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const int ld = p.ld;
+  PhaseClock pc;
+  pc.start(p, tid);
+  const int ps = finish_next ? 336 : 64 + 8 * (k & 31);  // debug slots of this step (kind A: its own group, all steps summed)
+
+  // Gram first: acc = -G(rt, kc) while nothing else is live in the register file, with chunk 0 of the
+  // panels already in flight into LDS buffer 0 (the Gram inputs are staged in buffer 1's space).
+  constexpr int CH2 = 2 * KT * LDST;
+  const T *gR = Lw + (size_t)rt * TS + (size_t)(c_first * KT) * ld, *gC = Lw + (size_t)k * TS + (size_t)(c_first * KT) * ld;
+  // timing probes (wrong results): 4096 = every tile reads fit (b & 7)'s first row panel (L2-resident row
+  // panels), 8192 = the same for the column panel
+  if (CGP_DBG_ON(p, 4096)) gR = reinterpret_cast<const T *>(p.Lw) + (size_t)(b & 7) * p.lw_stride + (size_t)p.NT * TS;
+  if (CGP_DBG_ON(p, 8192)) gC = reinterpret_cast<const T *>(p.Lw) + (size_t)(b & 7) * p.lw_stride + (size_t)k * TS;
+  const int nchunk = k * (TS / KT) - c_first;
+  const T *pimg = reinterpret_cast<const T *>(p.pimg) + ((size_t)b * img_slots(p) + k % img_slots(p)) * DPART;  // image of tile (k + 1, k)
+  // running predictive sums (extra tiles, throughput schedule): z of the newest block column
+  // (k - 1) goes to LDS behind the chunk ring; zeros when nothing is to be accumulated
+  const bool accm = p.macc != nullptr && rt >= p.NT && k > 0;
+  T *zs = smem + 4 * KT * LDST;
+  if (tid < TS) zs[tid] = accm ? Lw[(size_t)((k - 1) * TS + tid) * ld + (size_t)p.NT * TS + p.M] : T(0);
+  T ms[4] = {T(0), T(0), T(0), T(0)};
+  if constexpr (DEEP) {
+    RowFrag<T> rf;
+    {
+      GramPre<T> gp;
+      if (!(MID && from_image)) gram_prefetch<T>(p, b, k, rt, tid, gp);
+      rdirect_prologue<T>(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+      if (MID && from_image) acc_image<T, false, false>(acc, const_cast<T *>(pimg), tid);
+      else gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
+    }
+    pc.lap(p, ps + 0);
+    mfma_rowpanel_loop_rdirect<T>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
+  } else {
+    {
+      GramPre<T> gp;
+      if (!(MID && from_image)) gram_prefetch<T>(p, b, k, rt, tid, gp);
+      if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
+      if (CGP_DBG_ON(p, 16384)) {  // timing probe: no Gram tile
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[cb][j][r] = gp.v[0];
+      } else if (MID && from_image) acc_image<T, false, false>(acc, const_cast<T *>(pimg), tid);
+      else gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
+    }
+    pc.lap(p, ps + 0);
+    mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, accm ? zs : nullptr, ms);
+  }
+  pc.lap(p, ps + 1);
+  if (accm) {
+    // a row's 128 columns are spread over the four 16-lane groups: fold them, then the lanes of
+    // group 0 add to the fit's accumulators (this workgroup is the only writer of its rows)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ms[q] += __shfl_xor(ms[q], 16);
+      ms[q] += __shfl_xor(ms[q], 32);
+    }
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = (rt - p.NT) * TS + wave * 32 + 2 * lane + j;
+        if (m < p.M) {
+          // agent-scope accesses: neighbouring rows' sums share cache lines with other workgroups' rows, and in the one-launch
+          // schedule the previous block step's writer of THIS row may have run on another XCD (whose L2 is not coherent with ours)
+          double *pm = p.macc + (size_t)b * p.M + m, *pv = p.vacc + (size_t)b * p.M + m;
+          const double om = __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double ov = __hip_atomic_load(pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(pm, om + (double)ms[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(pv, ov + (double)ms[2 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+  __syncthreads();  // every wave is done with the staged inputs before W_k overwrites them
+  pc.lap(p, ps + 2);
+  if (!CGP_DBG_ON(p, 64)) trmm_in_registers<T>(p, acc, smem, b, k, tid, &pc, ps + 3);
+  pc.lap(p, ps + 4);
+  if (!CGP_DBG_ON(p, 32768) || acc[0][0][0] == T(12345.678))  // timing probe: no store
+  store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
+  pc.lap(p, ps + 5);
+  pc.count(p, ps + 7);
+  if constexpr (DIAGNEXT) {
+    if (finish_next) diag_next<T, DIAG_FINISH, kTriDiag, DEEP, mid_fat<T, MID>()>(p, acc, smem, Lw, b, k + 1, tid, &pc);
+  }
 }
 
 // DIAGNEXT (throughput schedule, fit launches): besides the row tiles below the diagonal and the extra
@@ -1048,7 +1153,6 @@ __device__ __forceinline__ void panel_partial(const FitArgs &p, typename Prec<T>
 // MID: kinds C / image-A compiled in (their branches cost registers the full-batch build cannot spare).  In fp32 the
 // mid-size build also takes the fat form of the diagonal tile (79 KB of LDS: two workgroups per CU, which these calls do
 // not fill anyway); fp64 would need 147 KB, one workgroup per CU, and keeps the packed form.
-template <typename T, bool MID> constexpr bool mid_fat() { return MID && sizeof(T) == 4; }
 #ifndef CGP_F32_FULL_OCC
 #define CGP_F32_FULL_OCC 4   // workgroups per CU the register-staged fp32 build is compiled for (`make variant` A/B: 3)
 #endif
@@ -1122,92 +1226,146 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (DEEP ? 3 : F32_FULL_OCC) : 2
     tile_fit_of_block(bt, b);
     rt = row_tile_of(bt + p.tile_off, k + 1, p.NT, p.rows_from_extra);
   }
-  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
-  const int ld = p.ld;
-  PhaseClock pc;
-  pc.start(p, tid);
-  const int ps = finish_next ? 336 : 64 + 8 * (k & 31);  // debug slots of this step (kind A: its own group, all steps summed)
-
-  // Gram first: acc = -G(rt, kc) while nothing else is live in the register file, with chunk 0 of the
-  // panels already in flight into LDS buffer 0 (the Gram inputs are staged in buffer 1's space).
-  constexpr int CH2 = 2 * KT * LDST;
-  const T *gR = Lw + (size_t)rt * TS + (size_t)(c_first * KT) * ld, *gC = Lw + (size_t)k * TS + (size_t)(c_first * KT) * ld;
-  // timing probes (wrong results): 4096 = every tile reads fit (b & 7)'s first row panel (L2-resident row
-  // panels), 8192 = the same for the column panel
-  if (CGP_DBG_ON(p, 4096)) gR = reinterpret_cast<const T *>(p.Lw) + (size_t)(b & 7) * p.lw_stride + (size_t)p.NT * TS;
-  if (CGP_DBG_ON(p, 8192)) gC = reinterpret_cast<const T *>(p.Lw) + (size_t)(b & 7) * p.lw_stride + (size_t)k * TS;
-  const int nchunk = k * (TS / KT) - c_first;
-  const T *pimg = reinterpret_cast<const T *>(p.pimg) + ((size_t)b * 2 + (k & 1)) * DPART;  // image of tile (k + 1, k)
-  // running predictive sums (extra tiles, throughput schedule): z of the newest block column
-  // (k - 1) goes to LDS behind the chunk ring; zeros when nothing is to be accumulated
-  const bool accm = p.macc != nullptr && rt >= p.NT && k > 0;
-  T *zs = smem + 4 * KT * LDST;
-  if (tid < TS) zs[tid] = accm ? Lw[(size_t)((k - 1) * TS + tid) * ld + (size_t)p.NT * TS + p.M] : T(0);
-  T ms[4] = {T(0), T(0), T(0), T(0)};
-  if constexpr (DEEP) {
-    RowFrag<T> rf;
-    {
-      GramPre<T> gp;
-      if (!(MID && from_image)) gram_prefetch<T>(p, b, k, rt, tid, gp);
-      rdirect_prologue<T>(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
-      if (MID && from_image) acc_image<T, false, false>(acc, const_cast<T *>(pimg), tid);
-      else gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
-    }
-    pc.lap(p, ps + 0);
-    mfma_rowpanel_loop_rdirect<T>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
-  } else {
-    {
-      GramPre<T> gp;
-      if (!(MID && from_image)) gram_prefetch<T>(p, b, k, rt, tid, gp);
-      if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
-      if (CGP_DBG_ON(p, 16384)) {  // timing probe: no Gram tile
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[cb][j][r] = gp.v[0];
-      } else if (MID && from_image) acc_image<T, false, false>(acc, const_cast<T *>(pimg), tid);
-      else gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
-    }
-    pc.lap(p, ps + 0);
-    mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, accm ? zs : nullptr, ms);
-  }
-  pc.lap(p, ps + 1);
-  if (accm) {
-    // a row's 128 columns are spread over the four 16-lane groups: fold them, then the lanes of
-    // group 0 add to the fit's accumulators (this workgroup is the only writer of its rows)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      ms[q] += __shfl_xor(ms[q], 16);
-      ms[q] += __shfl_xor(ms[q], 32);
-    }
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (lane < 16) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int m = (rt - p.NT) * TS + wave * 32 + 2 * lane + j;
-        if (m < p.M) {
-          p.macc[(size_t)b * p.M + m] += (double)ms[j];
-          p.vacc[(size_t)b * p.M + m] += (double)ms[2 + j];
-        }
-      }
-    }
-  }
-  __syncthreads();  // every wave is done with the staged inputs before W_k overwrites them
-  pc.lap(p, ps + 2);
-  if (!CGP_DBG_ON(p, 64)) trmm_in_registers<T>(p, acc, smem, b, k, tid, &pc, ps + 3);
-  pc.lap(p, ps + 4);
-  if (!CGP_DBG_ON(p, 32768) || acc[0][0][0] == T(12345.678))  // timing probe: no store
-  store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
-  pc.lap(p, ps + 5);
-  pc.count(p, ps + 7);
-  if constexpr (DIAGNEXT) {
-    if (finish_next) diag_next<T, DIAG_FINISH, kTriDiag, DEEP, mid_fat<T, MID>()>(p, acc, smem, Lw, b, k + 1, tid, &pc);
-  }
+  panel_tile_body<T, DIAGNEXT, DEEP, MID>(p, k, b, rt, c_first, finish_next, from_image, smem, tid);
   sc.leave(p, k, tid);
 }
+
+#ifdef CGP_AB
+// --------------------------------------------------------------------------------------------------
+// k_sched: a whole mid-size call (a few dozen fits: BASELINE configs[2] as sharded over 8 GPUs is 64 per GPU) in ONE launch.
+// As NT + 1 launches such a call is bound by what happens at the launch boundaries: every launch lasts as long as its
+// longest workgroup chain, carries an integer number of equal workgroups per CU (768 ... 320 tiles on 256 CUs), and all
+// its workgroups enter their input / Gram phases together and leave through trmm / store together, so the matrix
+// pipes idle at both ends of all eight launches (MFMA floor of the 64-fit fp32 call 0.46 ms, as
+// launches 0.98).  Here the same tile programs run as TASKS of one persistent launch: workgroups pull the next task of
+// a list ordered by block step (kinds: A tile (k+1,k) + diagonal tile k+1; B / C the pre-updates
+// of k_panel<T, true, DEEP, true>; T every other tile), wait for what it reads -- per fit: `prog[rt]` = block columns of
+// row tile rt stored so far, `wdone` = diagonal tiles factored, one flag per pre-update image -- and publish what they
+// wrote.  A fit's steps no longer wait for the other fits' (the chain of fit b's diagonal tiles runs beside the tiles of
+// the others), a CU's workgroups drift out of phase, and there is one wind-down per call.
+// Ordering: every task a task waits for is EARLIER in the list, and a workgroup only holds a task while it is resident,
+// so the earliest unfinished task can always run -- no assumption on residency, placement or dispatch order.  Hand-offs
+// follow the guide's counter form: producer  s_waitcnt vmcnt(0) (every wave) -> barrier -> lane 0: agent-scope release,
+// s_waitcnt vmcnt(0), relaxed agent-scope flag stores;  consumer  lane 0 polls with relaxed agent-scope loads
+// (s_sleep between polls, bounded: a timeout raises `abort`, every workgroup leaves and info reports it), one
+// agent-scope acquire, barrier, plain loads.  Pre-update images take one slot per tile index (FitArgs::img_slots), so
+// every address of the call is written once.  Same arithmetic in the same order as the launches: bitwise the same results.
+// --------------------------------------------------------------------------------------------------
+enum { SCHED_T = 0, SCHED_A = 1, SCHED_B = 2, SCHED_C = 3 };
+struct SchedArgs {
+  const int4 *tasks;   // {kind, block step k, fit b, row tile rt}
+  int ntasks;
+  int *head;           // next task
+  int *abort;          // a wait timed out: everybody leaves
+  int *prog;           // [fits][prog_stride] block columns stored per row tile
+  int prog_stride;
+  int *wdone;          // [fits] diagonal tiles factored (W_k published for k < wdone)
+  int *bflag, *cflag;  // [fits][flag_stride] pre-update images written (kind B: by diagonal tile index, kind C: by block column)
+  int flag_stride;
+};
+constexpr unsigned SCHED_SPIN_LIMIT = 1u << 19;   // polls before a wait gives up (~ a second; a call is milliseconds)
+
+__device__ __forceinline__ bool sched_wait_ge(int *addr, int want, int *abort) {
+  for (unsigned spins = 0;; ++spins) {
+    if (__hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+    if ((spins & 31) == 31 && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    if (spins >= SCHED_SPIN_LIMIT) {
+      __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(64);
+  }
+}
+
+template <typename T>
+__device__ __attribute__((noinline)) void sched_run_tile(const FitArgs &p, int k, int b, int rt, int c_first, int finish, int img, T *smem, int tid) {
+  panel_tile_body<T, true, true, true>(p, k, b, rt, c_first, finish != 0, img != 0, smem, tid);
+}
+template <typename T>
+__device__ __attribute__((noinline)) void sched_run_diag_partial(const FitArgs &p, T *smem, int b, int kn, int tid) {
+  typename Prec<T>::acc_t acc[NCB][2];
+  diag_next<T, DIAG_PARTIAL, kTriDiag, true>(p, acc, smem, reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride, b, kn, tid);
+}
+template <typename T>
+__device__ __attribute__((noinline)) void sched_run_panel_partial(const FitArgs &p, T *smem, int b, int k, int tid) {
+  typename Prec<T>::acc_t acc[NCB][2];
+  panel_partial<T, true>(p, acc, smem, b, k, tid);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_sched(FitArgs p, SchedArgs q) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  __shared__ int s_task, s_ok;
+  __shared__ FitArgs sp;   // the arguments where an out-of-line tile program can reach them (a kernel argument has no address)
+  if (threadIdx.x == 0) sp = p;
+  for (;;) {
+    // the thread index is re-read as an opaque value every trip: otherwise everything the tile programs derive from it (lane
+    // offsets, operand addresses) is hoisted out of the task loop and kept live across it -- 326 (fp32) / 856 (fp64) spilled VGPRs
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    __syncthreads();   // everybody is done with the previous task (LDS, s_task)
+    if (tid == 0) {
+      int t = q.ntasks;
+      if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        t = __hip_atomic_fetch_add(q.head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_task = t;
+    }
+    __syncthreads();
+    const int t = s_task;
+    if (t >= q.ntasks) return;
+    const int4 tk = q.tasks[t];
+    const int kind = tk.x, k = tk.y, b = tk.z, rt = tk.w;
+    int *prog = q.prog + (size_t)b * q.prog_stride, *wdone = q.wdone + b;
+    int *bflag = q.bflag + (size_t)b * q.flag_stride, *cflag = q.cflag + (size_t)b * q.flag_stride;
+    if (tid == 0) {
+      // `wdone` counts the diagonal tiles factored INSIDE this launch (tile 0 has a launch of its own ahead of it), so
+      // W_k is published when wdone >= k
+      bool ok = true;
+      if (kind == SCHED_T) {
+        ok = sched_wait_ge(wdone, k, q.abort) && (k == 0 || sched_wait_ge(prog + rt, k, q.abort));
+        // an extra tile with running predictive sums also reads z of block column k - 1: the y row's tile
+        if (ok && k > 0 && rt >= p.NT && p.macc != nullptr) ok = sched_wait_ge(prog + p.NT + p.M / TS, k, q.abort);
+      } else if (kind == SCHED_A) {
+        ok = sched_wait_ge(wdone, k, q.abort) && (k == 0 || sched_wait_ge(prog + k + 1, k, q.abort)) &&
+             (k < 1 || sched_wait_ge(cflag + k, 1, q.abort)) && (k < 2 || sched_wait_ge(bflag + k + 1, 1, q.abort));
+      } else if (kind == SCHED_B) {
+        ok = sched_wait_ge(prog + k + 2, k, q.abort);
+      } else {
+        ok = k == 0 || (sched_wait_ge(prog + k + 2, k, q.abort) && sched_wait_ge(prog + k + 1, k, q.abort));
+      }
+      if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 holds nothing older than what the flags announced
+      else atomicCAS(p.info + b, 0, -(1000 + k));                 // reported: the call fails with a negative info, it does not hang
+      s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    // the tile programs are OUT OF LINE (sched_run_*): inlined into the task loop they shared one register allocation with it and
+    // with each other (127 fp32 / 568 fp64 spilled VGPRs, some inside the hand-counted `s_waitcnt vmcnt(n)` loops, whose counts a
+    // spill's scratch access silently breaks); as functions each is allocated as its own kernel is
+    if (kind == SCHED_B) sched_run_diag_partial<T>(sp, smem, b, k + 2, tid);
+    else if (kind == SCHED_C) sched_run_panel_partial<T>(sp, smem, b, k, tid);
+    else {
+      const bool chain = kind == SCHED_A, img = chain && k >= 1;
+      sched_run_tile<T>(sp, k, b, rt, img ? (k - 1) * (TS / KT) : 0, chain ? 1 : 0, img ? 1 : 0, smem, tid);
+    }
+    // publish: every wave's stores have left the CU, then ONE lane's agent-scope release ahead of the flags
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (kind == SCHED_T) __hip_atomic_store(prog + rt, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (kind == SCHED_A) {
+        __hip_atomic_store(prog + k + 1, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(wdone, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (kind == SCHED_B) __hip_atomic_store(bflag + k + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(cflag + k + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+#endif  // CGP_AB (k_sched)
 
 #ifdef CGP_AB
 // --------------------------------------------------------------------------------------------------

@@ -480,6 +480,24 @@ def test_alternate_schedules_match_oracle(env):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("dt,N,B", [("f32", 640, 40), ("f64", 768, 24)])
+def test_one_launch_schedule_is_bitwise_the_launches(dt, N, B):
+    """k_sched (measurement library, CGP_SCHED=onelaunch): a mid-size call as ONE persistent launch whose workgroups pull
+    tile tasks and hand results over through per-fit progress counters (agent-scope release / acquire).  Same tile
+    programs in the same order as the NT + 1 launches the engine ships: every fit's outputs are bitwise equal, from the
+    FIRST call on (a missing dependency shows as a stale read only while the slabs still hold something else)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "corenav_gp_amd", "libcorenav_gp_ab.so")):
+        pytest.skip("libcorenav_gp_ab.so not built (make -C corenav_gp_amd/csrc ab)")
+    env = dict(os.environ, SVL_WARM="0", SVL_REPS="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sched_vs_launches.py"), dt, str(N), str(B)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = r.stdout.strip().splitlines()[-1]
+    assert "fits that differ: 0 " in line and "nonzero: 0 " in line, line
+
+
 def test_brownian_sign_structure(engine):
     """GPy Brownian.K is zero between inputs of opposite sign and min(|x|,|x'|) otherwise: a window that
     straddles zero gives a block-diagonal K (never the case on the rover, where ticks are positive,
