@@ -785,9 +785,10 @@ def host_description():
 def cpu_baseline(kid, X, y, Xs, th, nsample, dmean, dvar, dlogml, f_fit, context_rows=True):
     """The oracle ("port" of the reference arithmetic) timed on this box's host cores, ONE thread like the
     reference's catkin build, on a bounded sample of the same windows (warm-ups, then the MEDIAN of
-    the per-fit times).  Two single-thread implementations of the same restatement are timed -- oracle/gp_oracle.c
-    (plain C, gcc -O3 -march=native here) and oracle/gp_oracle.py on ONE LAPACK thread (dpotrf / dtrtrs: the
-    Eigen::LLT-class row) -- and the FASTER one is `value`: the honest single-thread denominator.  The C port's
+    the per-fit times).  Three single-thread implementations of the same restatement are timed -- oracle/gp_oracle.c
+    (plain C, gcc -O3 -march=native here), oracle/gp_oracle.py on ONE LAPACK thread, and oracle/gp_oracle_lapack.c (C on
+    dpotrf / dpotrs / dtrsm of the bundled OpenBLAS, one thread, vectorised Gram loop: the Eigen::LLT-class row) -- and
+    the FASTEST is `value`: the honest single-thread denominator.  The C port's
     outputs also check the timed GPU outputs.  Context row (not the baseline): the C port with one window per host
     thread over every CPU the container may use (cgroup quota stated)."""
     import ctypes
@@ -852,9 +853,49 @@ def cpu_baseline(kid, X, y, Xs, th, nsample, dmean, dvar, dlogml, f_fit, context
                                              f"limited to ONE thread (threadpoolctl); {f_fit / m1 / 1e9:.2f} GFLOP/s"}
     except Exception as e:
         rows["lapack_1_thread"] = {"error": repr(e)}
+    # the same steps in C on LAPACK / BLAS (dpotrf, dpotrs, dtrsm, dgemv of scipy's bundled OpenBLAS, dlopen'ed and held to ONE
+    # thread) with a vectorised Gram loop: the "Eigen::LLT-class" row -- no numpy temporaries in the denominator
+    try:
+        import glob
+        import scipy
+        blas = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so")))
+        so2 = os.path.join(os.path.dirname(so), "libgp_oracle_lapack.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fno-math-errno", "-fPIC", "-std=gnu11", "-shared", "-o", so2,
+                               os.path.join(ROOT, "oracle", "gp_oracle_lapack.c"), "-lm", "-ldl"])
+        lib2 = ctypes.CDLL(so2)
+        lib2.oracle_lapack_init.argtypes = [ctypes.c_char_p]
+        if not blas or lib2.oracle_lapack_init(blas[0].encode()) != 0:
+            raise RuntimeError("no bundled OpenBLAS to dlopen")
+
+        def run2(b):
+            mean, var, logml, jit, tp = np.zeros(M), np.zeros(M), np.zeros(1), np.zeros(1), np.zeros(1)
+            p = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
+            Xb, yb, Xsb, thb = (np.ascontiguousarray(a[b % nwin], dtype=np.float64) for a in (X, y, Xs, th))
+            t0 = time.perf_counter()
+            rc = lib2.oracle_fit_predict_lapack(kid, p(thb), N, d, p(Xb), p(yb), M, p(Xsb), 1, p(mean), p(var), p(logml), None,
+                                                p(jit), p(tp))
+            return time.perf_counter() - t0, rc, mean, var, float(logml[0]), float(tp[0])
+
+        run2(0)
+        n2 = max(3, min(20, int(4.0 / max(run2(0)[0], 1e-4))))
+        res = [run2(b) for b in range(n2)]
+        assert not any(r[1] for r in res)
+        w2 = max(max(float(np.max(np.abs(gm[b] - r[2])) / np.max(np.abs(r[2]))), float(np.max(np.abs(gv[b] - r[3]) / r[3])),
+                     abs(gl[b] - r[4]) / abs(r[4])) for b, r in enumerate(res) if b < nwin)
+        assert w2 < tol, f"timed GPU outputs differ from the LAPACK oracle: {w2:.3e}"
+        m2 = statistics.median(r[0] for r in res)
+        tpo = statistics.median(r[5] for r in res)
+        rows["c_lapack_1_thread"] = {"value": 1.0 / m2, "unit": "fits/s", "threads": 1,
+                                     "dpotrf_gflops": N ** 3 / 3.0 / tpo / 1e9,
+                                     "sample": f"median of {n2} of the step's windows after 2 warm-ups through oracle/gp_oracle_lapack.c (gcc -O3 "
+                                               f"-march=native; dpotrf / dpotrs / dtrsm / dgemv of scipy's bundled OpenBLAS on ONE thread, "
+                                               f"vectorised Gram loop); {f_fit / m2 / 1e9:.2f} GFLOP/s over the fit, dpotrf alone "
+                                               f"{N ** 3 / 3.0 / tpo / 1e9:.1f} GFLOP/s"}
+    except Exception as e:
+        rows["c_lapack_1_thread"] = {"error": repr(e)}
     best = max((k for k in rows if "value" in rows[k]), key=lambda k: rows[k]["value"])
     base = {"value": rows[best]["value"], "unit": "fits/s", "cores": 1, "kind": "port",
-            "sample": f"the faster of two single-thread runs of the oracle: {best} -- " + rows[best]["sample"],
+            "sample": f"the fastest of the single-thread runs of the oracle: {best} -- " + rows[best]["sample"],
             "single_thread_rows": rows, "host": host, "gpu_vs_oracle_max_rel_err": worst}
     if not context_rows:
         return base

@@ -85,6 +85,7 @@ struct cgp_ctx {
   int *la_ibuf = nullptr;
   size_t la_nd = 0, la_ni = 0;
   int sk_slots = 0;
+  size_t lat_units = 0;   // fits x tile slots the latency schedule's partial-tile slab holds
   // sliding windows (cgp_window_*)
   WindowArgs win{};
   int nwin = 0;
@@ -586,7 +587,10 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // the panel tiles of a step in one launch, inner dimension split over up to SK_MAX workgroups.
   if (latency) {
     const bool split_trmm = !sw.sk_fused_trmm;
-    SplitArgs q{c->dpart, c->dticket, c->sk_slots, 1, in_rows ? 1 : 0, c->dwready, c->dlatimg, split_trmm ? 0 : 1};
+    // tile slots per fit of THIS call (slab and tickets are indexed with it; the tickets are zero between launches whatever the stride)
+    const int call_slots = a.NT + a.ET + 1;
+    if ((size_t)batch * call_slots > c->lat_units) return CGP_ECAPACITY;
+    SplitArgs q{c->dpart, c->dticket, call_slots, 1, in_rows ? 1 : 0, c->dwready, c->dlatimg, split_trmm ? 0 : 1};
     for (int k = 0; k < a.NT; ++k) {
       const int tiles = (in_rows ? a.NT - k - 1 : 0) + a.ET;
       const int nslots = tiles + (in_rows ? 1 : 0);
@@ -639,7 +643,8 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // 3.92, 24 fits 3.48 -> 3.51, 12 fits 2.62 -> 3.45 (the call is one chain then: nothing to run beside it); fp32 N = 1024
   // 64 fits 0.99 -> 1.01, 32 fits 0.69 -> 0.76: its launches last as long as kind A's chain at every k, so the extra rows'
   // last launches only queue up behind it, and two contexts overlap worse (0.76 -> 0.96 ms per call).  fp64 from 28 fits.
-  const bool xsplit = mid && sizeof(T) == 8 && batch * a.NT >= XSPLIT64_WORK && in_rows && !split_diag && G == 1 && a.ET > 0 && !kNoExtraSplit;
+  // (not under cgp_profile_enable: per-launch events of two concurrent streams would overlap in time and their sum overstate the kernel)
+  const bool xsplit = mid && sizeof(T) == 8 && batch * a.NT >= XSPLIT64_WORK && in_rows && !split_diag && G == 1 && a.ET > 0 && !kNoExtraSplit && !c->prof;
   hipStream_t sE = c->wstream[0];
   Launcher LE{c, sE};
   for (int k = 0; k < a.NT; ++k) {
@@ -907,7 +912,17 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc((void **)&c->dgpart, (B * c->NTmax * (c->NTmax + 1) / 2 * GRAD_N + 2) * sizeof(double)) == hipSuccess;  // + logML, info of a single evaluation
   c->sk_slots = c->NTmax + c->ETmax + 1;
   c->lat_cap = std::min(LAT_FITS_ALLOC, max_batch);
-  ok = ok && hipMalloc(&c->dpart, (size_t)c->lat_cap * c->sk_slots * SK_MAX * TS * TS * c->esz) == hipSuccess;
+  // partial-tile slab: the latency schedule takes MORE fits the fewer block steps a window has (lat_fits_by_steps), and a
+  // call of NT block steps uses NT + ET + 1 tile slots per fit, so the slab is sized for the largest fits x slots product over
+  // the block-step counts this context can see (a max_n = 2048 fp64 context: 11 fits x 22 slots, not 32 x 22) and a call
+  // indexes it with its OWN slot count (SplitArgs::slots)
+  size_t lat_units = 0;
+  for (int nt = 1; nt <= c->NTmax; ++nt) {
+    const int fits = std::min(c->lat_cap, kAbBuild ? LAT_FITS_ALLOC : lat_fits_by_steps(dtype == CGP_F64, nt));
+    lat_units = std::max(lat_units, (size_t)fits * (nt + c->ETmax + 1));
+  }
+  c->lat_units = lat_units;
+  ok = ok && hipMalloc(&c->dpart, lat_units * SK_MAX * TS * TS * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dticket, sizeof(int) * c->lat_cap * c->sk_slots) == hipSuccess;
   ok = ok && hipMemset(c->dticket, 0, sizeof(int) * c->lat_cap * c->sk_slots) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dwready, sizeof(int) * c->lat_cap) == hipSuccess;
@@ -987,7 +1002,7 @@ int cgp_debug_buffers(cgp_ctx *c, unsigned long long out[2 * CGP_DEBUG_BUFFERS])
                                        (size_t)c->mid_cap * 2 * DPART * c->esz,
                                        B * c->max_d * c->max_n * c->esz,
                                        sizeof(double) * 2 * B * std::max(c->max_m, 1),
-                                       (size_t)c->lat_cap * c->sk_slots * SK_MAX * TS * TS * c->esz,
+                                       c->lat_units * SK_MAX * TS * TS * c->esz,
                                        (size_t)c->lat_cap * 2 * LAT_IMG_MAX * DPART * c->esz};
   for (int i = 0; i < CGP_DEBUG_BUFFERS; ++i) {
     out[2 * i] = (unsigned long long)(uintptr_t)p[i];
@@ -1486,8 +1501,11 @@ int upload_window(cgp_ctx *c, const double *X, const double *y, int N, int d, hi
 int nll_grad_resident(cgp_ctx *c, const double *X, int N, int d, int kid, const double *theta, double *nll, double *grad) {
   const int nth = ntheta(kid, d);
   hipStream_t s = c->stream;
-  if (!grow_pinned(c->opt_pin, c->opt_pin_cap, (kOptPinIn + 64) * sizeof(double))) return CGP_ENOMEM;
-  double *hin = static_cast<double *>(c->opt_pin);   // [theta (CGP_MAX_THETA) | jitter]; re-read after a grow in grad_eval
+  // the whole block -- [theta | jitter | partial sums, logML, info] -- before any copy is queued: grad_eval must never
+  // reallocate it under a copy in flight (hipHostFree would have to synchronise the device)
+  const size_t nt_ = cdiv(N, TS), need = kOptPinIn + std::max<size_t>(64, nt_ * (nt_ + 1) / 2 * GRAD_N + 2);
+  if (!grow_pinned(c->opt_pin, c->opt_pin_cap, need * sizeof(double))) return CGP_ENOMEM;
+  double *hin = static_cast<double *>(c->opt_pin);   // [theta (CGP_MAX_THETA) | jitter]
   double jit = 0.0, logml = 0.0, sums[GRAD_N];
   int info = 0, rc = CGP_OK;
   for (int attempt = 0; attempt <= 5; ++attempt) {  // GPy jitchol policy
@@ -1894,6 +1912,13 @@ extern "C" int cgp_window_push_device(cgp_ctx *c, int T, const double *dxs, cons
   }
   hipStream_t ws = pick_stream(c, hip_stream);
   const int N = a.N, CAP = a.CAP;
+  if (c->win_o < 0) {   // the mirror was invalidated by a failed push: read the windows' state back (they advance in lock-step)
+    int st[4];
+    HIP_TRY(c, hipStreamSynchronize(ws));
+    HIP_TRY(c, hipMemcpy(st, c->win.state, sizeof(st), hipMemcpyDeviceToHost));
+    c->win_o = st[0];
+    c->win_n = st[1];
+  }
   int o = c->win_o, n = c->win_n;
   auto one_tick = [&](int &oo, int &nn) {   // k_window_ticks, one tick
     if (oo + nn >= CAP) oo = 0;
@@ -1924,9 +1949,12 @@ extern "C" int cgp_window_push_device(cgp_ctx *c, int T, const double *dxs, cons
     hipLaunchKernelGGL(k_window_ticks, dim3(c->nwin), dim3(256), lds1, ws, a);
     t += ns;
   }
-  c->win_o = o;
+  if (!hip_ok(c, hipGetLastError(), "window launches")) {
+    c->win_o = c->win_n = -1;   // what reached the device is unknown: the next push re-reads the state
+    return CGP_EHIP;
+  }
+  c->win_o = o;   // committed only once every launch of the push was accepted
   c->win_n = n;
-  HIP_TRY(c, hipGetLastError());
   return CGP_OK;
 }
 

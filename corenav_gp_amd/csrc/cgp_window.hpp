@@ -377,6 +377,13 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
   const double noise = p.theta[(size_t)(w0 + wl0) * MAX_THETA + nth - 1];
   const unsigned woff = (unsigned)(wl0 * (int)(LWs * sizeof(double)));
   int o = p.state[w0 * 4], bad = tid < WPW ? p.state[(w0 + tid) * 4 + 2] : 0;
+  // The host cuts a push into launches from its MIRROR of the windows' origin and size; this kernel is only correct for full
+  // windows with room for two more rows.  A window whose device state says otherwise (the mirror went out of step: a failed
+  // launch, an earlier push that returned early) is flagged (state[2] = -1) and left untouched instead of being swept.
+  if (p.state[w0 * 4 + 1] != N || o + N + 1 >= CAP) {
+    if (tid < WPW && p.state[(w0 + tid) * 4 + 2] == 0) p.state[(w0 + tid) * 4 + 2] = -1;
+    return;
+  }
   const int m = N - 1;
   const int npan = (m + 1 + WPB - 1) / WPB;   // panels of tick t + 1 (columns 1 .. m); tick t uses columns 0 .. m - 1
   const int i = lane & (WPB - 1);

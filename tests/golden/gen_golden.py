@@ -13,6 +13,11 @@ Sources of the expected values, per fixture `source` field:
               shared with oracle/ -- itself checked here against the textbook noise-free forms (linear
               interpolation between samples, constant beyond the last one, bridge variance s2 (x-a)(b-x)/(b-a),
               s2 (x - x_N) beyond)
+  mpmath   -- the reference's product kernel RBF(1) x Brownian(1) (gp_slip_node.py:31) at a WORKING length-scale, on the
+              training part of the slipVal window (N = 134) and the 599 published ticks (gp_slip_node.py:45-49,59-61):
+              50-digit arithmetic (mpmath), kernel from its definition, LU with pivoting for the inverse and the
+              determinant -- no Cholesky, no numpy, nothing of oracle/ -- posterior mean, variance, log marginal
+              likelihood and its gradient wrt the four parameters
   restated -- oracle/gp_oracle.py outputs (regression vectors for the GPy-only RBF x Brownian kernel
               and for the GpPredictor look-ahead; PARITY UNPINNED vs GPy itself)
 """
@@ -176,6 +181,72 @@ def brownian_cases():
                         var_latent=np.array(var), logml=lml)
 
 
+def mp_rbfbrownian():
+    """mp_rbfbrownian_n134.npz: independent pin of the reference's kernel at theta = (0.5, 30, 0.01, 0.002)."""
+    import mpmath as mp
+    mp.mp.dps = 50
+    raw = np.loadtxt(REF_CSV, delimiter=",")
+    ticks = np.round(raw[:, 0] * 10.0)[:149]
+    slip = raw[:149, 1]
+    n = len(ticks)
+    ntr = int(0.9 * n)                                   # gp_slip_node.py:27-29
+    xs_grid = np.arange(ticks.min(), ticks.max() + 600, 1)[n:]   # :45, :59-61 (index slice)
+    x = [mp.mpf(float(v)) for v in ticks[:ntr]]
+    y = [mp.mpf(float(v)) for v in slip[:ntr]]
+    sr, ell, sb, sn = (mp.mpf(v) for v in ("0.5", "30", "0.01", "0.002"))
+
+    def k(a, b):                                         # GPy RBF.K * Brownian.K for positive inputs
+        return sr * mp.e ** (-(a - b) ** 2 / (2 * ell ** 2)) * sb * min(a, b)
+    N = ntr
+    K = mp.matrix(N, N)
+    for i in range(N):
+        for j in range(N):
+            K[i, j] = k(x[i], x[j])
+    Ky = K.copy()
+    for i in range(N):
+        Ky[i, i] += sn + mp.mpf("1e-8")                  # GPy ExactGaussianInference: K + (variance + 1e-8) I
+    Kinv = mp.inverse(Ky)                                # LU with partial pivoting
+    yv = mp.matrix(y)
+    alpha = Kinv * yv
+    P, L, U = mp.lu(Ky)
+    logdet = sum(mp.log(abs(U[i, i])) for i in range(N))
+    logml = -(yv.T * alpha)[0] / 2 - logdet / 2 - mp.mpf(N) / 2 * mp.log(2 * mp.pi)
+    mean, var = [], []
+    for xsv in xs_grid:
+        a = mp.mpf(float(xsv))
+        ks = mp.matrix([k(a, x[i]) for i in range(N)])
+        mean.append((ks.T * alpha)[0])
+        var.append(k(a, a) - (ks.T * (Kinv * ks))[0])    # latent variance (no noise term)
+    W = alpha * alpha.T - Kinv                           # 2 dL/dK
+    g = [mp.mpf(0)] * 4
+    for i in range(N):
+        for j in range(N):
+            wk = W[i, j] * K[i, j]
+            g[0] += wk / sr
+            g[1] += wk * (x[i] - x[j]) ** 2 / ell ** 3
+            g[2] += wk / sb
+        g[3] += W[i, i]
+    grad = [v / 2 for v in g]                            # d logML / d theta
+    # the restatement against it, before anything is written
+    theta = np.array([0.5, 30.0, 0.01, 0.002])
+    xtr, ytr = ticks[:ntr, None], slip[:ntr]
+    f = go.fit(go.KERNEL_RBF_BROWNIAN, theta, xtr, ytr)
+    omu, ovar = go.predict(f, xs_grid[:, None], include_noise=False)
+    onll, og = go.nll_and_grad(go.KERNEL_RBF_BROWNIAN, theta, xtr, ytr)
+    mu = np.array([float(v) for v in mean])
+    vr = np.array([float(v) for v in var])
+    gr = np.array([float(v) for v in grad])
+    e_mu = np.max(np.abs(omu - mu)) / np.max(np.abs(mu))
+    e_var = np.max(np.abs(ovar - vr) / vr)
+    e_l = abs(f.logml - float(logml)) / abs(float(logml))
+    e_g = np.max(np.abs(-og - gr)) / np.max(np.abs(gr))
+    print(f"mp_rbfbrownian_n134: oracle vs 50-digit LU  mean {e_mu:.2e}  var {e_var:.2e}  logml {e_l:.2e}  grad {e_g:.2e}")
+    assert e_mu < 1e-9 and e_var < 1e-7 and e_l < 1e-11 and e_g < 1e-8
+    np.savez_compressed(os.path.join(OUT, "mp_rbfbrownian_n134.npz"), source="mpmath", kernel_id=2, theta=theta, X=xtr, y=ytr,
+                        Xs=xs_grid[:, None], mean=mu, var_latent=vr, logml=float(logml), dlogml_dtheta=gr,
+                        alpha=np.array([float(v) for v in alpha]))
+
+
 def slipval_window():
     """The only real slip series in the reference (core_navigation/script/slipVal.csv, 199 rows
     time_s, slip @ 0.1 s).  Stored as data: tick = round(10 t), the first 149 rows form one
@@ -242,6 +313,8 @@ def main():
     kid, X, y, Xs, th, _ = synth.config(2)
     sklearn_case("sk_se_ard_n2048_d6", kid, X[0], y[0], Xs[0], th[0])
     brownian_cases()
+    if "--no-mp" not in sys.argv:
+        mp_rbfbrownian()
     slipval_window()
     restated_cases()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

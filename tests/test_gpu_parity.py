@@ -50,7 +50,21 @@ SK = ["sk_se_iso_n256_d3", "sk_se_ard_n2_d1", "sk_se_ard_n15_d3", "sk_se_ard_n13
       "closed_n1_se", "closed_n2_rbfbrownian",
       # the reference's kernel in its pure-Brownian limit at the reference's operating size, expected values from a
       # Kalman filter / RTS smoother recursion (tests/golden/gen_golden.py: brownian_cases) -- independent of oracle/
-      "closed_brownian_kalman_n134", "closed_brownian_bridge_n134", "closed_brownian_prior_n1"]
+      "closed_brownian_kalman_n134", "closed_brownian_bridge_n134", "closed_brownian_prior_n1",
+      # the reference's product kernel at a WORKING length-scale (theta = 0.5, 30, 0.01, 0.002) on the slipVal window:
+      # 50-digit LU (mpmath; tests/golden/gen_golden.py: mp_rbfbrownian), nothing of oracle/
+      "mp_rbfbrownian_n134"]
+
+
+def test_gradient_against_the_50_digit_pin(engine):
+    """d logML / d theta of the reference's kernel (gp_slip_node.py:31,36: what m.optimize() follows) at theta = (0.5, 30,
+    0.01, 0.002) on the slipVal window, from the 50-digit LU of tests/golden/mp_rbfbrownian_n134.npz -- through the
+    one-launch short-window kernel."""
+    g = load_golden("mp_rbfbrownian_n134")
+    ctx = engine.Context(max_n=256, max_m=256, max_d=1)
+    nll, grad = ctx.nll_grad(g["X"], g["y"], 2, g["theta"])
+    assert abs(-nll - float(g["logml"])) <= TOL64 * abs(float(g["logml"]))
+    assert np.max(np.abs(-grad - g["dlogml_dtheta"])) <= TOL64 * np.max(np.abs(g["dlogml_dtheta"]))
 
 
 @pytest.mark.parametrize("name", SK)
@@ -496,6 +510,27 @@ def test_one_launch_schedule_is_bitwise_the_launches(dt, N, B):
     assert r.returncode == 0, r.stdout + r.stderr
     line = r.stdout.strip().splitlines()[-1]
     assert "fits that differ: 0 " in line and "nonzero: 0 " in line, line
+
+
+@pytest.mark.parametrize("devices", [[0, 0, 0]])
+def test_sweep_fp32_matches_single_context_to_rounding(engine, devices):
+    """fp32: calls of up to 96 fits take the mid-size build (fat diagonal tile), larger calls the packed form, so a fit's
+    single-precision result depends on the size of the call it rides in (include/corenav_gp.h, sweep section): a 150-fit
+    sweep over three 50-fit shards agrees with the 150-fit call to rounding -- far inside the fp32 bar -- and a shard
+    equals a single context given the same 50 fits bitwise."""
+    kid, X, y, Xs, th, _ = synth.config(3, batch=150, N=384)
+    B = X.shape[0]
+    ctx = engine.Context(max_n=384, max_m=599, max_d=6, max_batch=B, dtype=engine.F32)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not info.any()
+    sw = engine.Sweep(devices, 384, 599, 6, B, dtype=engine.F32)
+    rc, m2, v2, l2, i2, summ = sw.fit_predict(X, y, Xs, th, kid)
+    assert rc == 0 and not i2.any()
+    assert relmax(m2, mean) < 3e-4 and np.max(np.abs(v2 - var) / var) < 3e-4 and np.max(np.abs(l2 - logml) / np.abs(logml)) < 3e-4
+    a, b = sw.shard(B, 1)
+    one = engine.Context(max_n=384, max_m=599, max_d=6, max_batch=b - a, dtype=engine.F32)
+    rc, m3, v3, l3, i3 = one.fit_predict_batch(X[a:b], y[a:b], Xs[a:b], th[a:b], kid)
+    assert rc == 0 and np.array_equal(m3, m2[a:b]) and np.array_equal(v3, v2[a:b]) and np.array_equal(l3, l2[a:b])
 
 
 def test_brownian_sign_structure(engine):

@@ -16,6 +16,9 @@ CLOSED = ["closed_n1_se", "closed_n2_rbfbrownian"]
 # reference's operating size: expected values from a Kalman filter / RTS smoother recursion in python floats
 # (tests/golden/gen_golden.py: brownian_cases), nothing shared with oracle/
 KALMAN = ["closed_brownian_kalman_n134", "closed_brownian_bridge_n134", "closed_brownian_prior_n1"]
+# the reference's product kernel at a working length-scale (theta = 0.5, 30, 0.01, 0.002), N = 134, M = 599: 50-digit LU
+# with pivoting (mpmath), kernel from its definition -- tests/golden/gen_golden.py: mp_rbfbrownian; nothing of oracle/
+MPMATH = ["mp_rbfbrownian_n134"]
 
 
 def rel(a, b, floor=1e-300):
@@ -23,7 +26,7 @@ def rel(a, b, floor=1e-300):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
 
 
-@pytest.mark.parametrize("name", SK + CLOSED + KALMAN)
+@pytest.mark.parametrize("name", SK + CLOSED + KALMAN + MPMATH)
 def test_numpy_oracle_vs_golden(name):
     g = load_golden(name)
     f = go.fit(int(g["kernel_id"]), g["theta"], g["X"], g["y"])
@@ -36,10 +39,31 @@ def test_numpy_oracle_vs_golden(name):
         assert np.max(np.abs(f.alpha - g["alpha"])) / np.max(np.abs(g["alpha"])) < 1e-7
 
 
-@pytest.mark.parametrize("name", SK + CLOSED + KALMAN)
+@pytest.mark.parametrize("name", SK + CLOSED + KALMAN + MPMATH)
 def test_c_oracle_vs_golden(name, oracle_c):
     g = load_golden(name)
     rc, mu, var, logml, alpha, jit = oracle_c(int(g["kernel_id"]), g["theta"], g["X"], g["y"], g["Xs"], False)
+    assert rc == 0 and jit == 0.0
+    scale = max(float(np.max(np.abs(g["mean"]))), 1e-300)
+    assert np.max(np.abs(mu - g["mean"])) / scale < 1e-9
+    assert rel(var, g["var_latent"], 1e-12) < 1e-7
+    assert abs(logml - float(g["logml"])) <= 1e-10 * abs(float(g["logml"]))
+
+
+def test_gradient_vs_the_50_digit_pin():
+    """The objective m.optimize() follows (gp_slip_node.py:36) and its gradient wrt (sigma_r^2, ell, sigma_b^2, sigma_n^2) at
+    a working length-scale, against the 50-digit LU: the restatement's dL/dK = (alpha alpha^T - Ky^-1) / 2 contraction."""
+    g = load_golden("mp_rbfbrownian_n134")
+    nll, grad = go.nll_and_grad(2, g["theta"], g["X"], g["y"])
+    assert abs(-nll - float(g["logml"])) <= 1e-12 * abs(float(g["logml"]))
+    assert np.max(np.abs(-grad - g["dlogml_dtheta"])) <= 1e-10 * np.max(np.abs(g["dlogml_dtheta"]))
+
+
+@pytest.mark.parametrize("name", SK[:5] + CLOSED + KALMAN + MPMATH)
+def test_c_lapack_oracle_vs_golden(name, oracle_c_lapack):
+    """oracle/gp_oracle_lapack.c (the single-thread LAPACK row of bench.py's cpu_baseline) against the same fixtures."""
+    g = load_golden(name)
+    rc, mu, var, logml, alpha, jit = oracle_c_lapack(int(g["kernel_id"]), g["theta"], g["X"], g["y"], g["Xs"], False)
     assert rc == 0 and jit == 0.0
     scale = max(float(np.max(np.abs(g["mean"]))), 1e-300)
     assert np.max(np.abs(mu - g["mean"])) / scale < 1e-9
