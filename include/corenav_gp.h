@@ -177,8 +177,8 @@ int cgp_fit_predict_batch_device(cgp_ctx *ctx, int batch, int N, int d, int M, i
  * Reproducibility across shardings: a fit's result does not depend on its slot in a call or on its neighbours, and
  * in CGP_F64 not on how many fits share the call either -- a sweep equals one context running the whole batch BITWISE.
  * In CGP_F32 calls of up to 96 fits factor the 128 x 128 diagonal tile in a different (fatter) form than larger calls
- * do, so a fit's fp32 result depends on the size of the call it rides in to single-precision rounding (a few 1e-4
- * of the bar): a 512-fit sweep over 8 shards of 64 agrees with the 512-fit call to rounding, not bitwise
+ * do, so a fit's fp32 result depends on the size of the call it rides in to single-precision rounding (inside the
+ * 1e-3 bar): a 512-fit sweep over 8 shards of 64 agrees with the 512-fit call to rounding, not bitwise
  * (tests/test_gpu_parity.py::test_sweep_fp32_matches_single_context_to_rounding). */
 typedef struct cgp_sweep cgp_sweep;
 cgp_sweep *cgp_sweep_create(const int *devices, int ndev, int max_n, int max_m, int max_d, int max_batch_total,
