@@ -128,6 +128,25 @@ template <bool BROWN, int DMAX> struct SmKern {
 #pragma unroll
     for (int q = 0; q < DMAX; ++q) iell[q] = sc[10 + q];
   }
+  // the length-scaled squared differences alone (the gradient phase has K itself from the Gram phase, in registers)
+  __device__ __forceinline__ void diffs(const double *xr, int d, int NP, int gi, int gj, double (&dq2)[DMAX]) const {
+    if constexpr (BROWN) {
+      const double x = xr[gi], xp = xr[gj];
+      double r2 = (gi == gj) ? 0.0 : (-2.0 * x * xp + (x * x + xp * xp));
+      r2 = r2 < 0.0 ? 0.0 : r2;
+      dq2[0] = r2 * (iell[0] * iell[0]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < DMAX; ++q) {
+        double v = 0.0;
+        if (q < d) {
+          const double df = (xr[q * NP + gi] - xr[q * NP + gj]) * iell[q];
+          v = df * df;
+        }
+        dq2[q] = v;
+      }
+    }
+  }
   __device__ __forceinline__ double eval(const double *xr, int d, int NP, int gi, int gj, const ExpC &ec, double (&dq2)[DMAX]) const {
     if constexpr (BROWN) {
       const double x = xr[gi], xp = xr[gj];
@@ -174,28 +193,34 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
   ck.start();
   SmKern<BROWN, DMAX> kern;
   kern.load(s.sc);
-  // ---- Gram: two blocks per pass, one entry per thread; two passes per trip with every LDS read (block table, inputs) of
-  // both ahead of the arithmetic -- the compiler cannot move a table read above the previous pass's store on its own
+  // ---- Gram, in the mapping the gradient phase uses (wave w: blocks w, w + 8, ...; lane (l15, lq): entries (row lq + 4 r, column
+  // l15)), so that the covariances stay in registers (kv) for the contraction at the end instead of being evaluated twice
+  constexpr int KVB = (SM_MAX_NB * (SM_MAX_NB + 1) / 2 + SM_WAVES - 1) / SM_WAVES;   // blocks per wave at most
+  double kv[KVB][4];
   {
     const double diag_add = s.sc[20];
-    const int e = tid & 255, r = e & 15, c = e >> 4, half = tid >> 8;
-    auto entry = [&](int gi, int gj) -> double {
-      double dq2[DMAX];
-      double g;
-      if (gi < N && gj < N) {
-        g = kern.eval(s.xr, d, NP, gi, gj, ec, dq2);
-        if (gi == gj) g += diag_add;
-      } else g = (gi == gj) ? 1.0 : 0.0;   // identity padding keeps the factor well defined
-      return g;
-    };
-    for (int b0 = 0; b0 < nblk; b0 += 4) {
-      const int blk0 = b0 + half, blk1 = b0 + 2 + half;
-      const bool on0 = blk0 < nblk, on1 = blk1 < nblk;
-      const int t0 = s.tb[on0 ? blk0 : 0], t1 = s.tb[on1 ? blk1 : 0];
-      const double g0 = entry((t0 & 255) * DB + r, (t0 >> 8) * DB + c);
-      const double g1 = entry((t1 & 255) * DB + r, (t1 >> 8) * DB + c);
-      if (on0) Bk[blk0 * SM_BLK + c * SM_LD + r] = g0;
-      if (on1) Bk[blk1 * SM_BLK + c * SM_LD + r] = g1;
+#pragma unroll
+    for (int i = 0; i < KVB; ++i) {
+      const int blk = wave + SM_WAVES * i;
+      if (blk < nblk) {
+        const int t = s.tb[blk], bi = t & 255, bj = t >> 8;
+        const int gj = bj * DB + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = bi * DB + lq + 4 * r;
+          double dq2[DMAX];
+          double k0 = 0.0, g;
+          if (gi < N && gj < N) {
+            k0 = kern.eval(s.xr, d, NP, gi, gj, ec, dq2);
+            g = gi == gj ? k0 + diag_add : k0;
+          } else g = (gi == gj) ? 1.0 : 0.0;   // identity padding keeps the factor well defined
+          kv[i][r] = k0;
+          Bk[blk * SM_BLK + l15 * SM_LD + lq + 4 * r] = g;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kv[i][r] = 0.0;
+      }
     }
   }
   __syncthreads();
@@ -456,7 +481,10 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
   double s_amp = 0.0, s_noise = 0.0, s_ell[DMAX];
 #pragma unroll
   for (int q = 0; q < DMAX; ++q) s_ell[q] = 0.0;
-  for (int blk = wave; blk < nblk; blk += SM_WAVES) {
+#pragma unroll
+  for (int i = 0; i < KVB; ++i) {
+    const int blk = wave + SM_WAVES * i;
+    if (blk >= nblk) continue;
     const int t = s.tb[blk], bi = t & 255, bj = t >> 8;
     acc_t a0 = acc_t{0, 0, 0, 0}, a1 = a0;
     int k = bi;
@@ -498,14 +526,10 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
       const int gi = bi * DB + lq + 4 * r;
       if (gi < N && gj < N) {
         double dq2[DMAX];
-#if defined(SM_PROBE) && SM_PROBE == 1   // timing probe (wrong results): no kernel evaluation in the gradient phase
-        double kv = s.xr[gi];
-        for (int q = 0; q < DMAX; ++q) dq2[q] = kv;
-#else
-        const double kv = kern.eval(s.xr, d, NP, gi, gj, ec, dq2);
-#endif
+        kern.diffs(s.xr, d, NP, gi, gj, dq2);
+        const double kvv = kv[i][r];
         const double w = s.al[gi] * alj - (a0[r] + a1[r]);
-        const double wk = wgt * w * kv;
+        const double wk = wgt * w * kvv;
         s_amp += wk;
 #pragma unroll
         for (int q = 0; q < DMAX; ++q) s_ell[q] += wk * dq2[q];
