@@ -86,6 +86,7 @@ struct cgp_ctx {
   size_t la_nd = 0, la_ni = 0;
   int sk_slots = 0;
   size_t lat_units = 0;   // fits x tile slots the latency schedule's partial-tile slab holds
+  int lat_img_fits = 0;   // fits the pre-update image buffer of the latency schedule holds (only windows of >= 3 block steps use it)
   // sliding windows (cgp_window_*)
   WindowArgs win{};
   int nwin = 0;
@@ -177,9 +178,11 @@ constexpr int LAT_FITS_F64 = 11, LAT_FITS_F32 = 20;
 // 0.920, 20 fits 1.010 vs 0.954; N = 1536 12 fits 1.487 vs 1.635, 16 fits 1.926 vs 1.682; N = 2048 11 (above).  fp32: N = 256 32 fits
 // 0.124 vs 0.133, 48 fits 0.154 vs 0.138; N = 512 24 fits 0.261 vs 0.272, 28 fits 0.290 vs 0.276; N = 768 20 fits 0.412 vs 0.414; N = 1024
 // 20 (above).  The slabs are sized for LAT_FITS_SHORT fits.
-constexpr int LAT_FITS_SHORT = 32;
+// (Round 4, tools/check_crossovers.py: fp64 N = 256 33 fits 0.168 latency vs 0.205 throughput -- the limit of 32 was the slab's,
+// not the crossover's; with round 3's 48 fits 0.225 vs 0.245 the fp64 limit for one and two block steps is 48.)
+constexpr int LAT_FITS_SHORT = 32, LAT_FITS_SHORT64 = 48;
 inline int lat_fits_by_steps(bool f64, int NT) {
-  if (NT <= 2) return LAT_FITS_SHORT;
+  if (NT <= 2) return f64 ? LAT_FITS_SHORT64 : LAT_FITS_SHORT;
   if (f64) return NT <= 4 ? 28 : NT <= 6 ? 22 : NT <= 8 ? 18 : NT <= 12 ? 13 : LAT_FITS_F64;
   return NT <= 4 ? 24 : LAT_FITS_F32;
 }
@@ -219,7 +222,7 @@ template <typename T> inline int mid_fits(int NT) {     // ablation build: CGP_M
   if (sizeof(T) == 8) return NT >= 8 ? MID_FITS_F32 : NT >= 6 ? 64 : MID_FITS_F64;
   return MID_FITS_F32;
 }
-constexpr int LAT_FITS_ALLOC = kAbBuild ? 64 : LAT_FITS_SHORT;  // slabs are sized for min(this, max_batch) fits
+constexpr int LAT_FITS_ALLOC = kAbBuild ? 64 : LAT_FITS_SHORT64;  // slabs are sized for min(this, max_batch) fits
 template <typename T> inline int lat_fits(int NT) {     // ablation build: CGP_LAT_FITS moves the crossover (measurement)
   if constexpr (kAbBuild) {
     const char *e = getenv("CGP_LAT_FITS");
@@ -589,7 +592,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     const bool split_trmm = !sw.sk_fused_trmm;
     // tile slots per fit of THIS call (slab and tickets are indexed with it; the tickets are zero between launches whatever the stride)
     const int call_slots = a.NT + a.ET + 1;
-    if ((size_t)batch * call_slots > c->lat_units) return CGP_ECAPACITY;
+    if ((size_t)batch * call_slots > c->lat_units || (a.NT >= 3 && batch > c->lat_img_fits)) return CGP_ECAPACITY;
     SplitArgs q{c->dpart, c->dticket, call_slots, 1, in_rows ? 1 : 0, c->dwready, c->dlatimg, split_trmm ? 0 : 1};
     for (int k = 0; k < a.NT; ++k) {
       const int tiles = (in_rows ? a.NT - k - 1 : 0) + a.ET;
@@ -926,7 +929,12 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc((void **)&c->dticket, sizeof(int) * c->lat_cap * c->sk_slots) == hipSuccess;
   ok = ok && hipMemset(c->dticket, 0, sizeof(int) * c->lat_cap * c->sk_slots) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dwready, sizeof(int) * c->lat_cap) == hipSuccess;
-  ok = ok && hipMalloc(&c->dlatimg, (size_t)c->lat_cap * 2 * LAT_IMG_MAX * DPART * c->esz) == hipSuccess;
+  // pre-update images exist from three block steps on (lat_images): sized for the most fits the latency schedule takes there
+  int img_fits = 1;
+  for (int nt = 3; nt <= std::max(3, c->NTmax); ++nt)
+    img_fits = std::max(img_fits, std::min(c->lat_cap, kAbBuild ? LAT_FITS_ALLOC : lat_fits_by_steps(dtype == CGP_F64, nt)));
+  c->lat_img_fits = c->NTmax >= 3 ? img_fits : 1;
+  ok = ok && hipMalloc(&c->dlatimg, (size_t)c->lat_img_fits * 2 * LAT_IMG_MAX * DPART * c->esz) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dmacc, sizeof(double) * 2 * B * std::max(c->max_m, 1)) == hipSuccess;
   ok = ok && hipMalloc(&c->ddiagimg, B * 2 * DPART * c->esz) == hipSuccess;
   c->mid_cap = std::min(MID_FITS_ALLOC, max_batch);
@@ -1003,7 +1011,7 @@ int cgp_debug_buffers(cgp_ctx *c, unsigned long long out[2 * CGP_DEBUG_BUFFERS])
                                        B * c->max_d * c->max_n * c->esz,
                                        sizeof(double) * 2 * B * std::max(c->max_m, 1),
                                        c->lat_units * SK_MAX * TS * TS * c->esz,
-                                       (size_t)c->lat_cap * 2 * LAT_IMG_MAX * DPART * c->esz};
+                                       (size_t)c->lat_img_fits * 2 * LAT_IMG_MAX * DPART * c->esz};
   for (int i = 0; i < CGP_DEBUG_BUFFERS; ++i) {
     out[2 * i] = (unsigned long long)(uintptr_t)p[i];
     out[2 * i + 1] = n[i];

@@ -26,7 +26,7 @@ FUS = {"diag inside": {"CGP_SCHED": "fuseddiag"}, "diag launches": {"CGP_SCHED":
 POINTS = [
     ("latency | throughput", "f64", 2048, 11, LAT), ("latency | throughput", "f64", 2048, 12, LAT),
     ("latency | throughput", "f64", 1024, 18, LAT), ("latency | throughput", "f64", 1024, 19, LAT),
-    ("latency | throughput", "f64", 256, 32, LAT), ("latency | throughput", "f64", 256, 33, LAT),
+    ("latency | throughput", "f64", 256, 48, LAT), ("latency | throughput", "f64", 256, 49, LAT),
     ("latency | throughput", "f32", 1024, 20, LAT), ("latency | throughput", "f32", 1024, 21, LAT),
     ("latency | throughput", "f32", 512, 24, LAT), ("latency | throughput", "f32", 512, 25, LAT),
     ("mid-size | full", "f32", 1024, 96, MID), ("mid-size | full", "f32", 1024, 97, MID),
