@@ -50,3 +50,14 @@ def test_fuzz_lookahead_prefix():
                        text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert " failures 0" in r.stdout.strip().splitlines()[-1], r.stdout[-500:]
+
+
+def test_fuzz_short_window_kernel_prefix():
+    """tests/fuzz/fuzz_small.py: the one-launch short-window kernel on every window length 2 ... 160, d = 1 ... 8, the three
+    kernels -- value, gradient and GPy's jitter against the oracle, cgp_predict after it (lazy refit), and the device
+    L-BFGS through cgp_optimize / cgp_optimize_batch (the builder ran 150 s of this seed clean)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_small.py"), "12", "1"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("cases ") and " failures 0 " in last, last
