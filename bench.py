@@ -342,7 +342,7 @@ def cfg3_strong_line(args, dry, world, rank, local, dev, cdev, use_dist, sync, t
     else:
         import corenav_gp_amd.engine as engine
         kid, X, y, Xs, th, dts = synth.config(3, batch=B, M=M_TEST, first=b0)
-        W3 = Workload(engine, torch, dev, local, kid, X, y, Xs, th, dts, 1)
+        W3 = Workload(engine, torch, dev, local, kid, X, y, Xs, th, dts, 2 if 56 <= B <= 96 else 1)   # a mid-size shard: two stream groups inside the call
         step = W3.step
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.1:   # working clock
@@ -365,7 +365,7 @@ def cfg3_strong_line(args, dry, world, rank, local, dev, cdev, use_dist, sync, t
         assert int(W3.dinfo.abs().sum().item()) == 0
     el = float(dt.item()) / steps
     return {"fits_per_s": total / el, "ms_per_step": el * 1e3, "fits_per_step_all_ranks": total, "fits_per_gpu_per_call": total / world,
-            "n_gpus": world, "scaling": "strong", "pipeline_depth": 1, "steps": steps,
+            "n_gpus": world, "scaling": "strong", "pipeline_depth": 1, "streams": 2 if 56 <= B <= 96 else 1, "steps": steps,
             "workload": f"BASELINE configs[2] as written: {total} x N=1024 d=6 SE-ARD fp32, M={M_TEST}, sharded over {world} ranks, "
                         "one context per GPU; divide by config.extra.cfg3_fits_per_s of the --gpus 1 line for the speed-up"}
 
@@ -629,7 +629,22 @@ def extras_cfg3(engine, torch, dev, local, W):
             ex["cfg3_strong_scaling_projection_8gpu"] = 8 * (64 / el64) / (512 / el)
             ex["cfg3_strong_scaling_note"] = ("8 x (64-fit call rate) / (512-fit call rate) on this one GPU; measure it with "
                                               "`bench.py --scaling strong --config 3 --gpus 8`")
-            # the same 64-fit calls dealt over TWO contexts on two HIP streams (what --scaling strong does by default):
+            # ONE context, the call cut into two stream groups of 32 fits (cgp_set_streams(2)): still the speed-up of one sweep
+            W64.ctx.set_streams(2)
+            for _ in range(10):
+                W64.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                W64.step()
+            torch.cuda.synchronize()
+            el64g = (time.perf_counter() - t0) / 20
+            W64.ctx.set_streams(1)
+            assert int(W64.dinfo.abs().sum().item()) == 0
+            ex["cfg3_ms_per_call_at_64_streams2"] = el64g * 1e3
+            ex["cfg3_fits_per_s_at_64_streams2"] = 64 / el64g
+            ex["cfg3_strong_scaling_projection_8gpu_streams2"] = 8 * (64 / el64g) / (512 / el)
+            # the same 64-fit calls dealt over TWO contexts on two HIP streams (--pipeline 2):
             # successive calls overlap, the chain-bound early block steps of one beside the MFMA-bound late ones of the other
             W64b = Workload(engine, torch, dev, local, kid, X[:64], y[:64], Xs[:64], th[:64], dts, 1)
             lanes = [W64, W64b]

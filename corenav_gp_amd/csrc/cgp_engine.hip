@@ -499,7 +499,14 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // diagonal tile's pre-update images (N <= 2560); anything else takes the throughput schedule
   const bool latency = !sw.no_latency && batch <= std::min(lat_fits<T>(a.NT), c->lat_cap) && a.NT >= CGP_LAT_MIN_NT && lat_images(a.NT - 1) <= LAT_IMG_MAX;
   const bool mid = batch <= std::min(mid_fits<T>(a.NT), c->mid_cap);  // the whole call (the images are indexed by fit)
-  if (latency || (mid && !(kAbBuild && getenv("CGP_MID_GROUPS")))) G = 1;  // a mid-size call has its own concurrency (factorisation || extra rows, below); -DCGP_AB + CGP_MID_GROUPS: measurement
+  // A latency-schedule call is one chain; an fp64 mid-size call has its own concurrency (factorisation || extra rows, below).
+  // An fp32 mid-size call honours cgp_set_streams: cut into groups on worker streams, the chain-bound early launches of
+  // one group run beside the others' (64 x N=1024: 0.99 -> 0.92 ms per call at two groups) -- as long as every group stays
+  // above the latency schedule's range (a group that small would switch schedule: four groups of 16 measured 1.50 ms).
+  // Two groups, from 56 fits (measured, ms per call at 1 / 2 / 3 groups: 48 fits 0.77 / 0.83 / 0.83, 64 fits 0.99 / 0.92 / 1.48,
+  // 96 fits 1.24 / 1.17 / 1.66).
+  if (latency || (mid && sizeof(T) == 8)) G = 1;
+  if (mid && G > 1) G = batch >= 56 && batch / 2 > lat_fits<T>(a.NT) ? 2 : 1;
   std::vector<FitArgs> ga(G);
   std::vector<int> gb(G);
   std::vector<hipStream_t> gs(G);

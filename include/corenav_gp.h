@@ -191,10 +191,12 @@ int cgp_sweep_fit_predict(cgp_sweep *sweep, int batch, int N, int d, int M, int 
                           int include_noise, double *mean, double *var, double *logml, int *info,
                           double *summary);
 
-/* Number of worker streams a LARGE batch is spread over (1..8, default 1): the batch is cut into that
+/* Number of worker streams a batch is spread over (1..8, default 1): the batch is cut into that
  * many groups whose launch schedules run concurrently (HIP streams + events, forked from and
  * joined to the caller's stream), so latency-bound launches of one group overlap MFMA-bound
- * launches of another. */
+ * launches of another.  Full-batch calls (hundreds of fits) gain nothing measurable; an fp32 call of 56 ... 96 fits
+ * (BASELINE configs[2] as sharded over 8 GPUs: 64 per GPU) is cut into TWO groups when n >= 2: 0.99 -> 0.92 ms per
+ * 64-fit call on one context.  Results do not depend on the setting (a fit's arithmetic is the same in any group). */
 int cgp_set_streams(cgp_ctx *ctx, int n);
 
 /* Development aid (-DCGP_ABLATION builds; all zero otherwise): in-kernel s_memtime sums.  [0, 8) potf2

@@ -303,6 +303,11 @@ def test_config3_as_sharded_64_fits_fp32(engine):
     rc, m2, v2, l2, i2 = ctx.fit_predict_batch(X[perm], y[perm], Xs[perm], th[perm], kid)
     assert rc == 0 and not i2.any()
     assert np.array_equal(m2, mean[perm]) and np.array_equal(v2, var[perm]) and np.array_equal(l2, logml[perm])
+    # cgp_set_streams(2): the same call as two stream groups of 32 fits on worker streams -- bitwise the same results
+    ctx.set_streams(2)
+    rc, m3, v3, l3, i3 = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0 and not i3.any()
+    assert np.array_equal(m3, mean) and np.array_equal(v3, var) and np.array_equal(l3, logml)
 
 
 @pytest.mark.parametrize("dtype_name,N,small,large", [("F32", 640, 64, 100), ("F32", 1024, 40, 97), ("F64", 640, 48, 52)])
