@@ -513,14 +513,18 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   for (int g = 0, g0 = 0; g < G; ++g) {
     gb[g] = batch / G + (g < batch % G ? 1 : 0);
     ga[g] = group_view<T>(a, g0);
-    gs[g] = (G == 1) ? s : c->wstream[g];
+    // group 0 stays on the caller's stream, the others go to worker streams: the workers live in another priority pool
+    // (cgp_create), so they never share a hardware queue with the caller's stream -- two WORKER streams may share one
+    // (the pool has few queues and every context creates eight streams: a 64-fit call as two groups on two workers ran
+    // 1.37 instead of 0.92 ms whenever other contexts existed in the process)
+    gs[g] = g == 0 ? s : c->wstream[g - 1];
     g0 += gb[g];
   }
   hipLaunchKernelGGL(k_prep, dim3(cdiv(batch, 64)), dim3(64), 0, s, a, batch, c->dprep, in_rows ? 1 : 0,
                      (latency && in_rows) ? c->dwready : nullptr);
   if (G > 1) {
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-    for (int g = 0; g < G; ++g) HIP_TRY(c, hipStreamWaitEvent(gs[g], c->ev_fork, 0));
+    for (int g = 1; g < G; ++g) HIP_TRY(c, hipStreamWaitEvent(gs[g], c->ev_fork, 0));
   }
   std::vector<Launcher> L;
   for (int g = 0; g < G; ++g) L.push_back(Launcher{c, gs[g]});
@@ -719,6 +723,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   HIP_TRY(c, hipGetLastError());
   if (G > 1) {
     for (int g = 0; g < G; ++g) {
+      if (g == 0) continue;   // group 0 ran on the caller's stream itself
       HIP_TRY(c, hipEventRecord(c->ev_join[g], gs[g]));
       HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[g], 0));
     }
