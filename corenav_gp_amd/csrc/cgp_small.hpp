@@ -37,7 +37,12 @@ constexpr int SM_LD = DB + 1;
 constexpr int SM_BLK = DB * SM_LD;         // elements per block
 constexpr int SM_THREADS = 512;
 constexpr int SM_WAVES = SM_THREADS / 64;
-constexpr int SM_NH = SM_WAVES - 2;        // helper waves beside the factor chain (every wave but 0 and its SIMD partner 4)
+#ifndef SM_HELPERS
+#define SM_HELPERS 7                       // `make variant` A/B: 6 = the chain wave's SIMD partner (wave 4) stays idle during the factor phases
+#endif
+constexpr int SM_NH = SM_HELPERS;          // helper waves beside the factor chain.  Measured (cycles per evaluation, N = 134): with 6 the chain
+                                           // issues alone on its SIMD (31 k) but the helpers end later (factor phases 48 k); with 7 the chain
+                                           // slows to 38 k and the phases end at 43.5 k
 constexpr int SM_DEAL = 12;                // entries of a helper's work list: count + at most 11 items
 constexpr int SM_OUT = 48;                 // doubles per window in SmallArgs::out ([32, 48): phase clocks of a -DCGP_ABLATION build)
 enum { SM_MODE_EVAL = 0, SM_MODE_OPT = 1 };
@@ -96,7 +101,7 @@ struct SmClock {
 };
 
 // Who does what beside the factor chain (sm_eval, phase F): for every step jb the items -- blocks (jp, j) of row jp = jb - 1
-// of W, cost jp - j + 1 products, code 0x100 | j; trailing blocks (bi, bj) with panel jp, one product, code bi << 4 | bj --
+// of W, cost jp - j + 1 products, code 0x100 | j; trailing blocks (bi, bj), bi > jb, bj >= jb, with panel jp, one product, code bi << 4 | bj --
 // are dealt to the SM_NH helper waves longest first, each to the helper with the least work so far.  Lists
 // deal[jb][helper] = {count, items...}; depends on the number of block rows only, built once per launch by thread jb.
 __device__ __forceinline__ void sm_build_deal(unsigned short *deal, int NB, int jb) {
@@ -111,8 +116,8 @@ __device__ __forceinline__ void sm_build_deal(unsigned short *deal, int NB, int 
   };
   const int jp = jb - 1;
   for (int j = 0; j < jp; ++j) give(0x100 | j, jp - j + 1);
-  for (int bi = jb + 1; bi < NB; ++bi)
-    for (int bj = jb + 1; bj <= bi; ++bj) give(bi << 4 | bj, 1);
+  for (int bi = jb + 1; bi < NB; ++bi)          // panel jp applied to every block below / right of the diagonal block jb,
+    for (int bj = jb; bj <= bi; ++bj) give(bi << 4 | bj, 1);   // column jb (rows >= jb + 1) included: block (jb, jb) is the chain's
   for (int h = 0; h < SM_NH; ++h) base[h * SM_DEAL] = (unsigned short)cnt[h];
 }
 
@@ -230,9 +235,8 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
   //   F(jb)  wave 0: factor + invert diagonal block jb in registers
   //          the other waves, meanwhile: row jb-1 of W (W_ij = -Dinv_i sum_{j <= q < i} L_iq W_qj; kept in registers
   //          until the barrier: it overwrites L_ij, which other blocks of the row still read) and the trailing update
-  //          with panel jb-1 of the block columns >= jb+1
-  //   P(jb)  panel L(i,jb) = A(i,jb) Dinv_jb^T;  U(jb)  update of block column jb+1 only with panel jb
-  // Wave 4 shares wave 0's SIMD and stays idle during F so the chain issues alone.
+  //          with panel jb-1 of everything below / right of block (jb, jb)
+  //   P(jb)  panel L(i,jb) = A(i,jb) Dinv_jb^T; the chain wave also updates the NEXT diagonal block with it
   auto inverse_block = [&](int i, int j) -> acc_t {   // W(i, j), i > j, returned in the accumulator layout
     acc_t t0 = acc_t{0, 0, 0, 0}, t1 = t0;
     int q = j;
@@ -307,21 +311,15 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
     for (int ks = 0; ks < 4; ++ks) acc = P::mfma(fa[ks], fb[ks], acc);
     return acc;
   };
-  // Helpers during F: every wave but 0 and its SIMD partner 4 (the chain issues alone on its SIMD).  What each of them does in
+  // Helpers during F: every wave but 0 (SM_HELPERS = 6: not its SIMD partner 4 either).  What each of them does in
   // step jb comes from a list built once per launch (sm_build_deal): the blocks (jp, j) of row jp = jb - 1 of W cost
   // jp - j + 1 products each, the trailing blocks one each.
-  const int helper = wave == 0 || wave == 4 ? -1 : (wave < 4 ? wave - 1 : wave - 2);
-  acc_t pend = acc_t{0, 0, 0, 0};   // wave 0: L(jb, jb-1), formed in the previous step's panel phase (see there)
+  const int helper = SM_NH == 7 ? wave - 1 : (wave == 0 || wave == 4 ? -1 : (wave < 4 ? wave - 1 : wave - 2));
   for (int jb = 0; jb < NB; ++jb) {
     acc_t wres[2];
     int wj[2] = {-1, -1};
     if (wave == 0) {
       double *dblk = Bk + sm_tri(jb, jb);
-      if (jb > 0) {
-        double *ab = Bk + sm_tri(jb, jb - 1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ab[(lq + 4 * r) * SM_LD + l15] = pend[r];
-      }
       double a[DB], w[DB];
       int bad = 0;
 #pragma unroll
@@ -359,59 +357,25 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
     ck.lap(s.sc, 2, tid);
     if (wj[0] >= 0) store_acc(Bk + sm_tri(jb - 1, wj[0]), wres[0]);
     if (wj[1] >= 0) store_acc(Bk + sm_tri(jb - 1, wj[1]), wres[1]);
-    // ---- P(jb) and U(jb) in one phase: a wave forms L(bi,jb) = A(bi,jb) Dinv_jb^T for its block rows AND (again, in
-    // registers) L(jb+1,jb), stores the former and updates C(bi, jb+1) -= L(bi,jb) L(jb+1,jb)^T straight from the two
-    // accumulators -- register `reg` of a product is the operand of k-step `reg` of the next (file header).  Block
-    // (jb+1, jb) itself is read by every wave in this phase, so its owner (wave 0) keeps L(jb+1,jb) in registers and
-    // stores it after the barrier, at the top of the next step (nobody reads it before step jb + 2).
-    if (jb + 1 < NB) {
-      // every operand of the three products is requested before the first MFMA; the two panel products are independent chains
-      const double *dj = Bk + sm_tri(jb, jb), *aj = Bk + sm_tri(jb + 1, jb);
-      int bi = jb + 1 + wave;
-      const bool mine = bi < NB;
-      double *ab = Bk + sm_tri(mine ? bi : jb + 1, jb), *cb = Bk + sm_tri(mine ? bi : jb + 1, jb + 1);
-      double fd[4], fj[4], fb[4];
-      acc_t acc = acc_t{0, 0, 0, 0};
+    // ---- P(jb): L(bi,jb) = A(bi,jb) Dinv_jb^T, one block row per wave, stored in place; the chain wave owns block row jb + 1
+    // and updates the next diagonal block C(jb+1,jb+1) -= L(jb+1,jb) L(jb+1,jb)^T straight from the accumulator (register
+    // `reg` of a product is the operand of k-step `reg` of the next, file header).  Every other block of the trailing
+    // matrix takes panel jb from the helpers during the next factor phase.
+    for (int bi = jb + 1 + wave; bi < NB; bi += SM_WAVES) {
+      const acc_t pb = panel_block(bi, jb);
+      double *ab = Bk + sm_tri(bi, jb);
+      if (bi == jb + 1) {
+        double *cb = Bk + sm_tri(bi, bi);
+        acc_t acc;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        fd[ks] = dj[(4 * ks + lq) * SM_LD + l15];        // Dinv_jb[m = l15][k]
-        fj[ks] = aj[(4 * ks + lq) * SM_LD + l15];        // A(jb+1,jb)[n = l15][k]
-        fb[ks] = ab[(4 * ks + lq) * SM_LD + l15];        // A(bi,jb)[n = l15][k]
-      }
-      if (mine) {
+        for (int r = 0; r < 4; ++r) acc[r] = cb[(lq + 4 * r) * SM_LD + l15];   // C[row = l15][col = lq + 4 r]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = cb[(lq + 4 * r) * SM_LD + l15];   // C(bi,jb+1)[row = l15][col = lq + 4 r]
-      }
-      acc_t pj = acc_t{0, 0, 0, 0}, pb = pj;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        pj = P::mfma(fd[ks], fj[ks], pj);
-        pb = P::mfma(fd[ks], fb[ks], pb);
-      }
-      if (mine) {
-        if (bi == jb + 1) pend = pb;
-        else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ab[(lq + 4 * r) * SM_LD + l15] = pb[r];  // L(bi,jb)[row = l15][col = lq + 4 r]
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc = P::mfma(-pj[ks], pb[ks], acc);
+        for (int ks = 0; ks < 4; ++ks) acc = P::mfma(-pb[ks], pb[ks], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) cb[(lq + 4 * r) * SM_LD + l15] = acc[r];
       }
-      for (bi += SM_WAVES; bi < NB; bi += SM_WAVES) {   // more block rows than waves (ten block rows, first step)
-        const acc_t p2 = panel_block(bi, jb);
-        double *a2 = Bk + sm_tri(bi, jb), *c2 = Bk + sm_tri(bi, jb + 1);
-        acc_t ac2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ac2[r] = c2[(lq + 4 * r) * SM_LD + l15];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a2[(lq + 4 * r) * SM_LD + l15] = p2[r];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) ac2 = P::mfma(-pj[ks], p2[ks], ac2);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c2[(lq + 4 * r) * SM_LD + l15] = ac2[r];
-      }
+      for (int r = 0; r < 4; ++r) ab[(lq + 4 * r) * SM_LD + l15] = pb[r];      // L(bi,jb)[row = l15][col = lq + 4 r]
     }
     lds_barrier();
     ck.lap(s.sc, 3, tid);
