@@ -558,10 +558,11 @@ __device__ __forceinline__ void sm_trial_point(const SmallLds &s, const SmallArg
   }
 }
 
-// The per-evaluation constants from theta and the jitter: 1 / ell_q (one lane per dimension), amplitudes, diagonal addend
+// The per-evaluation constants from theta and the jitter: 1 / ell_q (one lane per dimension), amplitudes, diagonal addend.
+// Called by the first wave right after sm_trial_point (same wave: its LDS writes are visible to its later reads in order).
 __device__ __forceinline__ void sm_constants(const SmallLds &s, int kid, int d, int nth, int tid) {
   if (tid < MAXD) s.sc[10 + tid] = tid < d ? ((kid == K_SE_ARD) ? 1.0 / s.sc[1 + tid] : 1.0 / s.sc[1]) : 0.0;
-  if (tid == 64) {
+  if (tid == MAXD) {
     s.sc[18] = s.sc[0];
     s.sc[19] = (kid == K_RBF_BROWNIAN) ? s.sc[2] : 0.0;
     s.sc[20] = s.sc[nth - 1] + 1e-8 + s.sc[21];
@@ -889,16 +890,18 @@ __global__ __launch_bounds__(SM_THREADS) void k_small(SmallArgs p) {
   }
   __syncthreads();
   const int max_rounds = p.mode == SM_MODE_OPT ? p.max_evals + 64 : 1;
+  // the first trial point and its constants by the first wave; every later one right behind the L-BFGS step, on the same
+  // wave, without a workgroup barrier in between (LDS accesses of one wave are in order)
+  if (tid < 64) {
+    sm_trial_point(s, p, nth, thb, tid);
+    sm_constants(s, kid, d, nth, tid);
+  }
+  __syncthreads();
   for (int round = 0; round < max_rounds; ++round) {
     SmClock ck;
     ck.start();
-    sm_trial_point(s, p, nth, thb, tid);
-    __syncthreads();
     // GPy jitchol: retry a matrix that is not positive definite with jitter mean(diag) 1e-6 10^k, k = 0..4
     for (;;) {
-      sm_constants(s, kid, d, nth, tid);
-      __syncthreads();
-      ck.lap(s.sc, 0, tid);
       sm_eval<BROWN, DMAX>(s, d, N, NB, tid);
       const int bad = s.flag[0];
       const int attempt = s.flag[2];
@@ -908,13 +911,21 @@ __global__ __launch_bounds__(SM_THREADS) void k_small(SmallArgs p) {
         const double noise = s.sc[nth - 1] + 1e-8;
         const double md = BROWN ? s.sc[0] * s.sc[2] * s.sc[23] + noise : s.sc[0] + noise;
         s.sc[21] = attempt == 0 ? md * 1e-6 : s.sc[21] * 10.0;
+        s.sc[20] = noise + s.sc[21];   // the diagonal addend is the only constant the jitter changes
         s.flag[2] = attempt + 1;
+        s.flag[0] = 0;
       }
       __syncthreads();
       ck.start();
     }
     ck.start();
-    if (tid < 64) sm_wave0_tell(s, p, kid, d, nth, ob, tid);
+    if (tid < 64) {
+      sm_wave0_tell(s, p, kid, d, nth, ob, tid);
+      if (p.mode == SM_MODE_OPT && !s.lb->finished) {
+        sm_trial_point(s, p, nth, thb, tid);
+        sm_constants(s, kid, d, nth, tid);
+      }
+    }
     ck.lap(s.sc, 8, tid);
     __syncthreads();
     if (s.flag[1]) break;
