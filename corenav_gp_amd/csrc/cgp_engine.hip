@@ -55,6 +55,7 @@ struct cgp_ctx {
   // one-workgroup-per-fit potf2 launches of one group overlap the MFMA launches of the others
   static constexpr int kMaxStreams = 8;
   hipStream_t wstream[kMaxStreams] = {nullptr};
+  hipStream_t hstream = nullptr;   // highest stream priority: for a latency chain that must be dispatched AHEAD of bulk work on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr};
   hipEvent_t ev_look[3 * 64] = {nullptr};  // look-ahead schedule: diag / P1 / P2 completion per step
   int nstreams = 1;   // cgp_set_streams: worker streams a LARGE batch is cut over (measured: no gain since the diagonal tiles ride in the panel launches)
@@ -512,6 +513,10 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   std::vector<hipStream_t> gs(G);
   for (int g = 0, g0 = 0; g < G; ++g) {
     gb[g] = batch / G + (g < batch % G ? 1 : 0);
+    if constexpr (kAbBuild) {   // measurement: CGP_GROUP0 = fits of group 0 of two (uneven halves run out of step with each other)
+      const char *e = getenv("CGP_GROUP0");
+      if (e && G == 2 && atoi(e) > 0 && atoi(e) < batch) gb[g] = g == 0 ? atoi(e) : batch - atoi(e);
+    }
     ga[g] = group_view<T>(a, g0);
     // group 0 stays on the caller's stream, the others go to worker streams: the workers live in another priority pool
     // (cgp_create), so they never share a hardware queue with the caller's stream -- two WORKER streams may share one
@@ -557,11 +562,12 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     // below the diagonal (the only one the next diagonal tile needs) and P2 = all the others, and
     //     sA:  P1(k) -> diag(k+1)            sB:  P2(k)
     // run concurrently; events carry the cross dependencies.  Measured: no gain.
-    hipStream_t sA = c->wstream[0], sB = c->wstream[1];
+    // sA = the context's HIGH-priority stream (the chain P1 -> diag must be dispatched ahead of the bulk P2 queued on the
+    // caller's stream; round 1-3 ran both on equal-priority worker streams, which may even have shared a hardware queue)
+    hipStream_t sA = c->hstream, sB = s;
     auto ev = [&](int i) { return c->ev_look[i]; };
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
     HIP_TRY(c, hipStreamWaitEvent(sA, c->ev_fork, 0));
-    HIP_TRY(c, hipStreamWaitEvent(sB, c->ev_fork, 0));
     FitArgs a1 = ga[0], a2 = ga[0];
     a1.tile_off = 0;
     a2.tile_off = 1;
@@ -912,6 +918,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
     ok = ok && hipStreamCreateWithPriority(&c->wstream[i], hipStreamNonBlocking, prio_least) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
   }
+  ok = ok && hipStreamCreateWithPriority(&c->hstream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
   for (auto &e : c->ev_look) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc(&c->Lw, B * c->lw_stride * c->esz) == hipSuccess;
@@ -985,6 +992,10 @@ void cgp_destroy(cgp_ctx *c) {
       (void)hipStreamDestroy(c->wstream[i]);
     }
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+  }
+  if (c->hstream) {
+    (void)hipStreamSynchronize(c->hstream);
+    (void)hipStreamDestroy(c->hstream);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   for (auto e : c->ev_look)
