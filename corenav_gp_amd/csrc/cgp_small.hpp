@@ -43,7 +43,7 @@ constexpr int SM_WAVES = SM_THREADS / 64;
 constexpr int SM_NH = SM_HELPERS;          // helper waves beside the factor chain.  Measured (cycles per evaluation, N = 134): with 6 the chain
                                            // issues alone on its SIMD (31 k) but the helpers end later (factor phases 48 k); with 7 the chain
                                            // slows to 38 k and the phases end at 43.5 k
-constexpr int SM_DEAL = 12;                // entries of a helper's work list: count + at most 11 items
+constexpr int SM_DEAL = 16;                // entries of a helper's work list: count + at most 15 items (ten block rows, six helpers: 52 items of a step, at most 12 on one)
 constexpr int SM_OUT = 48;                 // doubles per window in SmallArgs::out ([32, 48): phase clocks of a -DCGP_ABLATION build)
 enum { SM_MODE_EVAL = 0, SM_MODE_OPT = 1 };
 // out[]: 0 logML (at theta / at the optimum), 1 evaluations, 2 L-BFGS status, 3 iterations, 4 info (first non-positive
