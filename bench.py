@@ -868,6 +868,7 @@ def cpu_baseline(kid, X, y, Xs, th, nsample, dmean, dvar, dlogml, f_fit, context
                                              f"limited to ONE thread (threadpoolctl); {f_fit / m1 / 1e9:.2f} GFLOP/s"}
     except Exception as e:
         rows["lapack_1_thread"] = {"error": repr(e)}
+    lapack_run = None
     # the same steps in C on LAPACK / BLAS (dpotrf, dpotrs, dtrsm, dgemv of scipy's bundled OpenBLAS, dlopen'ed and held to ONE
     # thread) with a vectorised Gram loop: the "Eigen::LLT-class" row -- no numpy temporaries in the denominator
     try:
@@ -900,6 +901,7 @@ def cpu_baseline(kid, X, y, Xs, th, nsample, dmean, dvar, dlogml, f_fit, context
         assert w2 < tol, f"timed GPU outputs differ from the LAPACK oracle: {w2:.3e}"
         m2 = statistics.median(r[0] for r in res)
         tpo = statistics.median(r[5] for r in res)
+        lapack_run = run2
         rows["c_lapack_1_thread"] = {"value": 1.0 / m2, "unit": "fits/s", "threads": 1,
                                      "dpotrf_gflops": N ** 3 / 3.0 / tpo / 1e9,
                                      "sample": f"median of {n2} of the step's windows after 2 warm-ups through oracle/gp_oracle_lapack.c (gcc -O3 "
@@ -930,6 +932,24 @@ def cpu_baseline(kid, X, y, Xs, th, nsample, dmean, dvar, dlogml, f_fit, context
                                            "sample": f"{nw} windows after a {ncore}-window warm-up, {el2:.1f} s"}
     except Exception as e:
         base["port_threads_over_batch"] = {"error": repr(e)}
+    # the same with the LAPACK row: what every core of the container makes of the sweep (each call single-threaded, one window
+    # per host thread) -- the strongest CPU figure this host offers, for scale; not the reference's single-threaded build
+    if lapack_run is not None:
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            ncore = max(1, host["usable_cpus"])
+            nw = 8 * ncore
+            with ThreadPoolExecutor(max_workers=ncore) as ex:
+                list(ex.map(lambda i: lapack_run(i)[1], range(ncore)))
+                t2 = time.perf_counter()
+                rcs = list(ex.map(lambda i: lapack_run(i)[1], range(nw)))
+                el2 = time.perf_counter() - t2
+            assert not any(rcs)
+            base["lapack_threads_over_batch"] = {"value": nw / el2, "unit": "fits/s", "threads": ncore,
+                                                 "kind": "C + OpenBLAS (one thread per call), one window per host thread, all usable CPUs of the container",
+                                                 "sample": f"{nw} windows after a {ncore}-window warm-up, {el2:.1f} s"}
+        except Exception as e:
+            base["lapack_threads_over_batch"] = {"error": repr(e)}
     return base
 
 
