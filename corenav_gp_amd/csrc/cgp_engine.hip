@@ -101,6 +101,10 @@ struct cgp_ctx {
   size_t opt_pin_cap = 0;
   int *dinfo = nullptr;
   double *dsmall = nullptr;   // [max_batch][SM_OUT] results of the one-launch short-window kernel (k_small, fp64 contexts)
+  unsigned short *dsmdeal = nullptr;   // k_small's helper work lists (sm_build_deal) of every NB <= SM_MAX_NB, at smdeal_off[NB]
+  size_t smdeal_off[SM_MAX_NB + 1] = {0};
+  std::vector<double> lazy_win;   // [X (N, d) | y] of the window a short-window kernel evaluated in place (ensure_fitted uploads it)
+  double last_small[SM_OUT] = {0};   // the last single-window short-window record (the kernels write it to pinned host memory)
   size_t lw_stride = 0, winv_stride = 0, alpha_stride = 0;
   // state of the last single fit (cgp_fit -> cgp_predict)
   bool have_fit = false;
@@ -123,6 +127,17 @@ struct cgp_ctx {
 namespace {
 
 int ensure_fitted(cgp_ctx *c);   // below, with the short-window paths
+bool small_batch_predict_ok(const cgp_ctx *c, int batch, int N, int d, int M);
+struct SmallRaw;
+struct SmallDev {   // a batch resident in the caller's device buffers (cgp_fit_predict_batch_device): no ladder, jitter as given
+  const double *X, *y, *Xs, *theta, *jitter;
+  double *logml;
+  int *info;
+};
+int small_predict_launch(cgp_ctx *c, int batch, int N, int d, int M, int kid, int include_noise, double *dmean, double *dvar, double *dout,
+                         hipStream_t s, const SmallRaw *raw = nullptr, const SmallDev *dev = nullptr);
+int node_callback_small(cgp_ctx *c, const double *time_array, const double *slip_array, int n, int kid, double *theta, int max_evals,
+                        double *mean, double *sigma, int cap, int *m_out);
 bool grow_pinned(void *&p, size_t &cap, size_t bytes);
 bool grow_device(void *&p, size_t &cap, size_t bytes);
 
@@ -283,6 +298,8 @@ template <typename F> int for_each_small_kernel(F &&f) {
   if (rc == 0) rc = f(reinterpret_cast<const void *>(&k_small<false, 8>));
   return rc;
 }
+inline size_t small_predict_lds(int NB, int d) { return ((small_lds_bytes(NB, d) + 15) & ~(size_t)15) + small_predict_lds_extra(NB, d); }
+constexpr size_t kLdsPerWorkgroup = 160 * 1024;   // gfx950
 int set_small_attr(int device) {
   static bool done[64] = {false};
   if (device >= 0 && device < 64 && done[device]) return 0;
@@ -290,6 +307,10 @@ int set_small_attr(int device) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(SM_MAX_NB, MAXD)) == hipSuccess ? 0 : -1;
   });
   if (rc != 0) return -1;
+  const void *pk[] = {reinterpret_cast<const void *>(&k_small_predict<true, 1>), reinterpret_cast<const void *>(&k_small_predict<false, 1>),
+                      reinterpret_cast<const void *>(&k_small_predict<false, 3>), reinterpret_cast<const void *>(&k_small_predict<false, 8>)};
+  for (const void *fn : pk)
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerWorkgroup) != hipSuccess) return -1;
   if (device >= 0 && device < 64) done[device] = true;
   return 0;
 }
@@ -965,6 +986,16 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
   ok = ok && hipMalloc((void **)&c->dinfo, B * sizeof(int)) == hipSuccess;
   if (dtype == CGP_F64) {
     ok = ok && hipMalloc((void **)&c->dsmall, B * SM_OUT * sizeof(double)) == hipSuccess;
+    {
+      std::vector<unsigned short> tab;
+      for (int NB = 1; NB <= SM_MAX_NB; ++NB) {
+        c->smdeal_off[NB] = tab.size();
+        tab.resize(tab.size() + (size_t)NB * SM_NH * SM_DEAL, 0);
+        for (int jb = 0; jb < NB; ++jb) sm_build_deal(tab.data() + c->smdeal_off[NB], NB, jb);
+      }
+      ok = ok && hipMalloc((void **)&c->dsmdeal, tab.size() * sizeof(unsigned short)) == hipSuccess;
+      ok = ok && hipMemcpy(c->dsmdeal, tab.data(), tab.size() * sizeof(unsigned short), hipMemcpyHostToDevice) == hipSuccess;
+    }
     ok = ok && set_small_attr(device) == 0;
   }
   if (!ok) {
@@ -983,7 +1014,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg, c->dpanimg, c->dsmall};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg, c->dpanimg, c->dsmall, c->dsmdeal};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {
@@ -1046,8 +1077,7 @@ int cgp_debug_small(cgp_ctx *c, double out[CGP_SMALL_OUT]) {
   if (!c || !out) return CGP_EINVAL;
   if (!c->dsmall) return CGP_ESTATE;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipDeviceSynchronize());
-  HIP_TRY(c, hipMemcpy(out, c->dsmall, SM_OUT * sizeof(double), hipMemcpyDeviceToHost));
+  memcpy(out, c->last_small, SM_OUT * sizeof(double));
   return CGP_OK;
 }
 
@@ -1129,6 +1159,11 @@ int cgp_fit_predict_batch_device(cgp_ctx *c, int batch, int N, int d, int M, int
   a.info = dinfo;
   c->have_fit = false;
   c->lazy_fit = false;
+  if (small_batch_predict_ok(c, batch, N, d, M)) {   // short windows: fit + predictions of the whole batch in ONE launch, factors in LDS
+    const SmallDev dev{static_cast<const double *>(dX), static_cast<const double *>(dy), static_cast<const double *>(dXs), dtheta, djitter, dlogml, dinfo};
+    return small_predict_launch(c, batch, N, d, M, kid, include_noise, static_cast<double *>(dmean), static_cast<double *>(dvar), c->dsmall,
+                                pick_stream(c, hip_stream), nullptr, &dev);
+  }
   return run(c, a, batch, true, false, pick_stream(c, hip_stream));
 }
 
@@ -1409,6 +1444,12 @@ int cgp_slip_node_callback(cgp_ctx *c, const double *time_array, const double *s
   if (m_out) *m_out = (int)mo;
   const int M = (int)std::min<long long>(mo, cap);
   if (M == 0) return CGP_OK;
+  {   // a short fp64 window (the reference's 149-tick GP_Input is one): fit and predictions in one launch
+    double th[CGP_MAX_THETA];
+    std::copy(theta, theta + ntheta(kid, 1), th);
+    const int rs = node_callback_small(c, time_array, slip_array, n, kid, th, 0, mean, sigma, cap, m_out);
+    if (rs != CGP_ESTATE) return rs;
+  }
   std::vector<double> xs(M), var(M);
   for (int m = 0; m < M; ++m) xs[m] = xmin + (double)(n + m);
   // GPRegression(...) and the m.predict loop (gp_slip_node.py:35,45-49) in ONE factorisation pass: the
@@ -1586,26 +1627,36 @@ double mean_diag_from(int kid, const double *theta, int d, double meanabs) {   /
   return kid == CGP_KERNEL_RBF_BROWNIAN ? theta[0] * theta[2] * meanabs + noise : theta[0] + noise;
 }
 
-// ONE window (X (N, d) row-major, y, theta) to slot 0: staged in the pinned block, one H2D, one unpack launch
-int small_stage_window(cgp_ctx *c, const double *X, const double *y, int N, int d, const double *theta, int nth, hipStream_t s) {
-  const size_t nX = (size_t)N * d, in_bytes = (nX + N + CGP_MAX_THETA) * sizeof(double);
-  if (!grow_pinned(c->pin_in, c->pin_in_cap, in_bytes) || !grow_device(c->draw, c->draw_cap, in_bytes)) return CGP_ENOMEM;
+// ONE window (X (N, d) row-major, y, theta) and optionally M test points staged in the pinned block [X | y | Xs | theta],
+// which the short-window kernels read in place: no copy command and no unpack launch in front of them (8 KB over the
+// host link inside a launch costs less than either)
+struct SmallRaw {
+  const double *X, *y, *Xs;
+  double *theta;
+};
+int small_stage_window(cgp_ctx *c, const double *X, const double *y, int N, int d, const double *Xs, int M, const double *theta, int nth,
+                       SmallRaw &r) {
+  const size_t nX = (size_t)N * d, nXs = (size_t)M * d, in_bytes = (nX + N + nXs + CGP_MAX_THETA) * sizeof(double);
+  if (!grow_pinned(c->pin_in, c->pin_in_cap, in_bytes)) return CGP_ENOMEM;
   double *hin = static_cast<double *>(c->pin_in);
   memcpy(hin, X, nX * sizeof(double));
   memcpy(hin + nX, y, (size_t)N * sizeof(double));
-  for (int q = 0; q < CGP_MAX_THETA; ++q) hin[nX + N + q] = q < nth ? theta[q] : 0.0;
-  HIP_TRY(c, hipMemcpyAsync(c->draw, hin, in_bytes, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_pack_call<double>, dim3(std::min(64, cdiv(N * d, 256)), 1), dim3(256), 0, s, static_cast<const double *>(c->draw),
-                     static_cast<double *>(c->dX), static_cast<double *>(c->dy), static_cast<double *>(c->dXs), c->dtheta, c->djitter, 1, N, d, 0);
+  if (Xs) memcpy(hin + nX + N, Xs, nXs * sizeof(double));
+  for (int q = 0; q < CGP_MAX_THETA; ++q) hin[nX + N + nXs + q] = q < nth ? theta[q] : 0.0;
+  r = SmallRaw{hin, hin + nX, hin + nX + N, hin + nX + N + nXs};
   return CGP_OK;
 }
 
-int small_launch(cgp_ctx *c, int batch, int N, int d, int kid, int mode, int max_evals, hipStream_t s) {
+int small_launch(cgp_ctx *c, int batch, int N, int d, int kid, int mode, int max_evals, hipStream_t s, double *out = nullptr,
+                 const SmallRaw *raw = nullptr) {
   SmallArgs a{};
-  a.X = static_cast<const double *>(c->dX);
-  a.y = static_cast<const double *>(c->dy);
-  a.theta = c->dtheta;
-  a.out = c->dsmall;
+  a.X = raw ? raw->X : static_cast<const double *>(c->dX);
+  a.y = raw ? raw->y : static_cast<const double *>(c->dy);
+  a.theta = raw ? raw->theta : c->dtheta;
+  a.x_sq = raw ? 1 : N;
+  a.x_sr = raw ? d : 1;
+  a.out = out ? out : c->dsmall;
+  a.deal = c->dsmdeal + c->smdeal_off[cdiv(N, DB)];
   a.N = N;
   a.d = d;
   a.kernel_id = kid;
@@ -1623,19 +1674,77 @@ int small_launch(cgp_ctx *c, int batch, int N, int d, int kid, int mode, int max
   return CGP_OK;
 }
 
-// results of slot 0 -> the pinned block (behind its input part) -> host; one synchronisation
-int small_read_one(cgp_ctx *c, double out[SM_OUT], hipStream_t s) {
-  if (!grow_pinned(c->opt_pin, c->opt_pin_cap, (kOptPinIn + 64 + SM_OUT) * sizeof(double))) return CGP_ENOMEM;
-  double *h = static_cast<double *>(c->opt_pin) + kOptPinIn;
-  HIP_TRY(c, hipMemcpyAsync(h, c->dsmall, SM_OUT * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipStreamSynchronize(s));
-  memcpy(out, h, SM_OUT * sizeof(double));
+// fit at the theta slots + prediction of M test points per window in ONE launch (k_small_predict); `parts` workgroups per window
+inline bool small_predict_ok(const cgp_ctx *c, int N, int d, int M) {
+  return small_ok(c, N) && M > 0 && small_predict_lds(cdiv(N, DB), d) <= kLdsPerWorkgroup;
+}
+bool small_batch_predict_ok(const cgp_ctx *c, int batch, int N, int d, int M) {
+  static const bool off = [] {
+    const char *e = kAbBuild ? getenv("CGP_SMALLPRED") : nullptr;
+    return e && std::string(e) == "off";
+  }();
+  return !off && batch <= c->max_batch && small_predict_ok(c, N, d, M);
+}
+int small_predict_launch(cgp_ctx *c, int batch, int N, int d, int M, int kid, int include_noise, double *dmean, double *dvar, double *dout,
+                         hipStream_t s, const SmallRaw *raw, const SmallDev *dev) {
+  SmallArgs a{};
+  a.ladder = 1;
+  a.X = raw ? raw->X : static_cast<const double *>(c->dX);
+  a.y = raw ? raw->y : static_cast<const double *>(c->dy);
+  a.theta = raw ? raw->theta : c->dtheta;
+  a.x_sq = raw ? 1 : N;
+  a.x_sr = raw ? d : 1;
+  a.xs_sq = raw ? 1 : M;
+  a.xs_sr = raw ? d : 1;
+  a.out = dout;
+  a.deal = c->dsmdeal + c->smdeal_off[cdiv(N, DB)];
+  a.N = N;
+  a.d = d;
+  a.kernel_id = kid;
+  a.nth = ntheta(kid, d);
+  a.Xs = raw ? raw->Xs : static_cast<const double *>(c->dXs);
+  if (dev) {
+    a.X = dev->X, a.y = dev->y, a.Xs = dev->Xs, a.theta = const_cast<double *>(dev->theta);
+    a.jitter = dev->jitter, a.logml = dev->logml, a.info = dev->info, a.ladder = 0;
+  }
+  a.mean = dmean;
+  a.var = dvar;
+  a.M = M;
+  a.include_noise = include_noise;
+  const int nchunk = cdiv(M, DB);
+  // every workgroup repeats its window's fit (one workgroup per CU: the factor fills the LDS), so: as many parts as keep the
+  // launch to ONE round of workgroups -- a lone window: a chunk of 16 test points each; >= n_cu windows: one workgroup each
+  a.parts = std::max(1, std::min(nchunk, std::max(c->n_cu, 1) / batch));
+  const size_t lds = small_predict_lds(cdiv(N, DB), d);
+  const dim3 grid(batch * a.parts), block(SM_THREADS);
+  if (kid == CGP_KERNEL_RBF_BROWNIAN) hipLaunchKernelGGL((k_small_predict<true, 1>), grid, block, lds, s, a);
+  else if (d <= 1) hipLaunchKernelGGL((k_small_predict<false, 1>), grid, block, lds, s, a);
+  else if (d <= 3) hipLaunchKernelGGL((k_small_predict<false, 3>), grid, block, lds, s, a);
+  else hipLaunchKernelGGL((k_small_predict<false, 8>), grid, block, lds, s, a);
+  HIP_TRY(c, hipGetLastError());
   return CGP_OK;
 }
 
-void small_mark_fitted(cgp_ctx *c, const double *X, int N, int d, int kid, const double *theta, double jitter, bool ok) {
+// the single-window record: the kernel writes it to the pinned block (behind its input part); one synchronisation
+double *small_record_slot(cgp_ctx *c) {
+  if (!grow_pinned(c->opt_pin, c->opt_pin_cap, (kOptPinIn + 64 + SM_OUT) * sizeof(double))) return nullptr;
+  return static_cast<double *>(c->opt_pin) + kOptPinIn;
+}
+int small_read_one(cgp_ctx *c, const double *slot, double out[SM_OUT], hipStream_t s) {
+  HIP_TRY(c, hipStreamSynchronize(s));
+  memcpy(out, slot, SM_OUT * sizeof(double));
+  memcpy(c->last_small, slot, SM_OUT * sizeof(double));
+  return CGP_OK;
+}
+
+void small_mark_fitted(cgp_ctx *c, const double *X, const double *y, int N, int d, int kid, const double *theta, double jitter, bool ok) {
   c->have_fit = ok;
   c->lazy_fit = ok;
+  if (ok) {
+    c->lazy_win.resize((size_t)N * d + N);
+    memcpy(c->lazy_win.data(), X, (size_t)N * d * sizeof(double));
+    memcpy(c->lazy_win.data() + (size_t)N * d, y, (size_t)N * sizeof(double));
+  }
   c->f_meandiag_x = mean_abs_first(X, N, d);
   c->fjitter = ok ? jitter : 0.0;
   c->fN = N;
@@ -1650,6 +1759,13 @@ int ensure_fitted(cgp_ctx *c) {
   if (!c->lazy_fit) return CGP_OK;
   c->lazy_fit = false;
   hipStream_t s = c->stream;
+  {   // the window was evaluated where the caller's copy was staged: bring it (and theta) to slot 0 now
+    int rc = upload_window(c, c->lazy_win.data(), c->lazy_win.data() + (size_t)c->fN * c->fd, c->fN, c->fd, s);
+    if (rc != CGP_OK) return rc;
+    double th[CGP_MAX_THETA] = {0};
+    std::copy(c->ftheta, c->ftheta + ntheta(c->fkernel, c->fd), th);
+    HIP_TRY(c, hipMemcpyAsync(c->dtheta, th, sizeof th, hipMemcpyHostToDevice, s));   // pageable source: staged before the call returns
+  }
   FitArgs a = base_args(c, c->fN, c->fd, 0, c->fkernel, 0);
   a.X = c->dX;
   a.Xs = c->dXs;
@@ -1679,13 +1795,16 @@ int ensure_fitted(cgp_ctx *c) {
 int small_nll_grad(cgp_ctx *c, const double *X, const double *y, int N, int d, int kid, const double *theta, double *nll, double *grad) {
   hipStream_t s = c->stream;
   const int nth = ntheta(kid, d);
-  int rc = small_stage_window(c, X, y, N, d, theta, nth, s);
-  if (rc == CGP_OK) rc = small_launch(c, 1, N, d, kid, SM_MODE_EVAL, 1, s);
+  double *slot = small_record_slot(c);
+  if (!slot) return CGP_ENOMEM;
+  SmallRaw raw;
+  int rc = small_stage_window(c, X, y, N, d, nullptr, 0, theta, nth, raw);
+  if (rc == CGP_OK) rc = small_launch(c, 1, N, d, kid, SM_MODE_EVAL, 1, s, slot, &raw);
   double out[SM_OUT];
-  if (rc == CGP_OK) rc = small_read_one(c, out, s);
+  if (rc == CGP_OK) rc = small_read_one(c, slot, out, s);
   if (rc != CGP_OK) return rc;
   const int info = (int)out[SMO_INFO];
-  small_mark_fitted(c, X, N, d, kid, theta, out[SMO_JITTER], info == 0);
+  small_mark_fitted(c, X, y, N, d, kid, theta, out[SMO_JITTER], info == 0);
   if (info != 0) return info;
   *nll = -out[SMO_LOGML];
   for (int i = 0; i < nth; ++i) grad[i] = out[SMO_GRAD + i];
@@ -1699,17 +1818,20 @@ int small_optimize(cgp_ctx *c, const double *X, const double *y, int N, int d, i
   const int nth = ntheta(kid, d);
   for (int i = 0; i < nth; ++i)
     if (!(theta[i] > 0.0)) return CGP_EINVAL;
-  int rc = small_stage_window(c, X, y, N, d, theta, nth, s);
-  if (rc == CGP_OK) rc = small_launch(c, 1, N, d, kid, SM_MODE_OPT, max_evals, s);
+  double *slot = small_record_slot(c);
+  if (!slot) return CGP_ENOMEM;
+  SmallRaw raw;
+  int rc = small_stage_window(c, X, y, N, d, nullptr, 0, theta, nth, raw);
+  if (rc == CGP_OK) rc = small_launch(c, 1, N, d, kid, SM_MODE_OPT, max_evals, s, slot, &raw);
   double out[SM_OUT];
-  if (rc == CGP_OK) rc = small_read_one(c, out, s);
+  if (rc == CGP_OK) rc = small_read_one(c, slot, out, s);
   if (rc != CGP_OK) return rc;
   if (out[SMO_INFO] != 0.0) {   // the start itself is not positive definite even with the jitter ladder
     c->have_fit = false;
     return 1;
   }
   for (int i = 0; i < nth; ++i) theta[i] = out[SMO_THETA + i];
-  small_mark_fitted(c, X, N, d, kid, theta, 0.0, true);
+  small_mark_fitted(c, X, y, N, d, kid, theta, 0.0, true);
   if (logml) *logml = out[SMO_LOGML];
   if (n_evals) *n_evals = (int)out[SMO_EVALS];
   return CGP_OK;
@@ -1773,15 +1895,16 @@ extern "C" int cgp_optimize(cgp_ctx *c, const double *X, const double *y, int N,
 
 namespace {
 // The reference node's whole callback (gp_slip_node.py:16-63) for a short window in ONE host round trip: stage the window,
-// the 599 prediction ticks and the start values, then queue  unpack -> k_small (m.optimize() on the device, optimum left in
-// the context's theta slot) -> the fixed-theta fit + predict schedule reading that slot -> results, and synchronise once.
-int node_callback_opt_fused(cgp_ctx *c, const double *time_array, const double *slip_array, int n, int kid, double *theta,
-                            int max_evals, double *mean, double *sigma, int cap, int *m_out) {
+// the prediction ticks and theta (one H2D), then queue  unpack -> [k_small: m.optimize() on the device, optimum left in the
+// context's theta slot] -> k_small_predict (fit at that slot with GPy's jitter ladder + the predictions) -> one D2H, and
+// synchronise once.  max_evals == 0: fixed theta.  CGP_ESTATE: not a short fp64 window -- the caller's general path.
+int node_callback_small(cgp_ctx *c, const double *time_array, const double *slip_array, int n, int kid, double *theta, int max_evals,
+                        double *mean, double *sigma, int cap, int *m_out) {
   const int ntr = (int)(0.9 * (double)n);  // gp_slip_node.py:27-29
   if (ntr < 1 || !small_ok(c, ntr) || check_shape(c, 1, ntr, 1, ntr, kid) != CGP_OK) return CGP_ESTATE;
   const int nth = ntheta(kid, 1);
   for (int i = 0; i < nth; ++i)
-    if (!(theta[i] > 0.0)) return CGP_EINVAL;
+    if (!(theta[i] > 0.0)) return max_evals > 0 ? CGP_EINVAL : CGP_ESTATE;
   double xmin = time_array[0], xmax = time_array[0];   // gp_slip_node.py:45  X_ = np.arange(X.min(), X.max() + 600, 1)
   for (int i = 1; i < n; ++i) {
     xmin = std::min(xmin, time_array[i]);
@@ -1789,44 +1912,50 @@ int node_callback_opt_fused(cgp_ctx *c, const double *time_array, const double *
   }
   const long long glen = (long long)std::ceil((xmax + 600.0 - xmin) / 1.0);
   const long long mo = std::max(0LL, glen - n);         // gp_slip_node.py:59-61  means[len(X):]
-  if (m_out) *m_out = (int)mo;
   const int M = (int)std::min<long long>(mo, cap);
-  if (M == 0 || M > c->max_m) return CGP_ESTATE;
+  if (M == 0 || M > c->max_m || !small_predict_ok(c, ntr, 1, M)) return CGP_ESTATE;
+  if (m_out) *m_out = (int)mo;
   HIP_TRY(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
-  const size_t nX = ntr, nin = 2 * nX + M + CGP_MAX_THETA, in_bytes = nin * sizeof(double);
-  const size_t nout = 2 * (size_t)M + 2 + SM_OUT, out_bytes = nout * sizeof(double);   // mean, var, logML, info (as a double slot), k_small record
-  if (!grow_pinned(c->pin_in, c->pin_in_cap, in_bytes) || !grow_pinned(c->pin_out, c->pin_out_cap, out_bytes) ||
-      !grow_device(c->draw, c->draw_cap, in_bytes))
+  const size_t nout = 2 * (size_t)M + 2 * SM_OUT, out_bytes = nout * sizeof(double);   // mean, var, the two kernels' records
+  if (!grow_pinned(c->pin_in, c->pin_in_cap, (2 * (size_t)ntr + M + CGP_MAX_THETA) * sizeof(double)) ||
+      !grow_pinned(c->pin_out, c->pin_out_cap, out_bytes))
     return CGP_ENOMEM;
-  double *hin = static_cast<double *>(c->pin_in);
-  memcpy(hin, time_array, nX * sizeof(double));
-  memcpy(hin + nX, slip_array, nX * sizeof(double));
-  for (int m = 0; m < M; ++m) hin[2 * nX + m] = xmin + (double)(n + m);
-  for (int q = 0; q < CGP_MAX_THETA; ++q) hin[2 * nX + M + q] = q < nth ? theta[q] : 0.0;
-  HIP_TRY(c, hipMemcpyAsync(c->draw, hin, in_bytes, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_pack_call<double>, dim3(std::min(64, cdiv(std::max(ntr, M), 256)), 1), dim3(256), 0, s, static_cast<const double *>(c->draw),
-                     static_cast<double *>(c->dX), static_cast<double *>(c->dy), static_cast<double *>(c->dXs), c->dtheta, c->djitter, 1, ntr, 1, M);
-  int rc = small_launch(c, 1, ntr, 1, kid, SM_MODE_OPT, max_evals, s);
+  // no copy commands and no unpack launch: the kernels read the pinned block in place and write their results (10 KB) to
+  // pinned host memory, visible when the stream has drained
+  SmallRaw raw;
+  int rc = small_stage_window(c, time_array, slip_array, ntr, 1, nullptr, 0, theta, nth, raw);
   if (rc != CGP_OK) return rc;
-  rc = cgp_fit_predict_batch_device(c, 1, ntr, 1, M, kid, c->dX, c->dy, c->dXs, c->dtheta, c->djitter, 1, c->dmean, c->dvar, c->dlogml,
-                                    c->dinfo, CGP_STREAM_CTX);
-  if (rc != CGP_OK) return rc;
+  {   // the prediction ticks behind y, theta behind them
+    double *hin = static_cast<double *>(c->pin_in), *xs = hin + 2 * (size_t)ntr;
+    for (int m = 0; m < M; ++m) xs[m] = xmin + (double)(n + m);
+    for (int q = 0; q < CGP_MAX_THETA; ++q) xs[M + q] = q < nth ? theta[q] : 0.0;
+    raw.Xs = xs;
+    raw.theta = xs + M;
+  }
   double *hout = static_cast<double *>(c->pin_out);
-  int *hinfo = reinterpret_cast<int *>(hout + 2 * (size_t)M + 1);
-  HIP_TRY(c, hipMemcpyAsync(hout, c->dmean, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipMemcpyAsync(hout + M, c->dvar, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipMemcpyAsync(hout + 2 * (size_t)M, c->dlogml, sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipMemcpyAsync(hinfo, c->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipMemcpyAsync(hout + 2 * (size_t)M + 2, c->dsmall, SM_OUT * sizeof(double), hipMemcpyDeviceToHost, s));
+  double *rec = hout + 2 * (size_t)M, *opt = rec + SM_OUT;
+  if (max_evals > 0) {   // leaves the optimum in raw.theta, where the next launch reads it
+    rc = small_launch(c, 1, ntr, 1, kid, SM_MODE_OPT, max_evals, s, opt, &raw);
+    if (rc != CGP_OK) return rc;
+  }
+  rc = small_predict_launch(c, 1, ntr, 1, M, kid, 1, hout, hout + M, rec, s, &raw);
+  if (rc != CGP_OK) return rc;
   HIP_TRY(c, hipStreamSynchronize(s));
-  const double *so = hout + 2 * (size_t)M + 2;
-  if (so[SMO_INFO] != 0.0) return 1;   // the start values themselves are not positive definite even with the jitter ladder
-  for (int i = 0; i < nth; ++i) theta[i] = so[SMO_THETA + i];
-  if (*hinfo != 0) return CGP_ESTATE;  // the fit at the optimum needs GPy's jitter ladder: the caller's two-call path runs it (theta is the optimum already)
+  memcpy(c->last_small, max_evals > 0 ? opt : rec, SM_OUT * sizeof(double));
+  if (max_evals > 0) {
+    if (opt[SMO_INFO] != 0.0) {   // the start values themselves are not positive definite even with the jitter ladder
+      c->have_fit = false;
+      c->lazy_fit = false;
+      return 1;
+    }
+    for (int i = 0; i < nth; ++i) theta[i] = opt[SMO_THETA + i];
+  }
+  const int info = (int)rec[SMO_INFO];
+  small_mark_fitted(c, time_array, slip_array, ntr, 1, kid, theta, rec[SMO_JITTER], info == 0);
+  if (info != 0) return info;  // not positive definite even with GPy's jitter ladder (LinAlgError there)
   memcpy(mean, hout, (size_t)M * sizeof(double));
   for (int m = 0; m < M; ++m) sigma[m] = 2.0 * std::sqrt(hout[M + m]);   // gp_slip_node.py:61
-  c->fjitter = 0.0;
   return CGP_OK;
 }
 }  // namespace
@@ -1836,8 +1965,8 @@ extern "C" int cgp_slip_node_callback_opt(cgp_ctx *c, const double *time_array, 
                                           int *m_out) {
   if (!c || !time_array || !slip_array || !theta || n < 2) return CGP_EINVAL;
   if (max_evals > 0 && mean && sigma && cap >= 0) {
-    const int rc = node_callback_opt_fused(c, time_array, slip_array, n, kid, theta, max_evals, mean, sigma, cap, m_out);
-    if (rc != CGP_ESTATE) return rc;   // CGP_ESTATE: not a short fp64 window (or its fit needs the jitter ladder) -- the two-call path below
+    const int rc = node_callback_small(c, time_array, slip_array, n, kid, theta, max_evals, mean, sigma, cap, m_out);
+    if (rc != CGP_ESTATE) return rc;   // CGP_ESTATE: not a short fp64 window -- the two-call path below
   }
   if (max_evals > 0) {
     const int ntr = (int)(0.9 * (double)n);  // gp_slip_node.py:27-29

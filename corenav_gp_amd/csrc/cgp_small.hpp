@@ -60,8 +60,24 @@ struct SmallArgs {
   double *out;       // [windows][SM_OUT]
   int N, d, kernel_id, nth, mode, max_evals;
   double pgtol, factr;
+  // element (point r, coordinate q) of X at X[q * x_sq + r * x_sr], of Xs at Xs[q * xs_sq + r * xs_sr]: the engine's resident
+  // layout is coordinate-major ({N, 1} / {M, 1}); a lone window is read as the caller staged it, point-major ({1, d}), in place
+  int x_sq, x_sr, xs_sq, xs_sr;
+  const unsigned short *deal;   // [NB][SM_NH][SM_DEAL] helper work lists of this NB (sm_build_deal, built by the host)
+  // k_small_predict: test points [windows][d][M], outputs [windows][M], `parts` workgroups per window (each refits, each predicts a slice)
+  const double *Xs;
+  double *mean, *var;
+  int M, include_noise, parts;
+  const double *jitter;   // per window or NULL: the jitter to start from
+  int ladder;             // 1: GPy's jitchol ladder inside the launch; 0: one attempt at the given jitter, the pivot reported
+  double *logml;          // per window or NULL (beside the record)
+  int *info;
 };
 
+// extra dynamic LDS of k_small_predict: one 16-column chunk of K* (NB blocks), its test points, partial sums
+__host__ __device__ __forceinline__ constexpr size_t small_predict_lds_extra(int NB, int d) {
+  return sizeof(double) * ((size_t)NB * SM_BLK + (size_t)d * DB + (size_t)NB * DB + SM_WAVES * DB + 16);
+}
 // dynamic LDS of k_small for a window of NB block rows and d input dimensions
 __host__ __device__ __forceinline__ constexpr size_t small_lds_bytes(int NB, int d) {
   return sizeof(double) * ((size_t)NB * (NB + 1) / 2 * SM_BLK + (size_t)(d + 7) * NB * DB + SM_WAVES * GRAD_N + 64) +
@@ -103,8 +119,10 @@ struct SmClock {
 // Who does what beside the factor chain (sm_eval, phase F): for every step jb the items -- blocks (jp, j) of row jp = jb - 1
 // of W, cost jp - j + 1 products, code 0x100 | j; trailing blocks (bi, bj), bi > jb, bj >= jb, with panel jp, one product, code bi << 4 | bj --
 // are dealt to the SM_NH helper waves longest first, each to the helper with the least work so far.  Lists
-// deal[jb][helper] = {count, items...}; depends on the number of block rows only, built once per launch by thread jb.
-__device__ __forceinline__ void sm_build_deal(unsigned short *deal, int NB, int jb) {
+// deal[jb][helper] = {count, items...}; depends on the number of block rows only: the host builds the table of every NB once
+// per context (a thread building its list in the kernel indexes load[] / cnt[] dynamically, i.e. in scratch memory: 39 us of
+// a 77 us launch when it was done there) and a launch copies its 2 KB into LDS.
+__host__ __device__ inline void sm_build_deal(unsigned short *deal, int NB, int jb) {
   int load[SM_NH], cnt[SM_NH];
   for (int h = 0; h < SM_NH; ++h) load[h] = cnt[h] = 0;
   unsigned short *base = deal + jb * SM_NH * SM_DEAL;
@@ -121,6 +139,15 @@ __device__ __forceinline__ void sm_build_deal(unsigned short *deal, int NB, int 
   for (int h = 0; h < SM_NH; ++h) base[h * SM_DEAL] = (unsigned short)cnt[h];
 }
 
+// mean |x| of the first input (jitchol's mean(diag) for the Brownian factor) by one wave, straight from the window in HBM
+__device__ __forceinline__ void sm_mean_abs(double *dst, const double *x, int N, int stride, int lane) {
+  double sa = 0.0;
+  for (int i = lane; i < N; i += 64) sa += fabs(x[(size_t)i * stride]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o);
+  if (lane == 0) *dst = sa / (double)N;
+}
+
 // K_ij of two window points (no noise term) with the per-evaluation constants in registers.  BROWN: the reference's
 // RBF(1) x Brownian(1) (gp_slip_node.py:31) in GPy's form -- r^2 = -2 x x' + (x^2 + x'^2), clipped at 0, forced 0 on the
 // diagonal; sigma_b^2 min(|x|, |x'|) where the signs agree -- else SE-iso / SE-ARD over d <= DMAX length-scaled
@@ -132,6 +159,27 @@ template <bool BROWN, int DMAX> struct SmKern {
     amp_b = sc[19];
 #pragma unroll
     for (int q = 0; q < DMAX; ++q) iell[q] = sc[10 + q];
+  }
+  // k(training point gi, test point c of the staged chunk xt[q * 16 + c])
+  __device__ __forceinline__ double cross(const double *xr, const double *xt, int d, int NP, int gi, int c, const ExpC &ec) const {
+    if constexpr (BROWN) {
+      const double x = xr[gi], xp = xt[c];
+      double r2 = -2.0 * x * xp + (x * x + xp * xp);
+      r2 = r2 < 0.0 ? 0.0 : r2;
+      const bool same = (x > 0.0 && xp > 0.0) || (x < 0.0 && xp < 0.0) || (x == 0.0 && xp == 0.0);
+      const double ax = __builtin_fabs(x), ap = __builtin_fabs(xp);
+      const double kb = same ? amp_b * (ax < ap ? ax : ap) : 0.0;
+      return amp * exp_nonpos(-0.5 * r2 * (iell[0] * iell[0]), ec) * kb;
+    } else {
+      double d2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < DMAX; ++q)
+        if (q < d) {
+          const double df = (xr[q * NP + gi] - xt[q * DB + c]) * iell[q];
+          d2 += df * df;
+        }
+      return amp * exp_nonpos(-0.5 * d2, ec);
+    }
   }
   // the length-scaled squared differences alone (the gradient phase has K itself from the Gram phase, in registers)
   __device__ __forceinline__ void diffs(const double *xr, int d, int NP, int gi, int gj, double (&dq2)[DMAX]) const {
@@ -184,7 +232,7 @@ template <bool BROWN, int DMAX> struct SmKern {
 // addend already in s.sc[10..20]: sm_prepare): on return (after the final barrier) s.flag[0] = first non-positive
 // pivot (0 = positive definite), s.sc[22] = logML, s.sc[24..35] = gradient sums (k_grad's layout: [0] amplitude,
 // [1..8] length-scales, [9] noise).  Every thread of the workgroup calls it.
-template <bool BROWN, int DMAX>
+template <bool BROWN, int DMAX, bool GRAD = true>
 __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB, int tid) {
   using P = Prec<double>;
   using acc_t = P::acc_t;
@@ -193,7 +241,7 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double *Bk = s.Bk;
   ExpC ec;
-  ec.load();
+  ec.load_literals();
   SmClock ck;
   ck.start();
   SmKern<BROWN, DMAX> kern;
@@ -219,7 +267,7 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
             k0 = kern.eval(s.xr, d, NP, gi, gj, ec, dq2);
             g = gi == gj ? k0 + diag_add : k0;
           } else g = (gi == gj) ? 1.0 : 0.0;   // identity padding keeps the factor well defined
-          kv[i][r] = k0;
+          kv[i][r] = GRAD ? k0 : 0.0;
           Bk[blk * SM_BLK + l15 * SM_LD + lq + 4 * r] = g;
         }
       } else {
@@ -441,6 +489,7 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
   __syncthreads();
   ck.lap(s.sc, 6, tid);
 
+  if constexpr (!GRAD) return;   // fit + predict (k_small_predict): no gradient
   // ---- gradient sums: Ky^-1(bi,bj) = sum_{k >= bi} W(k,bi)^T W(k,bj) in registers, contracted on the spot
   double s_amp = 0.0, s_noise = 0.0, s_ell[DMAX];
 #pragma unroll
@@ -863,7 +912,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small(SmallArgs p) {
   double *thb = p.theta + (size_t)b * MAX_THETA, *ob = p.out + (size_t)b * SM_OUT;
   for (int i = tid; i < d * NP; i += SM_THREADS) {
     const int q = i / NP, r = i - q * NP;
-    s.xr[i] = r < N ? Xb[(size_t)q * N + r] : 0.0;
+    s.xr[i] = r < N ? Xb[(size_t)q * p.x_sq + (size_t)r * p.x_sr] : 0.0;
   }
   for (int i = tid; i < NP; i += SM_THREADS) s.yv[i] = i < N ? yb[i] : 0.0;
   for (int i = tid; i < nblk; i += SM_THREADS) {   // packed index -> (block row, block column)
@@ -874,12 +923,10 @@ __global__ __launch_bounds__(SM_THREADS) void k_small(SmallArgs p) {
     }
     s.tb[i] = bi | (rem << 8);
   }
-  if (tid >= 64 && tid < 64 + NB) sm_build_deal(s.deal, NB, tid - 64);
+  for (int i = tid; i < NB * SM_NH * SM_DEAL; i += SM_THREADS) s.deal[i] = p.deal[i];
+  if (tid >= 64 && tid < 128) sm_mean_abs(s.sc + 23, Xb, N, p.x_sr, tid - 64);
   __syncthreads();
   if (tid == 0) {
-    double sa = 0.0;   // mean |x| of the first input: jitchol's mean(diag) for the Brownian factor
-    for (int i = 0; i < N; ++i) sa += fabs(s.xr[i]);
-    s.sc[23] = sa / (double)N;
     s.flag[1] = 0;
     for (int i = 0; i < 16; ++i) s.sc[48 + i] = 0.0;
     if (p.mode == SM_MODE_OPT) {
@@ -947,6 +994,190 @@ __global__ __launch_bounds__(SM_THREADS) void k_small(SmallArgs p) {
       for (int i = 0; i < MAX_THETA; ++i) ob[SMO_GRAD + i] = i < nth ? lb.g[i] : 0.0;   // wrt x, at the optimum
     }
   }
+}
+
+// --------------------------------------------------------------------------------------------------
+// k_small_predict: the reference node's fixed-theta work item (gp_slip_node.py:35,45-49,57-61: GPRegression at theta, then
+// mean and variance on the 599 ticks after the window) for a short window in ONE launch.  `parts` workgroups per window:
+// each repeats the fit in its own LDS (Gram, Cholesky, W = L^-1, alpha, logML, GPy's jitter ladder: ~40 us, cheaper
+// than handing a factor from CU to CU) and predicts its slice of the test points, 16 at a time:
+//   K* chunk (NB blocks of 16 x 16) -> LDS;  mean = K*^T alpha;  V = W K* block row by block row on MFMA;
+//   var = k** - |V|^2 (clipped at 1e-15, + sigma_n^2 on request).
+// Part 0 writes the window's record (logML, info, jitter).
+// --------------------------------------------------------------------------------------------------
+template <bool BROWN, int DMAX>
+__global__ __launch_bounds__(SM_THREADS) void k_small_predict(SmallArgs p) {
+  using P = Prec<double>;
+  using acc_t = P::acc_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, b = blockIdx.x / p.parts, part = blockIdx.x % p.parts;
+  const int lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = p.N, d = p.d, kid = p.kernel_id, nth = p.nth, M = p.M;
+  const int NB = (N + DB - 1) / DB, NP = NB * DB, nblk = NB * (NB + 1) / 2;
+  SmallLds s;
+  s.Bk = reinterpret_cast<double *>(smem_raw);
+  s.xr = s.Bk + (size_t)nblk * SM_BLK;
+  s.yv = s.xr + (size_t)d * NP;
+  s.zv = s.yv + NP;
+  s.al = s.zv + NP;
+  s.ldg = s.al + NP;
+  s.tmp = s.ldg + NP;
+  s.red = s.tmp + 3 * NP;
+  s.sc = s.red + SM_WAVES * GRAD_N;
+  s.lb = reinterpret_cast<corenav::LbfgsCore *>(s.sc + 64);
+  s.flag = reinterpret_cast<int *>(reinterpret_cast<char *>(s.lb) + sizeof(corenav::LbfgsCore));
+  s.tb = s.flag + 8;
+  s.deal = reinterpret_cast<unsigned short *>(s.tb + nblk);
+  // behind k_small's layout (small_lds_bytes): the prediction scratch
+  double *Ks = reinterpret_cast<double *>(smem_raw + ((small_lds_bytes(NB, d) + 15) & ~(size_t)15));
+  double *xt = Ks + (size_t)NB * SM_BLK;     // [d][16] test points of the chunk
+  double *mpart = xt + (size_t)d * DB;       // [NB][16] partial means by block row
+  double *vpart = mpart + (size_t)NB * DB;   // [waves][16] partial |V|^2
+  const double *Xb = p.X + (size_t)b * d * N, *yb = p.y + (size_t)b * N, *Xsb = p.Xs + (size_t)b * d * M;
+  SmClock ck;   // CGP_ABLATION builds: slots 10 staging, 11 K* chunk, 12 means + V, 13 outputs (the fit laps slots 1..7 itself)
+  ck.start();
+  double *thb = p.theta + (size_t)b * MAX_THETA, *ob = p.out + (size_t)b * SM_OUT;
+  for (int i = tid; i < d * NP; i += SM_THREADS) {
+    const int q = i / NP, r = i - q * NP;
+    s.xr[i] = r < N ? Xb[(size_t)q * p.x_sq + (size_t)r * p.x_sr] : 0.0;
+  }
+  for (int i = tid; i < NP; i += SM_THREADS) s.yv[i] = i < N ? yb[i] : 0.0;
+  for (int i = tid; i < nblk; i += SM_THREADS) {
+    int bi = 0, rem = i;
+    while (rem > bi) {
+      rem -= bi + 1;
+      ++bi;
+    }
+    s.tb[i] = bi | (rem << 8);
+  }
+  for (int i = tid; i < NB * SM_NH * SM_DEAL; i += SM_THREADS) s.deal[i] = p.deal[i];
+  if (tid >= 64 && tid < 128) sm_mean_abs(s.sc + 23, Xb, N, p.x_sr, tid - 64);
+  __syncthreads();
+  if (tid < 16) s.sc[48 + tid] = 0.0;
+  __syncthreads();
+  ck.lap(s.sc, 14, tid);
+  if (tid < MAX_THETA) s.sc[tid] = tid < nth ? thb[tid] : 0.0;
+  if (tid == 0) {
+    s.sc[21] = p.jitter ? p.jitter[b] : 0.0;
+    s.flag[2] = 0;
+  }
+  __syncthreads();
+  ck.lap(s.sc, 15, tid);
+  if (tid < 64) sm_constants(s, kid, d, nth, tid);
+  ck.lap(s.sc, 9, tid);
+  __syncthreads();
+  ck.lap(s.sc, 10, tid);
+  for (;;) {   // GPy jitchol ladder (every part of a window climbs it identically)
+    sm_eval<BROWN, DMAX, false>(s, d, N, NB, tid);
+    const int bad = s.flag[0], attempt = s.flag[2];
+    if (bad == 0 || attempt >= 5 || !p.ladder) break;
+    __syncthreads();
+    if (tid == 0) {
+      const double noise = s.sc[nth - 1] + 1e-8;
+      const double md = BROWN ? s.sc[0] * s.sc[2] * s.sc[23] + noise : s.sc[0] + noise;
+      s.sc[21] = attempt == 0 ? md * 1e-6 : s.sc[21] * 10.0;
+      s.sc[20] = noise + s.sc[21];
+      s.flag[2] = attempt + 1;
+      s.flag[0] = 0;
+    }
+    __syncthreads();
+  }
+  const bool ok = s.flag[0] == 0;
+  if (part == 0 && tid == 0) {
+    ob[SMO_LOGML] = s.sc[22];
+    ob[SMO_EVALS] = 1.0;
+    ob[SMO_STATUS] = 0.0;
+    ob[SMO_ITERS] = 0.0;
+    ob[SMO_INFO] = (double)s.flag[0];
+    ob[SMO_JITTER] = ok ? s.sc[21] : 0.0;
+    if (p.logml) p.logml[b] = s.sc[22];
+    if (p.info) p.info[b] = s.flag[0];
+  }
+  if (!ok || M <= 0) return;
+  ck.start();
+  // ---- this part's slice of the test points, 16 at a time
+  ExpC ec;
+  ec.load_literals();
+  SmKern<BROWN, DMAX> kern;
+  kern.load(s.sc);
+  const double noise_add = p.include_noise ? s.sc[nth - 1] : 0.0;
+  const int nchunk = (M + DB - 1) / DB, per = (nchunk + p.parts - 1) / p.parts;
+  double *Bk = s.Bk;
+  for (int ch = part * per; ch < min(nchunk, (part + 1) * per); ++ch) {
+    const int m0 = ch * DB;
+    if (tid < d * DB) {
+      const int q = tid / DB, c = tid - q * DB;
+      xt[tid] = m0 + c < M ? Xsb[(size_t)q * p.xs_sq + (size_t)(m0 + c) * p.xs_sr] : 0.0;
+    }
+    __syncthreads();
+    {   // K* blocks: two per pass, one entry per thread; entry (training row r of block bj, test column c) at Ks[bj][c * 17 + r]
+      const int e = tid & 255, r = e & 15, c = e >> 4;
+      for (int b0 = 0; b0 < NB; b0 += 2) {
+        const int bj = b0 + (tid >> 8);
+        if (bj < NB) {
+          const int gi = bj * DB + r;
+          Ks[bj * SM_BLK + c * SM_LD + r] = (gi < N && m0 + c < M) ? kern.cross(s.xr, xt, d, NP, gi, c, ec) : 0.0;
+        }
+      }
+    }
+    __syncthreads();
+    ck.lap(s.sc, 11, tid);
+    if (tid < NB * DB) {   // partial means by block row
+      const int bj = tid >> 4, c = tid & 15;
+      const double *kb = Ks + bj * SM_BLK + c * SM_LD;
+      double a = 0.0;
+#pragma unroll
+      for (int r = 0; r < DB; ++r) a = __builtin_fma(kb[r], s.al[bj * DB + r], a);
+      mpart[bj * DB + c] = a;
+    }
+    double q2 = 0.0;   // lanes of the wave: sum over this wave's block rows of V[row][col l15]^2, rows lq + 4 r
+    for (int bi = wave; bi < NB; bi += SM_WAVES) {
+      acc_t a0 = acc_t{0, 0, 0, 0}, a1 = a0;
+      for (int bj = 0; bj <= bi; ++bj) {
+        const double *wb = Bk + sm_tri(bi, bj), *kb = Ks + bj * SM_BLK;
+        double fa[4], fb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          fa[ks] = wb[(4 * ks + lq) * SM_LD + l15];   // W(bi,bj)[m = l15][k]
+          fb[ks] = kb[l15 * SM_LD + 4 * ks + lq];     // K*(bj)[k][n = l15]
+        }
+        if (bj & 1) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) a1 = P::mfma(fa[ks], fb[ks], a1);
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) a0 = P::mfma(fa[ks], fb[ks], a0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = a0[r] + a1[r];
+        q2 = __builtin_fma(v, v, q2);
+      }
+    }
+    q2 += __shfl_xor(q2, 16);
+    q2 += __shfl_xor(q2, 32);
+    if (lane < DB) vpart[wave * DB + lane] = q2;
+    __syncthreads();
+    ck.lap(s.sc, 12, tid);
+    if (tid < DB && m0 + tid < M) {
+      double mu = 0.0, q = 0.0;
+      for (int bj = 0; bj < NB; ++bj) mu += mpart[bj * DB + tid];
+      for (int w = 0; w < SM_WAVES; ++w) q += vpart[w * DB + tid];
+      const double kss = BROWN ? s.sc[18] * s.sc[19] * fabs(xt[tid]) : s.sc[18];
+      double v = kss - q;
+      v = v < 1e-15 ? 1e-15 : v;
+      p.mean[(size_t)b * M + m0 + tid] = mu;
+      p.var[(size_t)b * M + m0 + tid] = v + noise_add;
+    }
+    __syncthreads();
+    ck.lap(s.sc, 13, tid);
+  }
+#ifdef CGP_ABLATION
+  if (part == 0 && tid == 0)
+    for (int i = 0; i < 16; ++i) ob[32 + i] = s.sc[48 + i];
+#endif
 }
 
 }  // namespace cgp

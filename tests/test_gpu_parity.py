@@ -121,6 +121,38 @@ def test_ragged_shapes_fp64(engine, N, d, M, kid):
     check_fit_predict(engine, kid, theta, X, y, Xs, engine.F64, TOL64)
 
 
+@pytest.mark.parametrize("B,N,d,M,kid,noise", [(1, 134, 1, 599, 2, True), (5, 134, 1, 599, 2, False), (40, 100, 3, 70, 0, True),
+                                               (300, 64, 6, 33, 1, True), (3, 16, 1, 17, 2, True), (2, 160, 1, 40, 2, True),
+                                               (9, 97, 8, 16, 1, False), (2, 150, 8, 20, 1, True)])
+def test_short_windows_one_launch(engine, B, N, d, M, kid, noise):
+    """Windows of at most 160 ticks (the reference's GP_Input is 134 after its 0.9 cut) through the batched ABI: fit and
+    predictions of the whole batch in ONE launch, factors in LDS (csrc/cgp_small.hpp: k_small_predict) -- lone windows cut into
+    parts, more windows than CUs, M below / at / above the 16-point chunk, the largest window that fits, and one that does not
+    (N = 150, d = 8: the tiled schedules), with and without the noise term in the variance."""
+    rng = np.random.default_rng(31 * N + B)
+    if kid == 2:
+        X = np.stack([(5 + b + np.arange(N, dtype=float))[:, None] for b in range(B)])
+        Xs = np.stack([(5 + b + N + np.arange(M, dtype=float))[:, None] for b in range(B)])
+        th = np.tile(np.array([0.5, 30.0, 0.01, 0.002]), (B, 1))
+    else:
+        X, Xs = rng.normal(size=(B, N, d)), rng.normal(size=(B, M, d))
+        th = np.stack([np.concatenate([[0.8], rng.uniform(0.6, 2.0, 1 if kid == 0 else d), [0.02]]) for _ in range(B)])
+    y = 0.1 * np.sin(np.arange(N) / 7.0)[None, :] + 0.03 * rng.normal(size=(B, N))
+    ctx = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=B)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid, include_noise=noise)
+    assert rc == 0 and not info.any()
+    for b in range(B) if B <= 40 else range(0, B, 13):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b], noise)
+        assert relmax(mean[b], omu) < TOL64 and releach(var[b], ovar) < TOL64
+        assert abs(logml[b] - f.logml) <= TOL64 * abs(f.logml)
+    # the same windows one by one give the same bits (a window's result does not depend on its slot or on the cut into parts)
+    c1 = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=1)
+    for b in (0, B - 1):
+        rc, m1, v1, l1, i1 = c1.fit_predict_batch(X[b:b + 1], y[b:b + 1], Xs[b:b + 1], th[b:b + 1], kid, include_noise=noise)
+        assert rc == 0 and np.array_equal(m1[0], mean[b]) and np.array_equal(v1[0], var[b]) and l1[0] == logml[b]
+
+
 @pytest.mark.parametrize("B,N,d,M,kid", [(7, 300, 6, 64, 1), (16, 513, 8, 257, 1), (9, 640, 2, 1, 0), (5, 385, 1, 40, 2)])
 def test_ragged_batches_throughput_schedule(engine, B, N, d, M, kid):
     """Ragged shapes through the batched ABI on the throughput schedule (batch > 4): batch sizes that are

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Where the one-launch fit + predict kernel of a short window (csrc/cgp_small.hpp: k_small_predict) spends its cycles: per-phase
+s_memtime sums of workgroup 0 / lane 0 from a -DCGP_ABLATION library (CGP_LIB=corenav_gp_amd/libcorenav_gp_ab.so), for the
+reference's own callback (149-tick GP_Input, 599 predictions, fixed theta)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import corenav_gp_amd.engine as engine
+g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "slipval_window_rbfbrownian.npz"))
+t, s, th = g["time_array"], g["slip_array"], g["theta"]
+ctx = engine.Context(max_n=256, max_m=1024, max_d=1, max_batch=1)
+for _ in range(5): ctx.slip_node_callback(t, s, th)
+ts = []
+for _ in range(50):
+    t0 = time.perf_counter(); ctx.slip_node_callback(t, s, th); ts.append(time.perf_counter() - t0)
+print(f"callback: median {1e6 * np.median(ts):.0f} us")
+r = ctx.debug_small()
+names = {0: "constants", 1: "Gram", 2: "F (factor chain | W row, trailing)", 3: "P (panel)", 5: "last row of W", 6: "z, alpha, logML",
+         14: "staging: window, work lists -> LDS", 15: "staging: theta", 9: "staging: constants (wave 0)", 10: "staging: barrier behind them", 11: "K* chunks", 12: "means, V = W K*, |V|^2", 13: "outputs"}
+tot = 0.0
+for i, nm in names.items():
+    print(f"  {nm:42s} {r[32 + i]:9.0f} ticks")
+    tot += r[32 + i]
+print(f"  {'sum':42s} {tot:9.0f} ticks (x 10 ns if s_memtime is the 100 MHz counter)")
