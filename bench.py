@@ -764,7 +764,24 @@ def node_line(engine, local):
         t0 = time.perf_counter()
         ctx.slip_node_callback_opt(t, s, np.ones(4))
         to.append(time.perf_counter() - t0)
+    # the same work item for an ensemble: 256 windows of the series (shifted starts) in one batched call, fixed theta
+    W, n = 256, int(0.9 * len(t))
+    X = np.stack([t[:n] + k for k in range(W)])[:, :, None]
+    y = np.stack([np.roll(s, k)[:n] for k in range(W)])
+    Xs = np.stack([X[k, -1, 0] + 1 + np.arange(599.0) for k in range(W)])[:, :, None]
+    thw = np.tile(th, (W, 1))
+    bctx = engine.Context(device=local, max_n=n, max_m=599, max_d=1, max_batch=W)
+    for _ in range(2):
+        rc, _, _, _, info = bctx.fit_predict_batch(X, y, Xs, thw, engine.KERNEL_RBF_BROWNIAN)
+    assert rc == 0 and not info.any()
+    tb = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        bctx.fit_predict_batch(X, y, Xs, thw, engine.KERNEL_RBF_BROWNIAN)
+        tb.append(time.perf_counter() - t0)
     return {"node_callback_us": 1e6 * float(np.median(ts)), "node_callback_opt_ms": 1e3 * float(np.median(to)),
+            "node_windows_per_s": W / float(np.median(tb)),
+            "node_windows_workload": f"{W} such windows ({n} kept ticks, 599 predictions each) in one cgp_fit_predict_batch call, host buffers (PCIe copies included)",
             "node_workload": f"one GP_Input window of the reference's slip series ({len(t)} ticks, 599 predictions, RBF x Brownian, fp64), "
                              "host buffers, per callback: fixed theta / with m.optimize() from theta = ones"}
 

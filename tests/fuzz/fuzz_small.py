@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised sweep of the one-launch short-window kernel (csrc/cgp_small.hpp; test infrastructure: uses oracle/): every
 window length 2 ... 160, d = 1 ... 8, the three kernels, through cgp_nll_grad (value, gradient, jitter of GPy's ladder
-against the oracle), cgp_predict after it (the lazy refit), and -- every few cases -- cgp_optimize against
+against the oracle), cgp_predict after it (the lazy refit), cgp_fit_predict_batch on the same window (fit and predictions in
+one launch, k_small_predict, a random number of test points, in a batch slot among others), and -- every few cases -- cgp_optimize against
 cgp_optimize_batch on the same window (both run the device L-BFGS; they must agree to rounding) and against the
 objective re-evaluated by the oracle at the returned optimum.
    python tests/fuzz/fuzz_small.py [seconds=60] [seed=0]"""
@@ -18,6 +19,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end, cases, bad, worst, nopt, njit, nedge = time.time() + budget, 0, 0, 0.0, 0, 0, 0
 ctx = engine.Context(max_n=160, max_m=160, max_d=8)
 ctxb = engine.Context(max_n=160, max_m=160, max_d=8, max_batch=3)
+ctxp = engine.Context(max_n=160, max_m=160, max_d=8, max_batch=5)
+npred = 0
 
 
 def check(name, err, bar, tag):
@@ -68,6 +71,21 @@ while time.time() < t_end:
         omu, ovar = go.predict(f, Xs)
         check("mean", float(np.max(np.abs(mean - omu)) / max(np.max(np.abs(omu)), 1e-300)), 1e-6, tag)
         check("var", float(np.max(np.abs(var - ovar) / np.abs(ovar))), 1e-6, tag)
+    if cases % 2 == 0:                                # fit + predictions in one launch, the window in a random slot of a batch
+        Mp, Bp = int(rng.integers(1, 161)), int(rng.integers(1, 6))
+        slot = int(rng.integers(0, Bp))
+        Xp = rng.normal(size=(Mp, d)) if kid != synth.KERNEL_RBF_BROWNIAN else (X[-1, 0] + 1.0 + np.arange(Mp, dtype=np.float64))[:, None]
+        noise = bool(rng.integers(0, 2))
+        XB, yB, XsB, thB = (np.stack([v] * Bp) for v in (X, y, Xp, th))
+        for b in range(Bp):
+            if b != slot: yB[b] = np.roll(y, b + 1)
+        rc, mB, vB, lB, iB = ctxp.fit_predict_batch(XB, yB, XsB, thB, kid, include_noise=noise)
+        if f.jitter == 0 and iB[slot] == 0:
+            npred += 1
+            omu, ovar = go.predict(f, Xp, noise)
+            check("one-launch mean", float(np.max(np.abs(mB[slot] - omu)) / max(np.max(np.abs(omu)), 1e-300)), 1e-6, tag + f" M={Mp} B={Bp}")
+            check("one-launch var", float(np.max(np.abs(vB[slot] - ovar) / np.abs(ovar))), 1e-6, tag + f" M={Mp} B={Bp}")
+            check("one-launch logml", abs(lB[slot] - f.logml) / max(abs(f.logml), N / 2), 1e-6, tag + f" M={Mp} B={Bp}")
     if cases % 6 == 0 and f.jitter == 0 and N >= 8:
         nopt += 1
         th0 = np.ones(len(th))
@@ -78,5 +96,5 @@ while time.time() < t_end:
         onl = go.nll_and_grad(kid, t1, X, y)[0]
         check("logml at optimum", abs(-l1 - onl) / max(abs(onl), N / 2), 1e-6, tag)
         check("descent", max(0.0, (-l1) - go.nll_and_grad(kid, th0, X, y)[0]) / max(abs(onl), 1.0), 1e-9, tag)
-print(f"cases {cases} failures {bad} worst error / bar {worst:.3g} (optimised {nopt}, jitter ladder {njit}, pivot-sign edge cases skipped {nedge})")
+print(f"cases {cases} failures {bad} worst error / bar {worst:.3g} (optimised {nopt}, one-launch fit + predict {npred}, jitter ladder {njit}, pivot-sign edge cases skipped {nedge})")
 sys.exit(1 if bad else 0)
