@@ -303,6 +303,11 @@ def run_rank(args):
                 out["config"]["extra"] = extras(engine, torch, dev, local, W)
             if not args.no_cpu and world == 1:   # rank 0 at N = 1 only: other ranks would wait on the host work
                 out["cpu_baseline"] = cpu_baseline(kid, X, y, Xs, th, args.cpu_sample, W.dmean, W.dvar, W.dlogml, f_fit)
+                if not args.no_extra and not strong:
+                    try:
+                        out["config"]["extra"]["node_cpu_baseline"] = node_cpu_leg(engine, local)
+                    except Exception as e:
+                        out["config"]["extra"]["node_cpu_error"] = repr(e)
             if world == 1 and not args.no_extra and not strong:
                 ex3 = extras_cfg3(engine, torch, dev, local, W)
                 leg = ex3.pop("_cpu_leg", None)
@@ -784,6 +789,46 @@ def node_line(engine, local):
             "node_windows_workload": f"{W} such windows ({n} kept ticks, 599 predictions each) in one cgp_fit_predict_batch call, host buffers (PCIe copies included)",
             "node_workload": f"one GP_Input window of the reference's slip series ({len(t)} ticks, 599 predictions, RBF x Brownian, fp64), "
                              "host buffers, per callback: fixed theta / with m.optimize() from theta = ones"}
+
+
+def node_cpu_leg(engine, local):
+    """The reference node's own work item on the host (test infrastructure: oracle/gp_oracle.py, numpy + scipy LAPACK and
+    scipy's L-BFGS-B held to ONE thread), beside the engine's callback on the same window; the oracle's outputs check the
+    engine's.  gp_slip_node.py:16-63."""
+    import numpy as np
+    from oracle import gp_oracle as go
+    g = np.load(os.path.join(ROOT, "tests", "golden", "slipval_window_rbfbrownian.npz"))
+    t, s, th = g["time_array"], g["slip_array"], g["theta"]
+    ctx = engine.Context(device=local, max_n=256, max_m=1024, max_d=1, max_batch=1)
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=1)
+    except Exception:
+        limit = None
+    try:
+        go.slip_node_callback(t, s, th)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            omean, osigma = go.slip_node_callback(t, s, th)
+        fixed = (time.perf_counter() - t0) / 5
+        _, _, Xtr, Ytr = go.slip_node_split(t, s)
+        ytr = Ytr[:, 0]
+        t0 = time.perf_counter()
+        tho, ologml, nev = go.optimize(go.KERNEL_RBF_BROWNIAN, Xtr, ytr)
+        om2, os2 = go.slip_node_callback(t, s, tho)
+        opt = time.perf_counter() - t0
+    finally:
+        if limit is not None:
+            limit.restore_original_limits()
+    mean, sigma = ctx.slip_node_callback(t, s, th)
+    m2, s2, th2 = ctx.slip_node_callback_opt(t, s, np.ones(4))
+    rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - b)) / max(np.max(np.abs(b)), 1e-300))
+    # the two optimisers stop at their own resolution: compare the objective reached, and the fixed-theta outputs exactly
+    f_gpu = go.nll_and_grad(go.KERNEL_RBF_BROWNIAN, th2, Xtr, ytr)[0]
+    return {"fixed_theta_ms": fixed * 1e3, "with_optimize_ms": opt * 1e3, "optimizer_evaluations": int(nev), "cores": 1, "kind": "port",
+            "sample": "one GP_Input window of the reference's slip series (149 ticks, 599 predictions, RBF x Brownian), oracle/gp_oracle.py on one host thread",
+            "gpu_vs_oracle_max_rel_err_fixed_theta": max(rel(mean, omean), rel(sigma, osigma)),
+            "nll_at_gpu_optimum_minus_nll_at_oracle_optimum": float(f_gpu - (-ologml))}
 
 
 def host_description():

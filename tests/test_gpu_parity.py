@@ -123,7 +123,8 @@ def test_ragged_shapes_fp64(engine, N, d, M, kid):
 
 @pytest.mark.parametrize("B,N,d,M,kid,noise", [(1, 134, 1, 599, 2, True), (5, 134, 1, 599, 2, False), (40, 100, 3, 70, 0, True),
                                                (300, 64, 6, 33, 1, True), (3, 16, 1, 17, 2, True), (2, 160, 1, 40, 2, True),
-                                               (9, 97, 8, 16, 1, False), (2, 150, 8, 20, 1, True)])
+                                               (9, 97, 8, 16, 1, False), (2, 150, 8, 20, 1, True), (2, 1, 1, 1, 0, True),
+                                               (3, 2, 1, 3, 2, True)])
 def test_short_windows_one_launch(engine, B, N, d, M, kid, noise):
     """Windows of at most 160 ticks (the reference's GP_Input is 134 after its 0.9 cut) through the batched ABI: fit and
     predictions of the whole batch in ONE launch, factors in LDS (csrc/cgp_small.hpp: k_small_predict) -- lone windows cut into
