@@ -104,6 +104,7 @@ struct cgp_ctx {
   unsigned short *dsmdeal = nullptr;   // k_small's helper work lists (sm_build_deal) of every NB <= SM_MAX_NB, at smdeal_off[NB]
   size_t smdeal_off[SM_MAX_NB + 1] = {0};
   std::vector<double> lazy_win;   // [X (N, d) | y] of the window a short-window kernel evaluated in place (ensure_fitted uploads it)
+  bool last_small_dev = false;       // ... or window 0's record of the last batched fit + predict launch, still in dsmall
   double last_small[SM_OUT] = {0};   // the last single-window short-window record (the kernels write it to pinned host memory)
   size_t lw_stride = 0, winv_stride = 0, alpha_stride = 0;
   // state of the last single fit (cgp_fit -> cgp_predict)
@@ -1077,7 +1078,10 @@ int cgp_debug_small(cgp_ctx *c, double out[CGP_SMALL_OUT]) {
   if (!c || !out) return CGP_EINVAL;
   if (!c->dsmall) return CGP_ESTATE;
   HIP_TRY(c, hipSetDevice(c->device));
-  memcpy(out, c->last_small, SM_OUT * sizeof(double));
+  if (c->last_small_dev) {
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(out, c->dsmall, SM_OUT * sizeof(double), hipMemcpyDeviceToHost));
+  } else memcpy(out, c->last_small, SM_OUT * sizeof(double));
   return CGP_OK;
 }
 
@@ -1716,6 +1720,7 @@ int small_predict_launch(cgp_ctx *c, int batch, int N, int d, int M, int kid, in
   // launch to ONE round of workgroups -- a lone window: a chunk of 16 test points each; >= n_cu windows: one workgroup each
   a.parts = std::max(1, std::min(nchunk, std::max(c->n_cu, 1) / batch));
   const size_t lds = small_predict_lds(cdiv(N, DB), d);
+  c->last_small_dev = dout == c->dsmall;
   const dim3 grid(batch * a.parts), block(SM_THREADS);
   if (kid == CGP_KERNEL_RBF_BROWNIAN) hipLaunchKernelGGL((k_small_predict<true, 1>), grid, block, lds, s, a);
   else if (d <= 1) hipLaunchKernelGGL((k_small_predict<false, 1>), grid, block, lds, s, a);
@@ -1734,6 +1739,7 @@ int small_read_one(cgp_ctx *c, const double *slot, double out[SM_OUT], hipStream
   HIP_TRY(c, hipStreamSynchronize(s));
   memcpy(out, slot, SM_OUT * sizeof(double));
   memcpy(c->last_small, slot, SM_OUT * sizeof(double));
+  c->last_small_dev = false;
   return CGP_OK;
 }
 
