@@ -1055,17 +1055,13 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_predict(SmallArgs p) {
   if (tid >= 64 && tid < 128) sm_mean_abs(s.sc + 23, Xb, N, p.x_sr, tid - 64);
   __syncthreads();
   if (tid < 16) s.sc[48 + tid] = 0.0;
-  __syncthreads();
-  ck.lap(s.sc, 14, tid);
   if (tid < MAX_THETA) s.sc[tid] = tid < nth ? thb[tid] : 0.0;
   if (tid == 0) {
     s.sc[21] = p.jitter ? p.jitter[b] : 0.0;
     s.flag[2] = 0;
   }
   __syncthreads();
-  ck.lap(s.sc, 15, tid);
   if (tid < 64) sm_constants(s, kid, d, nth, tid);
-  ck.lap(s.sc, 9, tid);
   __syncthreads();
   ck.lap(s.sc, 10, tid);
   for (;;) {   // GPy jitchol ladder (every part of a window climbs it identically)

@@ -23,7 +23,7 @@ if batch:
     for _ in range(3): ctx.fit_predict_batch(X, y, Xs, np.tile(th, (W, 1)), engine.KERNEL_RBF_BROWNIAN)
 r = ctx.debug_small()   # batch: window 0's record of the batched launch
 names = {0: "constants", 1: "Gram", 2: "F (factor chain | W row, trailing)", 3: "P (panel)", 5: "last row of W", 6: "z, alpha, logML",
-         14: "staging: window, work lists -> LDS", 15: "staging: theta", 9: "staging: constants (wave 0)", 10: "staging: barrier behind them", 11: "K* chunks", 12: "means, V = W K*, |V|^2", 13: "outputs"}
+         10: "staging (window, work lists, theta, constants)", 11: "K* chunks", 12: "means, V = W K*, |V|^2", 13: "outputs"}
 tot = 0.0
 for i, nm in names.items():
     print(f"  {nm:42s} {r[32 + i]:9.0f} ticks")
