@@ -145,7 +145,7 @@ int cgp_slip_node_callback(cgp_ctx *ctx, const double *time_array, const double 
  * X (batch, N, d), y (batch, N), Xs (batch, M, d), theta (batch, theta_stride) row-major; outputs
  * mean/var (batch, M), logml (batch), info (batch; per-fit status as the return-value convention).
  * Returns 0 if every fit succeeded, else the first non-zero per-fit status.
- * Short fp64 windows (N <= 144 for any d, N <= 160 at d = 1; M > 0) run as ONE launch with the factor in LDS
+ * Short fp64 windows (N <= 144 for any d, N <= 160 at d <= 2; M > 0) run as ONE launch with the factor in LDS
  * (csrc/cgp_small.hpp: k_small_predict), the same form the node callbacks take; longer ones on the tiled schedules.  Which
  * form runs depends on (N, d, M) only, never on `batch` or the slot; cgp_fit + cgp_predict of the same window (always the
  * tiled schedules: the factor stays resident for cgp_get_factor) agree with it to rounding, not bitwise. */
