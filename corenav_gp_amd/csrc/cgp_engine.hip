@@ -1719,6 +1719,7 @@ int small_predict_launch(cgp_ctx *c, int batch, int N, int d, int M, int kid, in
   // every workgroup repeats its window's fit (one workgroup per CU: the factor fills the LDS), so: as many parts as keep the
   // launch to ONE round of workgroups -- a lone window: a chunk of 16 test points each; >= n_cu windows: one workgroup each
   a.parts = std::max(1, std::min(nchunk, std::max(c->n_cu, 1) / batch));
+  a.parts = cdiv(nchunk, cdiv(nchunk, a.parts));   // no part without a chunk (8 windows x 38 chunks: 19 parts of two, not 32)
   const size_t lds = small_predict_lds(cdiv(N, DB), d);
   c->last_small_dev = dout == c->dsmall;
   const dim3 grid(batch * a.parts), block(SM_THREADS);
