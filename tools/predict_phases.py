@@ -21,6 +21,10 @@ if batch:
     y = np.stack([np.roll(s, k)[:n] for k in range(W)])
     Xs = np.stack([X[k, -1, 0] + 1 + np.arange(599.0) for k in range(W)])[:, :, None]
     for _ in range(3): ctx.fit_predict_batch(X, y, Xs, np.tile(th, (W, 1)), engine.KERNEL_RBF_BROWNIAN)
+    tb = []
+    for _ in range(10):
+        t0 = time.perf_counter(); ctx.fit_predict_batch(X, y, Xs, np.tile(th, (W, 1)), engine.KERNEL_RBF_BROWNIAN); tb.append(time.perf_counter() - t0)
+    print(f"{W} windows in one call, host buffers: median {1e3 * np.median(tb):.3f} ms")
 r = ctx.debug_small()   # batch: window 0's record of the batched launch
 names = {0: "constants", 1: "Gram", 2: "F (factor chain | W row, trailing)", 3: "P (panel)", 5: "last row of W", 6: "z, alpha, logML",
          10: "staging (window, work lists, theta, constants)", 11: "K* chunks", 12: "means, V = W K*, |V|^2", 13: "outputs"}
