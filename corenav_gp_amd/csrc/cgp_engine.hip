@@ -991,8 +991,9 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
       std::vector<unsigned short> tab;
       for (int NB = 1; NB <= SM_MAX_NB; ++NB) {
         c->smdeal_off[NB] = tab.size();
-        tab.resize(tab.size() + (size_t)NB * SM_NH * SM_DEAL, 0);
+        tab.resize(tab.size() + small_table_elems(NB), 0);
         for (int jb = 0; jb < NB; ++jb) sm_build_deal(tab.data() + c->smdeal_off[NB], NB, jb);
+        sm_build_rowmap(tab.data() + c->smdeal_off[NB] + (size_t)NB * SM_NH * SM_DEAL, NB);
       }
       ok = ok && hipMalloc((void **)&c->dsmdeal, tab.size() * sizeof(unsigned short)) == hipSuccess;
       ok = ok && hipMemcpy(c->dsmdeal, tab.data(), tab.size() * sizeof(unsigned short), hipMemcpyHostToDevice) == hipSuccess;

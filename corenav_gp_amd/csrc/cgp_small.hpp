@@ -74,6 +74,24 @@ struct SmallArgs {
   int *info;
 };
 
+// Block rows of k_small_predict's V = W K* phase -> waves: row bi costs bi + 1 products.  The two waves of a SIMD (w and w + 4) share
+// one fp64 MFMA pipe (one MFMA per 64 cycles, the older wave first: tools/mfma_dep_latency.hip), so rows are dealt longest first to
+// the SIMD with the least work and, inside it, to its wave with the least (round-robin rows {w, w + 8} left SIMD 0 with 15 of the
+// 45 products of nine block rows and its wave 0 with 10 in a row).  One 16-bit row mask per wave, behind the work lists.
+__host__ __device__ inline void sm_build_rowmap(unsigned short *map, int NB) {
+  int load[SM_WAVES];
+  for (int w = 0; w < SM_WAVES; ++w) load[w] = 0, map[w] = 0;
+  for (int bi = NB - 1; bi >= 0; --bi) {
+    int sd = 0;
+    for (int q = 1; q < 4; ++q) sd = load[q] + load[q + 4] < load[sd] + load[sd + 4] ? q : sd;
+    const int w = load[sd + 4] < load[sd] ? sd + 4 : sd;
+    load[w] += bi + 1;
+    map[w] = (unsigned short)(map[w] | (1u << bi));
+  }
+}
+// per-NB table the host builds once per context: [NB][SM_NH][SM_DEAL] work lists, then SM_WAVES row masks
+__host__ __device__ __forceinline__ constexpr size_t small_table_elems(int NB) { return (size_t)NB * SM_NH * SM_DEAL + SM_WAVES; }
+
 // extra dynamic LDS of k_small_predict: one 16-column chunk of K* (NB blocks), its test points, partial sums
 __host__ __device__ __forceinline__ constexpr size_t small_predict_lds_extra(int NB, int d) {
   return sizeof(double) * ((size_t)NB * SM_BLK + (size_t)d * DB + (size_t)NB * DB + SM_WAVES * DB + 16);
@@ -1052,6 +1070,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_predict(SmallArgs p) {
     s.tb[i] = bi | (rem << 8);
   }
   for (int i = tid; i < NB * SM_NH * SM_DEAL; i += SM_THREADS) s.deal[i] = p.deal[i];
+  const unsigned rowmask = __builtin_amdgcn_readfirstlane((unsigned)p.deal[NB * SM_NH * SM_DEAL + wave]);   // sm_build_rowmap
   if (tid >= 64 && tid < 128) sm_mean_abs(s.sc + 23, Xb, N, p.x_sr, tid - 64);
   __syncthreads();
   if (tid < 16) s.sc[48 + tid] = 0.0;
@@ -1128,7 +1147,9 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_predict(SmallArgs p) {
       mpart[bj * DB + c] = a;
     }
     double q2 = 0.0;   // lanes of the wave: sum over this wave's block rows of V[row][col l15]^2, rows lq + 4 r
-    for (int bi = wave; bi < NB; bi += SM_WAVES) {
+    for (unsigned rows = rowmask; rows;) {
+      const int bi = 31 - __builtin_clz(rows);
+      rows &= ~(1u << bi);
       acc_t a0 = acc_t{0, 0, 0, 0}, a1 = a0;
       for (int bj = 0; bj <= bi; ++bj) {
         const double *wb = Bk + sm_tri(bi, bj), *kb = Ks + bj * SM_BLK;
