@@ -1023,6 +1023,23 @@ __global__ __launch_bounds__(SM_THREADS) void k_small(SmallArgs p) {
 //   var = k** - |V|^2 (clipped at 1e-15, + sigma_n^2 on request).
 // Part 0 writes the window's record (logML, info, jitter).
 // --------------------------------------------------------------------------------------------------
+// Operands of one 16 x 16 x 16 fp64 product of k_small_predict's V phase: the A side (a block of W, element [m = l15][k = 4 ks + lq],
+// column stride 17) and the B side (a block of K*, element [k][n = l15]).  The V loop requests the NEXT product's operands
+// unconditionally before multiplying the current one, in two identical halves, behind a sched_barrier and with carried
+// addresses: conditional request blocks make the compiler's wait-count pass wait for ALL outstanding LDS loads before the first
+// MFMA of every product, plain requests are sunk behind the MFMAs by the scheduler, and addresses recomputed per product land
+// in the other operand set's destination registers (a full wait again).
+struct SmOperands {
+  double a[4], b[4];
+};
+__device__ __forceinline__ void sm_req(SmOperands &o, const double *w, const double *k) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    o.a[ks] = w[4 * ks * SM_LD];
+    o.b[ks] = k[4 * ks];
+  }
+}
+
 template <bool BROWN, int DMAX>
 __global__ __launch_bounds__(SM_THREADS) void k_small_predict(SmallArgs p) {
   using P = Prec<double>;
@@ -1138,8 +1155,8 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_predict(SmallArgs p) {
     }
     __syncthreads();
     ck.lap(s.sc, 11, tid);
-    if (tid < NB * DB) {   // partial means by block row
-      const int bj = tid >> 4, c = tid & 15;
+    if (tid >= 256 && tid < 256 + NB * DB) {   // partial means by block row, on the waves with the short V rows (sm_build_rowmap)
+      const int bj = (tid - 256) >> 4, c = tid & 15;
       const double *kb = Ks + bj * SM_BLK + c * SM_LD;
       double a = 0.0;
 #pragma unroll
@@ -1151,21 +1168,28 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_predict(SmallArgs p) {
       const int bi = 31 - __builtin_clz(rows);
       rows &= ~(1u << bi);
       acc_t a0 = acc_t{0, 0, 0, 0}, a1 = a0;
-      for (int bj = 0; bj <= bi; ++bj) {
-        const double *wb = Bk + sm_tri(bi, bj), *kb = Ks + bj * SM_BLK;
-        double fa[4], fb[4];
+      // the next product's operands are requested (always: a repeat of the last one's when there is none) before this one's
+      // MFMAs, in two identical halves with the addresses carried along -- see SmOperands
+      const double *wp = Bk + sm_tri(bi, 0) + lq * SM_LD + l15, *kp = Ks + l15 * SM_LD + lq;
+      SmOperands o0, o1;
+      sm_req(o0, wp, kp);
+      for (int bj = 0;; bj += 2) {
+        const int s1 = bj + 1 <= bi ? SM_BLK : 0;
+        wp += s1;
+        kp += s1;
+        sm_req(o1, wp, kp);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          fa[ks] = wb[(4 * ks + lq) * SM_LD + l15];   // W(bi,bj)[m = l15][k]
-          fb[ks] = kb[l15 * SM_LD + 4 * ks + lq];     // K*(bj)[k][n = l15]
-        }
-        if (bj & 1) {
+        for (int ks = 0; ks < 4; ++ks) a0 = P::mfma(o0.a[ks], o0.b[ks], a0);
+        if (bj + 1 > bi) break;
+        const int s2 = bj + 2 <= bi ? SM_BLK : 0;
+        wp += s2;
+        kp += s2;
+        sm_req(o0, wp, kp);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) a1 = P::mfma(fa[ks], fb[ks], a1);
-        } else {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) a0 = P::mfma(fa[ks], fb[ks], a0);
-        }
+        for (int ks = 0; ks < 4; ++ks) a1 = P::mfma(o1.a[ks], o1.b[ks], a1);
+        if (bj + 2 > bi) break;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
