@@ -157,12 +157,43 @@ __host__ __device__ inline void sm_build_deal(unsigned short *deal, int NB, int 
   for (int h = 0; h < SM_NH; ++h) base[h * SM_DEAL] = (unsigned short)cnt[h];
 }
 
+// Cross-lane sums on the VALU's DPP path instead of ds_bpermute (what __shfl_xor compiles to: an LDS round trip per step, ~100
+// cycles each when the steps depend on each other -- 72 of them closed every evaluation's gradient phase, ~50 every L-BFGS
+// step).  A double moves as two 32-bit halves.  sm_row_sum: every lane gets the total of its row of 16 (rotations by 8, 4, 2,
+// 1: the same tree in every lane up to the order of each addition's two operands, so all lanes hold identical bits);
+// sm_wave_sum: the four row totals added in fixed order through scalar registers, every lane gets the wave's total.
+template <int CTRL> __device__ __forceinline__ double sm_dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sm_row_sum(double v) {
+  v += sm_dpp_mov<0x128>(v);   // row_ror:8
+  v += sm_dpp_mov<0x124>(v);   // row_ror:4
+  v += sm_dpp_mov<0x122>(v);   // row_ror:2
+  v += sm_dpp_mov<0x121>(v);   // row_ror:1
+  return v;
+}
+__device__ __forceinline__ double sm_row_max(double v) {
+  v = __builtin_fmax(v, sm_dpp_mov<0x128>(v));
+  v = __builtin_fmax(v, sm_dpp_mov<0x124>(v));
+  v = __builtin_fmax(v, sm_dpp_mov<0x122>(v));
+  v = __builtin_fmax(v, sm_dpp_mov<0x121>(v));
+  return v;
+}
+__device__ __forceinline__ double sm_lane_value(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double sm_wave_sum(double v) {
+  v = sm_row_sum(v);
+  return ((sm_lane_value(v, 0) + sm_lane_value(v, 16)) + sm_lane_value(v, 32)) + sm_lane_value(v, 48);
+}
+
 // mean |x| of the first input (jitchol's mean(diag) for the Brownian factor) by one wave, straight from the window in HBM
 __device__ __forceinline__ void sm_mean_abs(double *dst, const double *x, int N, int stride, int lane) {
   double sa = 0.0;
   for (int i = lane; i < N; i += 64) sa += fabs(x[(size_t)i * stride]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o);
+  sa = sm_wave_sum(sa);
   if (lane == 0) *dst = sa / (double)N;
 }
 
@@ -495,8 +526,7 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
     const double z = s.zv[tid];
     lsum = -0.5 * z * z - (tid < N ? log(s.ldg[tid]) : 0.0);
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+  lsum = sm_wave_sum(lsum);
   if (lane == 0) s.red[wave * GRAD_N] = lsum;
   __syncthreads();
   if (tid == 0) {
@@ -577,9 +607,8 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
     vals[10] = vals[11] = 0.0;
 #pragma unroll
     for (int i = 0; i < GRAD_N; ++i) {
-      double v = vals[i];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      const bool used = i == 0 || i == 9 || (i >= 1 && i <= DMAX);   // the other slots are zeros by construction
+      const double v = used ? sm_wave_sum(vals[i]) : 0.0;
       if (lane == 0) s.red[wave * GRAD_N + i] = v;
     }
   }
@@ -646,19 +675,11 @@ __device__ __forceinline__ void sm_constants(const SmallLds &s, int kid, int d, 
 // agree with the host stepper to rounding, not bitwise.
 __device__ __forceinline__ double lb_dot(double a, double b, bool on) {
   double p = on ? a * b : 0.0;
-  p += __shfl_xor(p, 8);
-  p += __shfl_xor(p, 4);
-  p += __shfl_xor(p, 2);
-  p += __shfl_xor(p, 1);
-  return p;
+  return sm_row_sum(p);
 }
 __device__ __forceinline__ double lb_amax(double a, bool on) {
   double p = on ? __builtin_fabs(a) : 0.0;
-  p = __builtin_fmax(p, __shfl_xor(p, 8));
-  p = __builtin_fmax(p, __shfl_xor(p, 4));
-  p = __builtin_fmax(p, __shfl_xor(p, 2));
-  p = __builtin_fmax(p, __shfl_xor(p, 1));
-  return p;
+  return sm_row_max(p);
 }
 
 __device__ __attribute__((noinline)) void sm_lbfgs_tell_wave(corenav::LbfgsCore &c, double fv, double gv, int lane) {
