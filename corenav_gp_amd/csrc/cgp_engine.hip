@@ -2395,6 +2395,7 @@ extern "C" int cgp_optimize_batch(cgp_ctx *c, int batch, int N, int d, int kid, 
     std::vector<double> hth;
     rc = upload_theta(c, theta, theta_stride, nth, batch, s, hth);
     if (rc == CGP_OK) rc = small_launch(c, batch, N, d, kid, SM_MODE_OPT, max_evals, s);
+    c->last_small_dev = true;
     if (rc != CGP_OK) return rc;
     std::vector<double> out((size_t)batch * SM_OUT);
     HIP_TRY(c, hipMemcpyAsync(out.data(), c->dsmall, out.size() * sizeof(double), hipMemcpyDeviceToHost, s));
