@@ -628,6 +628,22 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
 // Logexp (GPy paramz.transformations.Logexp): theta = log(1 + exp(x))
 __device__ __forceinline__ double sm_to_theta(double x) { return x > 35.0 ? x : log1p(exp(x)); }
 __device__ __forceinline__ double sm_to_x(double th) { return th > 35.0 ? th : log(expm1(th)); }
+// The trial point's Logexp pair with ONE exponential and one logarithm: theta = softplus(x) = max(x, 0) + log1p(e), e = exp(-|x|),
+// and dtheta/dx = 1 - exp(-theta) = sigmoid(x) = (x >= 0 ? 1 : e) / (1 + e).  log1p(e) as log(w) e / (w - 1), w = 1 + e (exact
+// to rounding where 1 + e rounds; w == 1: e itself).  The library's log1p(exp(x)) and expm1(-theta) were 5.4 k cycles of
+// every evaluation on the wave that also runs the L-BFGS step.
+__device__ __forceinline__ double sm_softplus(double x, double &slope) {
+  if (x > 35.0) {
+    slope = 1.0;
+    return x;
+  }
+  ExpC ec;
+  ec.load_literals();
+  const double e = exp_nonpos(-__builtin_fabs(x), ec), w = 1.0 + e;
+  const double l = w == 1.0 ? e : log(w) * (e / (w - 1.0));
+  slope = (x >= 0.0 ? 1.0 : e) / w;
+  return __builtin_fmax(x, 0.0) + l;
+}
 
 // Before an evaluation, one lane per parameter (the transcendental functions of the Logexp transform are a few hundred
 // instructions each: in parallel they cost one of them, on lane 0 they cost nth of them): theta from the trial point
@@ -638,8 +654,7 @@ __device__ __forceinline__ void sm_trial_point(const SmallLds &s, const SmallArg
     if (tid < nth) {
       if (p.mode == SM_MODE_OPT) {
         const double x = s.lb->xn[tid];
-        th = fmax(sm_to_theta(x), 1e-300);
-        dth = x > 35.0 ? 1.0 : -expm1(-th);
+        th = fmax(sm_softplus(x, dth), 1e-300);
       } else {
         th = thb[tid];
         dth = 1.0;
