@@ -136,7 +136,7 @@ struct SmallDev {   // a batch resident in the caller's device buffers (cgp_fit_
   int *info;
 };
 int small_predict_launch(cgp_ctx *c, int batch, int N, int d, int M, int kid, int include_noise, double *dmean, double *dvar, double *dout,
-                         hipStream_t s, const SmallRaw *raw = nullptr, const SmallDev *dev = nullptr);
+                         hipStream_t s, const SmallRaw *raw = nullptr, const SmallDev *dev = nullptr, int tab_n = 0);
 int node_callback_small(cgp_ctx *c, const double *time_array, const double *slip_array, int n, int kid, double *theta, int max_evals,
                         double *mean, double *sigma, int cap, int *m_out);
 bool grow_pinned(void *&p, size_t &cap, size_t bytes);
@@ -291,6 +291,7 @@ template <typename T> int set_lds_attrs(int device) {
   return 0;
 }
 
+constexpr size_t kLdsPerWorkgroup = 160 * 1024;   // gfx950
 // k_small<BROWN, DMAX>: the reference's kernel, and SE kernels compiled for d <= 1 / 3 / 8 (the smallest that fits is launched)
 template <typename F> int for_each_small_kernel(F &&f) {
   int rc = f(reinterpret_cast<const void *>(&k_small<true, 1>));
@@ -300,12 +301,11 @@ template <typename F> int for_each_small_kernel(F &&f) {
   return rc;
 }
 inline size_t small_predict_lds(int NB, int d) { return ((small_lds_bytes(NB, d) + 15) & ~(size_t)15) + small_predict_lds_extra(NB, d); }
-constexpr size_t kLdsPerWorkgroup = 160 * 1024;   // gfx950
 int set_small_attr(int device) {
   static bool done[64] = {false};
   if (device >= 0 && device < 64 && done[device]) return 0;
   const int rc = for_each_small_kernel([](const void *fn) {
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(SM_MAX_NB, MAXD)) == hipSuccess ? 0 : -1;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerWorkgroup) == hipSuccess ? 0 : -1;
   });
   if (rc != 0) return -1;
   const void *pk[] = {reinterpret_cast<const void *>(&k_small_predict<true, 1>), reinterpret_cast<const void *>(&k_small_predict<false, 1>),
@@ -1622,6 +1622,28 @@ bool small_enabled() {   // CGP_SMALL=off: the large-window machinery for every 
 }
 inline bool small_ok(const cgp_ctx *c, int N) { return c->dtype == CGP_F64 && N <= SM_MAX_N && c->dsmall && small_enabled(); }
 
+// Tick-grid table of the short-window kernels (SmallArgs::tab_n): entries needed when every input is integer-valued and small
+// enough for r^2 to be exact, 0 otherwise.  ad hoc off-switch for A/B and the bitwise test: CGP_TICKTAB=off.
+int tick_table_entries(int kid, int d, const double *X, int N, const double *Xs, int M) {
+  static const bool off = [] {
+    const char *e = getenv("CGP_TICKTAB");
+    return e && std::string(e) == "off";
+  }();
+  if (off || kid != CGP_KERNEL_RBF_BROWNIAN || d != 1) return 0;
+  double lo = X[0], hi = X[0];
+  auto scan = [&](const double *v, int n) {
+    for (int i = 0; i < n; ++i) {
+      if (!(std::fabs(v[i]) <= 67108864.0) || v[i] != std::nearbyint(v[i])) return false;
+      lo = std::min(lo, v[i]);
+      hi = std::max(hi, v[i]);
+    }
+    return true;
+  };
+  if (!scan(X, N) || (Xs && !scan(Xs, M))) return 0;
+  const double spread = hi - lo;
+  return spread < (double)SM_TAB_MAX ? (int)spread + 1 : 0;
+}
+
 double mean_abs_first(const double *X, int N, int d) {
   double s = 0;
   for (int i = 0; i < N; ++i) s += std::fabs(X[(size_t)i * d]);
@@ -1653,8 +1675,9 @@ int small_stage_window(cgp_ctx *c, const double *X, const double *y, int N, int 
 }
 
 int small_launch(cgp_ctx *c, int batch, int N, int d, int kid, int mode, int max_evals, hipStream_t s, double *out = nullptr,
-                 const SmallRaw *raw = nullptr) {
+                 const SmallRaw *raw = nullptr, int tab_n = 0) {
   SmallArgs a{};
+  a.tab_n = tab_n;
   a.X = raw ? raw->X : static_cast<const double *>(c->dX);
   a.y = raw ? raw->y : static_cast<const double *>(c->dy);
   a.theta = raw ? raw->theta : c->dtheta;
@@ -1670,7 +1693,7 @@ int small_launch(cgp_ctx *c, int batch, int N, int d, int kid, int mode, int max
   a.max_evals = max_evals > 0 ? max_evals : 1000;
   a.pgtol = 1e-5;   // scipy fmin_l_bfgs_b as paramz calls it: pgtol 1e-5, factr 1e7
   a.factr = 1e7;
-  const size_t lds = small_lds_bytes(cdiv(N, DB), d);
+  const size_t lds = ((small_lds_bytes(cdiv(N, DB), d) + 15) & ~(size_t)15) + (size_t)tab_n * sizeof(double);
   if (kid == CGP_KERNEL_RBF_BROWNIAN) hipLaunchKernelGGL((k_small<true, 1>), dim3(batch), dim3(SM_THREADS), lds, s, a);
   else if (d <= 1) hipLaunchKernelGGL((k_small<false, 1>), dim3(batch), dim3(SM_THREADS), lds, s, a);
   else if (d <= 3) hipLaunchKernelGGL((k_small<false, 3>), dim3(batch), dim3(SM_THREADS), lds, s, a);
@@ -1691,7 +1714,7 @@ bool small_batch_predict_ok(const cgp_ctx *c, int batch, int N, int d, int M) {
   return !off && batch <= c->max_batch && small_predict_ok(c, N, d, M);
 }
 int small_predict_launch(cgp_ctx *c, int batch, int N, int d, int M, int kid, int include_noise, double *dmean, double *dvar, double *dout,
-                         hipStream_t s, const SmallRaw *raw, const SmallDev *dev) {
+                         hipStream_t s, const SmallRaw *raw, const SmallDev *dev, int tab_n) {
   SmallArgs a{};
   a.ladder = 1;
   a.X = raw ? raw->X : static_cast<const double *>(c->dX);
@@ -1721,7 +1744,10 @@ int small_predict_launch(cgp_ctx *c, int batch, int N, int d, int M, int kid, in
   // launch to ONE round of workgroups -- a lone window: a chunk of 16 test points each; >= n_cu windows: one workgroup each
   a.parts = std::max(1, std::min(nchunk, std::max(c->n_cu, 1) / batch));
   a.parts = cdiv(nchunk, cdiv(nchunk, a.parts));   // no part without a chunk (8 windows x 38 chunks: 19 parts of two, not 32)
-  const size_t lds = small_predict_lds(cdiv(N, DB), d);
+  size_t lds = small_predict_lds(cdiv(N, DB), d);
+  if (lds + (size_t)tab_n * sizeof(double) > kLdsPerWorkgroup) tab_n = 0;   // no room beside the factor and the K* chunk: direct evaluation
+  a.tab_n = tab_n;
+  lds += (size_t)tab_n * sizeof(double);
   c->last_small_dev = dout == c->dsmall;
   const dim3 grid(batch * a.parts), block(SM_THREADS);
   if (kid == CGP_KERNEL_RBF_BROWNIAN) hipLaunchKernelGGL((k_small_predict<true, 1>), grid, block, lds, s, a);
@@ -1807,7 +1833,7 @@ int small_nll_grad(cgp_ctx *c, const double *X, const double *y, int N, int d, i
   if (!slot) return CGP_ENOMEM;
   SmallRaw raw;
   int rc = small_stage_window(c, X, y, N, d, nullptr, 0, theta, nth, raw);
-  if (rc == CGP_OK) rc = small_launch(c, 1, N, d, kid, SM_MODE_EVAL, 1, s, slot, &raw);
+  if (rc == CGP_OK) rc = small_launch(c, 1, N, d, kid, SM_MODE_EVAL, 1, s, slot, &raw, tick_table_entries(kid, d, X, N, nullptr, 0));
   double out[SM_OUT];
   if (rc == CGP_OK) rc = small_read_one(c, slot, out, s);
   if (rc != CGP_OK) return rc;
@@ -1830,7 +1856,7 @@ int small_optimize(cgp_ctx *c, const double *X, const double *y, int N, int d, i
   if (!slot) return CGP_ENOMEM;
   SmallRaw raw;
   int rc = small_stage_window(c, X, y, N, d, nullptr, 0, theta, nth, raw);
-  if (rc == CGP_OK) rc = small_launch(c, 1, N, d, kid, SM_MODE_OPT, max_evals, s, slot, &raw);
+  if (rc == CGP_OK) rc = small_launch(c, 1, N, d, kid, SM_MODE_OPT, max_evals, s, slot, &raw, tick_table_entries(kid, d, X, N, nullptr, 0));
   double out[SM_OUT];
   if (rc == CGP_OK) rc = small_read_one(c, slot, out, s);
   if (rc != CGP_OK) return rc;
@@ -1944,10 +1970,10 @@ int node_callback_small(cgp_ctx *c, const double *time_array, const double *slip
   double *hout = static_cast<double *>(c->pin_out);
   double *rec = hout + 2 * (size_t)M, *opt = rec + SM_OUT;
   if (max_evals > 0) {   // leaves the optimum in raw.theta, where the next launch reads it
-    rc = small_launch(c, 1, ntr, 1, kid, SM_MODE_OPT, max_evals, s, opt, &raw);
+    rc = small_launch(c, 1, ntr, 1, kid, SM_MODE_OPT, max_evals, s, opt, &raw, tick_table_entries(kid, 1, time_array, ntr, nullptr, 0));
     if (rc != CGP_OK) return rc;
   }
-  rc = small_predict_launch(c, 1, ntr, 1, M, kid, 1, hout, hout + M, rec, s, &raw);
+  rc = small_predict_launch(c, 1, ntr, 1, M, kid, 1, hout, hout + M, rec, s, &raw, nullptr, tick_table_entries(kid, 1, time_array, ntr, raw.Xs, M));
   if (rc != CGP_OK) return rc;
   HIP_TRY(c, hipStreamSynchronize(s));
   memcpy(c->last_small, max_evals > 0 ? opt : rec, SM_OUT * sizeof(double));

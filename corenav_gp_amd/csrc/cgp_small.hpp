@@ -43,6 +43,7 @@ constexpr int SM_WAVES = SM_THREADS / 64;
 constexpr int SM_NH = SM_HELPERS;          // helper waves beside the factor chain.  Measured (cycles per evaluation, N = 134): with 6 the chain
                                            // issues alone on its SIMD (31 k) but the helpers end later (factor phases 48 k); with 7 the chain
                                            // slows to 38 k and the phases end at 43.5 k
+constexpr int SM_TAB_MAX = 1024;           // entries of the tick-grid RBF table (8 KB)
 constexpr int SM_DEAL = 16;                // entries of a helper's work list: count + at most 15 items (ten block rows, six helpers: 52 items of a step, at most 12 on one)
 constexpr int SM_OUT = 48;                 // doubles per window in SmallArgs::out ([32, 48): phase clocks of a -DCGP_ABLATION build)
 enum { SM_MODE_EVAL = 0, SM_MODE_OPT = 1 };
@@ -68,6 +69,11 @@ struct SmallArgs {
   const double *Xs;
   double *mean, *var;
   int M, include_noise, parts;
+  // RBF x Brownian on a tick grid: every input (window and test points) integer-valued, |x| <= 2^26, spread < tab_n <= SM_TAB_MAX:
+  // r^2 = -2 x x' + (x^2 + x'^2) is then the exact integer (x - x')^2 and the RBF factor takes tab_n values per evaluation, which
+  // the kernels keep in LDS (same expression, same bits as the direct evaluation).  0: no table.  The host decides (it has the
+  // arrays: node callbacks, cgp_nll_grad, cgp_optimize); device-resident batches run without.
+  int tab_n;
   const double *jitter;   // per window or NULL: the jitter to start from
   int ladder;             // 1: GPy's jitchol ladder inside the launch; 0: one attempt at the given jitter, the pivot reported
   double *logml;          // per window or NULL (beside the record)
@@ -114,6 +120,8 @@ struct SmallLds {
   int *flag;     // [0] first non-positive pivot of the running evaluation, [1] optimiser finished, [2] ladder attempt
   int *tb;       // [blocks] packed block index -> block row | block column << 8
   unsigned short *deal;   // [NB][SM_NH][SM_DEAL] helper work lists (sm_build_deal)
+  double *etab;           // [tab_n] sigma_r^2 exp(-(i / ell)^2 / 2) of the tick-grid form, rebuilt per evaluation; tab_n = 0: none
+  int tab_n;
 };
 
 // Phase clocks (-DCGP_ABLATION builds only): lane 0 adds the s_memtime ticks since the previous lap to sc[48 + slot]; k_small
@@ -230,6 +238,28 @@ template <bool BROWN, int DMAX> struct SmKern {
       return amp * exp_nonpos(-0.5 * d2, ec);
     }
   }
+  // tick-grid forms (SmallArgs::tab_n): the RBF factor from the table, index |x - x'| (an exact integer)
+  __device__ __forceinline__ double brownian(double x, double xp) const {
+    const bool same = (x > 0.0 && xp > 0.0) || (x < 0.0 && xp < 0.0) || (x == 0.0 && xp == 0.0);
+    const double ax = __builtin_fabs(x), ap = __builtin_fabs(xp);
+    return same ? amp_b * (ax < ap ? ax : ap) : 0.0;
+  }
+  // (tmax = tab_n - 1 as a double: padded rows / columns are evaluated and discarded, their index must stay inside the table)
+  __device__ __forceinline__ double eval_tab(const double *xr, const double *etab, double tmax, int gi, int gj) const {
+    const double x = xr[gi], xp = xr[gj];
+    return etab[(int)__builtin_fmin(__builtin_fabs(x - xp), tmax)] * brownian(x, xp);
+  }
+  __device__ __forceinline__ double cross_tab(const double *xr, const double *xt, const double *etab, double tmax, int gi, int c) const {
+    const double x = xr[gi], xp = xt[c];
+    return etab[(int)__builtin_fmin(__builtin_fabs(x - xp), tmax)] * brownian(x, xp);
+  }
+  // the table itself: entry i = amp exp(-0.5 (i^2 / ell^2)), the expression eval / cross evaluate for r^2 = i^2
+  __device__ __forceinline__ void fill_tab(double *etab, int tab_n, int tid, const ExpC &ec) const {
+    for (int i = tid; i < tab_n; i += SM_THREADS) {
+      const double r2 = (double)i * (double)i;
+      etab[i] = amp * exp_nonpos(-0.5 * (r2 * (iell[0] * iell[0])), ec);
+    }
+  }
   // the length-scaled squared differences alone (the gradient phase has K itself from the Gram phase, in registers)
   __device__ __forceinline__ void diffs(const double *xr, int d, int NP, int gi, int gj, double (&dq2)[DMAX]) const {
     if constexpr (BROWN) {
@@ -295,6 +325,13 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
   ck.start();
   SmKern<BROWN, DMAX> kern;
   kern.load(s.sc);
+  const bool tab = BROWN && s.tab_n > 0;
+  if constexpr (BROWN) {
+    if (tab) {
+      kern.fill_tab(s.etab, s.tab_n, tid, ec);
+      __syncthreads();
+    }
+  }
   // ---- Gram, in the mapping the gradient phase uses (wave w: blocks w, w + 8, ...; lane (l15, lq): entries (row lq + 4 r, column
   // l15)), so that the covariances stay in registers (kv) for the contraction at the end instead of being evaluated twice
   constexpr int KVB = (SM_MAX_NB * (SM_MAX_NB + 1) / 2 + SM_WAVES - 1) / SM_WAVES;   // blocks per wave at most
@@ -313,7 +350,8 @@ __device__ __forceinline__ void sm_eval(const SmallLds &s, int d, int N, int NB,
           double dq2[DMAX];
           double k0 = 0.0, g;
           if (gi < N && gj < N) {
-            k0 = kern.eval(s.xr, d, NP, gi, gj, ec, dq2);
+            if constexpr (BROWN) k0 = tab ? kern.eval_tab(s.xr, s.etab, (double)(s.tab_n - 1), gi, gj) : kern.eval(s.xr, d, NP, gi, gj, ec, dq2);
+            else k0 = kern.eval(s.xr, d, NP, gi, gj, ec, dq2);
             g = gi == gj ? k0 + diag_add : k0;
           } else g = (gi == gj) ? 1.0 : 0.0;   // identity padding keeps the factor well defined
           kv[i][r] = GRAD ? k0 : 0.0;
@@ -962,6 +1000,8 @@ __global__ __launch_bounds__(SM_THREADS) void k_small(SmallArgs p) {
   s.flag = reinterpret_cast<int *>(reinterpret_cast<char *>(s.lb) + sizeof(corenav::LbfgsCore));
   s.tb = s.flag + 8;
   s.deal = reinterpret_cast<unsigned short *>(s.tb + nblk);
+  s.etab = reinterpret_cast<double *>(smem_raw + ((small_lds_bytes(NB, d) + 15) & ~(size_t)15));   // behind everything else
+  s.tab_n = BROWN ? p.tab_n : 0;
   const double *Xb = p.X + (size_t)b * d * N, *yb = p.y + (size_t)b * N;
   double *thb = p.theta + (size_t)b * MAX_THETA, *ob = p.out + (size_t)b * SM_OUT;
   for (int i = tid; i < d * NP; i += SM_THREADS) {
@@ -1105,6 +1145,8 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_predict(SmallArgs p) {
   double *xt = Ks + (size_t)NB * SM_BLK;     // [d][16] test points of the chunk
   double *mpart = xt + (size_t)d * DB;       // [NB][16] partial means by block row
   double *vpart = mpart + (size_t)NB * DB;   // [waves][16] partial |V|^2
+  s.etab = vpart + SM_WAVES * DB + 16;       // small_predict_lds_extra ends here
+  s.tab_n = BROWN ? p.tab_n : 0;
   const double *Xb = p.X + (size_t)b * d * N, *yb = p.y + (size_t)b * N, *Xsb = p.Xs + (size_t)b * d * M;
   SmClock ck;   // CGP_ABLATION builds: slots 10 staging, 11 K* chunk, 12 means + V, 13 outputs (the fit laps slots 1..7 itself)
   ck.start();
@@ -1185,7 +1227,10 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_predict(SmallArgs p) {
         const int bj = b0 + (tid >> 8);
         if (bj < NB) {
           const int gi = bj * DB + r;
-          Ks[bj * SM_BLK + c * SM_LD + r] = (gi < N && m0 + c < M) ? kern.cross(s.xr, xt, d, NP, gi, c, ec) : 0.0;
+          double kv;
+          if constexpr (BROWN) kv = s.tab_n > 0 ? kern.cross_tab(s.xr, xt, s.etab, (double)(s.tab_n - 1), gi, c) : kern.cross(s.xr, xt, d, NP, gi, c, ec);
+          else kv = kern.cross(s.xr, xt, d, NP, gi, c, ec);
+          Ks[bj * SM_BLK + c * SM_LD + r] = (gi < N && m0 + c < M) ? kv : 0.0;
         }
       }
     }

@@ -193,3 +193,38 @@ def test_short_window_kernel_matches_the_large_window_machinery(engine):
     np.testing.assert_allclose(a["mean"], b["mean"], rtol=0, atol=2e-3 * np.max(np.abs(b["mean"])))
     np.testing.assert_allclose(a["sigma"], b["sigma"], rtol=2e-3)
     assert abs(a["nev"] - b["nev"]) <= 6
+
+
+def test_tick_grid_table_is_bitwise_the_direct_evaluation():
+    """RBF x Brownian windows whose inputs are tick counts (integer-valued, as the reference's GP_Input always is) take the RBF
+    factor from a per-evaluation table in LDS (csrc/cgp_small.hpp: SmallArgs::tab_n).  r^2 is then an exact integer, the table
+    entry is the same expression, and every output must carry the same BITS as with the table switched off (CGP_TICKTAB=off,
+    read once per process: child processes) -- gradient, optimum, callback mean and sigma; gaps in the ticks, a large tick
+    offset; and a window off the grid (x + 0.25) must simply take the direct path."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from corenav_gp_amd import engine\n"
+        "g = np.load(%r)\n"
+        "t, s, th = g['time_array'], g['slip_array'], g['theta']\n"
+        "out = {}\n"
+        "for name, tt in (('plain', t), ('gaps', np.delete(t + 40000.0, [5, 6, 40, 90]) + np.r_[np.zeros(60), 7 * np.ones(len(t) - 64)]), ('offgrid', t + 0.25)):\n"
+        "    ss = s[:len(tt)]\n"
+        "    ctx = engine.Context(max_n=256, max_m=1024, max_d=1)\n"
+        "    n = int(0.9 * len(tt))\n"
+        "    nll, gr = ctx.nll_grad(tt[:n, None], ss[:n], engine.KERNEL_RBF_BROWNIAN, th)\n"
+        "    m, sg = ctx.slip_node_callback(tt, ss, th)\n"
+        "    m2, sg2, tho = ctx.slip_node_callback_opt(tt, ss, np.ones(4))\n"
+        "    out[name] = [float(nll).hex()] + [float(v).hex() for v in np.concatenate([gr, m, sg, m2, sg2, tho])]\n"
+        "print('RESULT' + json.dumps(out))\n" % (root, os.path.join(root, "tests", "golden", "slipval_window_rbfbrownian.npz")))
+
+    def run(env):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1][6:])
+
+    on, off = run({}), run({"CGP_TICKTAB": "off"})
+    for name in ("plain", "gaps", "offgrid"):
+        assert on[name] == off[name], name
