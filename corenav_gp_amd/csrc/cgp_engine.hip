@@ -104,6 +104,7 @@ struct cgp_ctx {
   unsigned short *dsmdeal = nullptr;   // k_small's helper work lists (sm_build_deal) of every NB <= SM_MAX_NB, at smdeal_off[NB]
   size_t smdeal_off[SM_MAX_NB + 1] = {0};
   std::vector<double> lazy_win;   // [X (N, d) | y] of the window a short-window kernel evaluated in place (ensure_fitted uploads it)
+  int pending_tab = 0;               // tick-grid table size cgp_fit_predict_batch found for the batch it is about to submit (0: none)
   bool last_small_dev = false;       // ... or window 0's record of the last batched fit + predict launch, still in dsmall
   double last_small[SM_OUT] = {0};   // the last single-window short-window record (the kernels write it to pinned host memory)
   size_t lw_stride = 0, winv_stride = 0, alpha_stride = 0;
@@ -129,6 +130,7 @@ namespace {
 
 int ensure_fitted(cgp_ctx *c);   // below, with the short-window paths
 bool small_batch_predict_ok(const cgp_ctx *c, int batch, int N, int d, int M);
+int tick_table_entries_batch(int kid, int d, int batch, const double *X, int N, const double *Xs, int M);
 struct SmallRaw;
 struct SmallDev {   // a batch resident in the caller's device buffers (cgp_fit_predict_batch_device): no ladder, jitter as given
   const double *X, *y, *Xs, *theta, *jitter;
@@ -1166,8 +1168,10 @@ int cgp_fit_predict_batch_device(cgp_ctx *c, int batch, int N, int d, int M, int
   c->lazy_fit = false;
   if (small_batch_predict_ok(c, batch, N, d, M)) {   // short windows: fit + predictions of the whole batch in ONE launch, factors in LDS
     const SmallDev dev{static_cast<const double *>(dX), static_cast<const double *>(dy), static_cast<const double *>(dXs), dtheta, djitter, dlogml, dinfo};
+    const int tab = c->pending_tab;   // only the host-buffer entry point knows whether the inputs are tick counts
+    c->pending_tab = 0;
     return small_predict_launch(c, batch, N, d, M, kid, include_noise, static_cast<double *>(dmean), static_cast<double *>(dvar), c->dsmall,
-                                pick_stream(c, hip_stream), nullptr, &dev);
+                                pick_stream(c, hip_stream), nullptr, &dev, tab);
   }
   return run(c, a, batch, true, false, pick_stream(c, hip_stream));
 }
@@ -1263,8 +1267,14 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
     if (M > 0) pack(draw + nX + ny, c->dXs, M, d);
     HIP_TRY(c, hipMemsetAsync(c->djitter, 0, sizeof(double) * batch, s));
   }
+  // (the scan that establishes "tick counts" is 1.5 ns per input on the host: 0.3 ms for 256 windows with their 599 test points,
+  // more than the launch it would shorten by a tenth -- ensembles beyond 20 k inputs take the direct evaluation)
+  const int tick_tab = small_batch_predict_ok(c, batch, N, d, M) && (size_t)batch * (N + M) <= 20000
+                           ? tick_table_entries_batch(kid, d, batch, X, N, Xs, M) : 0;
+  c->pending_tab = tick_tab;
   rc = cgp_fit_predict_batch_device(c, batch, N, d, M, kid, c->dX, c->dy, c->dXs, c->dtheta, c->djitter,
                                     include_noise, c->dmean, c->dvar, c->dlogml, c->dinfo, CGP_STREAM_CTX);
+  c->pending_tab = 0;
   if (rc != CGP_OK) return rc;
   char *hout = static_cast<char *>(c->pin_out);
   double *hl = reinterpret_cast<double *>(hout + out_elems * esz);
@@ -1294,6 +1304,7 @@ int cgp_fit_predict_batch(cgp_ctx *c, int batch, int N, int d, int M, int kid, c
     retried = true;
     for (int attempt = 0; attempt < 5 && hinfo[b] != 0; ++attempt, jit *= 10.0) {
       HIP_TRY(c, hipMemcpyAsync(c->djitter + b, &jit, sizeof(double), hipMemcpyHostToDevice, s));
+      c->pending_tab = tick_tab;
       rc = cgp_fit_predict_batch_device(
           c, 1, N, d, M, kid, (char *)c->dX + (size_t)b * d * N * esz, (char *)c->dy + (size_t)b * N * esz,
           (char *)c->dXs + (size_t)b * d * M * esz, c->dtheta + (size_t)b * CGP_MAX_THETA, c->djitter + b,
@@ -1631,17 +1642,34 @@ int tick_table_entries(int kid, int d, const double *X, int N, const double *Xs,
   }();
   if (off || kid != CGP_KERNEL_RBF_BROWNIAN || d != 1) return 0;
   double lo = X[0], hi = X[0];
-  auto scan = [&](const double *v, int n) {
+  auto scan = [&](const double *v, int n) {   // branch-free body (vectorises): this runs in front of launches that take 50 us
+    double l = lo, h = hi;
+    int bad = 0;
     for (int i = 0; i < n; ++i) {
-      if (!(std::fabs(v[i]) <= 67108864.0) || v[i] != std::nearbyint(v[i])) return false;
-      lo = std::min(lo, v[i]);
-      hi = std::max(hi, v[i]);
+      const double x = v[i];
+      const double c = x < -67108864.0 ? -67108864.0 : (x > 67108864.0 ? 67108864.0 : x);   // NaN falls through as itself
+      bad |= (double)(int)c != x;
+      l = x < l ? x : l;
+      h = x > h ? x : h;
     }
-    return true;
+    lo = l;
+    hi = h;
+    return bad == 0;
   };
   if (!scan(X, N) || (Xs && !scan(Xs, M))) return 0;
   const double spread = hi - lo;
   return spread < (double)SM_TAB_MAX ? (int)spread + 1 : 0;
+}
+
+// ... of a batch of windows (and their test points): the largest of the windows' tables, 0 as soon as one window is off the grid
+int tick_table_entries_batch(int kid, int d, int batch, const double *X, int N, const double *Xs, int M) {
+  int n = 0;
+  for (int b = 0; b < batch; ++b) {
+    const int nb = tick_table_entries(kid, d, X + (size_t)b * N * d, N, Xs ? Xs + (size_t)b * M * d : nullptr, M);
+    if (nb == 0) return 0;
+    n = std::max(n, nb);
+  }
+  return n;
 }
 
 double mean_abs_first(const double *X, int N, int d) {
@@ -2420,7 +2448,7 @@ extern "C" int cgp_optimize_batch(cgp_ctx *c, int batch, int N, int d, int kid, 
         if (!(theta[(size_t)b * theta_stride + i] > 0.0)) return CGP_EINVAL;
     std::vector<double> hth;
     rc = upload_theta(c, theta, theta_stride, nth, batch, s, hth);
-    if (rc == CGP_OK) rc = small_launch(c, batch, N, d, kid, SM_MODE_OPT, max_evals, s);
+    if (rc == CGP_OK) rc = small_launch(c, batch, N, d, kid, SM_MODE_OPT, max_evals, s, nullptr, nullptr, tick_table_entries_batch(kid, d, batch, X, N, nullptr, 0));
     c->last_small_dev = true;
     if (rc != CGP_OK) return rc;
     std::vector<double> out((size_t)batch * SM_OUT);

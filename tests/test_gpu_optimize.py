@@ -200,7 +200,8 @@ def test_tick_grid_table_is_bitwise_the_direct_evaluation():
     factor from a per-evaluation table in LDS (csrc/cgp_small.hpp: SmallArgs::tab_n).  r^2 is then an exact integer, the table
     entry is the same expression, and every output must carry the same BITS as with the table switched off (CGP_TICKTAB=off,
     read once per process: child processes) -- gradient, optimum, callback mean and sigma; gaps in the ticks, a large tick
-    offset; and a window off the grid (x + 0.25) must simply take the direct path."""
+    offset; the batched entry points (cgp_fit_predict_batch, cgp_optimize_batch); and a window off the grid (x + 0.25) must simply
+    take the direct path."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
@@ -218,6 +219,14 @@ def test_tick_grid_table_is_bitwise_the_direct_evaluation():
         "    m, sg = ctx.slip_node_callback(tt, ss, th)\n"
         "    m2, sg2, tho = ctx.slip_node_callback_opt(tt, ss, np.ones(4))\n"
         "    out[name] = [float(nll).hex()] + [float(v).hex() for v in np.concatenate([gr, m, sg, m2, sg2, tho])]\n"
+        "n, W = int(0.9 * len(t)), 5\n"
+        "X = np.stack([t[:n] + 1000.0 * k for k in range(W)])[:, :, None]; y = np.stack([np.roll(s, k)[:n] for k in range(W)])\n"
+        "Xs = np.stack([X[k, -1, 0] + 1 + np.arange(77.0) for k in range(W)])[:, :, None]\n"
+        "bctx = engine.Context(max_n=n, max_m=256, max_d=1, max_batch=W)\n"
+        "rc, mean, var, logml, info = bctx.fit_predict_batch(X, y, Xs, np.tile(th, (W, 1)), engine.KERNEL_RBF_BROWNIAN)\n"
+        "tb, lb, eb = bctx.optimize_batch(X, y, engine.KERNEL_RBF_BROWNIAN, np.ones(4), max_evals=30)\n"
+        "assert rc == 0 and not info.any()\n"
+        "out['batch'] = [float(v).hex() for v in np.concatenate([mean.ravel(), var.ravel(), logml, tb.ravel(), lb])]\n"
         "print('RESULT' + json.dumps(out))\n" % (root, os.path.join(root, "tests", "golden", "slipval_window_rbfbrownian.npz")))
 
     def run(env):
@@ -226,5 +235,5 @@ def test_tick_grid_table_is_bitwise_the_direct_evaluation():
         return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1][6:])
 
     on, off = run({}), run({"CGP_TICKTAB": "off"})
-    for name in ("plain", "gaps", "offgrid"):
+    for name in ("plain", "gaps", "offgrid", "batch"):
         assert on[name] == off[name], name
