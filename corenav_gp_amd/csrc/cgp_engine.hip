@@ -2365,6 +2365,20 @@ extern "C" int cgp_selftest_lbfgs(double *x, int n, int max_evals, double *f_out
   return r.status == 3 ? -1 : r.evals;
 }
 
+extern "C" int cgp_lbfgs_minimize(cgp_objective_fn fn, void *user, double *x, int n, int max_evals, double pgtol, double factr,
+                                  double *f_out, int *n_evals, int *n_iters, int *status) {
+  if (!fn || !x || n < 1 || n > corenav::LB_N) return CGP_EINVAL;
+  std::vector<double> xv(x, x + n);
+  auto fg = [&](const std::vector<double> &v, std::vector<double> &g) { return fn(v.data(), g.data(), n, user); };
+  corenav::LbfgsResult r = corenav::lbfgs_minimize(fg, xv, max_evals > 0 ? max_evals : 1000, pgtol, factr);
+  for (int i = 0; i < n; ++i) x[i] = xv[i];
+  if (f_out) *f_out = r.f;
+  if (n_evals) *n_evals = r.evals;
+  if (n_iters) *n_iters = r.iters;
+  if (status) *status = r.status;
+  return CGP_OK;
+}
+
 namespace {
 // Gradient-mode evaluation of `batch` windows already uploaded to slots 0..batch-1 (theta in dtheta).
 template <typename T>

@@ -740,101 +740,53 @@ __device__ __attribute__((noinline)) void sm_lbfgs_tell_wave(corenav::LbfgsCore 
   const int j = lane & 15, n = c.n;
   const bool on = j < n, wr = lane < 16;
   double xj = c.x[j], gj = c.g[j], xnj = c.xn[j], gnj = c.gn[j], dj = c.dir[j];
-  double f = c.f, fn = c.fn, dg0 = c.dg0, t = c.t, t_lo = c.t_lo, f_lo = c.f_lo, dg_lo = c.dg_lo, t_hi = c.t_hi, f_hi = c.f_hi,
-         t_prev = c.t_prev, f_prev = c.f_prev;
-  int hist = c.hist, ls = c.ls, iters = c.iters, have_hi = c.have_hi, first = c.first;
+  double f = c.f, fn = c.fn, dg0 = c.dg0, t = c.t;
+  corenav::MtSearch mt = c.mt;
+  int hist = c.hist, ls = c.ls, iters = c.iters, first = c.first;
   const int evals = c.evals + 1, max_evals = c.max_evals;
   const double pgtol = c.pgtol, ftol = c.ftol;
   bool do_start = false;
   int fin = -1;
-  if (!__builtin_isfinite(fv)) fv = INFINITY;
+  const bool feas = __builtin_isfinite(fv);
+  if (!feas) fv = corenav::LB_INFEASIBLE;
   if (first) {
     first = 0;
     f = fv;
     gj = gv;
-    if (!__builtin_isfinite(f)) fin = 3;
+    if (!feas) fin = 3;
+    else if (lb_amax(gj, on) <= pgtol) fin = 0;
     else do_start = true;
   } else {
     fn = fv;
-    gnj = gv;
-    // line search step (Nocedal & Wright alg. 3.5 / 3.6, c1 = 1e-4, c2 = 0.9)
-    const double c1 = 1e-4, c2 = 0.9;
-    const double tt = t;
-    const double dgn = __builtin_isfinite(fn) ? lb_dot(gnj, dj, on) : 0.0;
-    bool ok = false, give_up = false, again = false;
-    double tnew = 0.0;
-    if (!have_hi) {
-      if (fn > f + c1 * tt * dg0 || (ls > 0 && fn >= f_prev)) {
-        t_lo = t_prev;
-        f_lo = f_prev;
-        t_hi = tt;
-        f_hi = fn;
-        have_hi = 1;
-      } else if (__builtin_fabs(dgn) <= -c2 * dg0) {
-        ok = true;
-      } else if (dgn >= 0) {
-        t_hi = t_prev;
-        f_hi = f_prev;
-        t_lo = tt;
-        f_lo = fn;
-        dg_lo = dgn;
-        have_hi = 1;
+    gnj = feas ? gv : 0.0;
+    // one call of the More-Thuente search (lbfgs_core.hpp: MtSearch, the same code as the host stepper)
+    const double gd = lb_dot(gnj, dj, on);
+    double tt = t;
+    const int task = mt.step(fn, gd, tt);
+    if (task == 0) {
+      if (evals >= max_evals) fin = 2;
+      else if (ls >= corenav::LB_MAXLS) {   // the search failed: back to x, without memory if there was any
+        if (hist == 0) fin = 3;
+        else {
+          hist = 0;
+          do_start = true;
+        }
       } else {
-        t_prev = tt;
-        f_prev = fn;
-        dg_lo = dgn;
         ++ls;
-        if (ls >= 30 || evals >= max_evals) give_up = true;
-        else {
-          again = true;
-          tnew = 2.0 * tt;
-        }
+        t = tt;
+        xnj = xj + tt * dj;
       }
-    } else {
-      if (fn > f + c1 * tt * dg0 || fn >= f_lo) {
-        t_hi = tt;
-        f_hi = fn;
-      } else {
-        if (__builtin_fabs(dgn) <= -c2 * dg0) ok = true;
-        else {
-          if (dgn * (t_hi - t_lo) >= 0) {
-            t_hi = t_lo;
-            f_hi = f_lo;
-          }
-          t_lo = tt;
-          f_lo = fn;
-          dg_lo = dgn;
-        }
-      }
-    }
-    if (!again && !ok && !give_up) {
-      ++ls;
-      const double lo = t_lo < t_hi ? t_lo : t_hi, hi = t_lo < t_hi ? t_hi : t_lo;
-      if (ls >= 30 || evals >= max_evals || __builtin_fabs(hi - lo) < 1e-16 * __builtin_fmax(1.0, __builtin_fabs(lo))) give_up = true;
+    } else {   // accept the step
+      const double sj = xnj - xj, yj = gnj - gj;
+      const double sy = lb_dot(sj, yj, on), fold = f;
+      xj = xnj;
+      gj = gnj;
+      f = fn;
+      ++iters;
+      if (lb_amax(gj, on) <= pgtol) fin = 0;
+      else if ((fold - f) <= ftol * __builtin_fmax(__builtin_fmax(__builtin_fabs(fold), __builtin_fabs(f)), 1.0)) fin = 1;
       else {
-        const double dt = t_hi - t_lo;  // quadratic interpolation, safeguarded by bisection
-        double tq = t_lo - 0.5 * dg_lo * dt * dt / (f_hi - f_lo - dg_lo * dt);
-        if (!__builtin_isfinite(tq) || tq <= lo + 0.1 * (hi - lo) || tq >= hi - 0.1 * (hi - lo)) tq = 0.5 * (lo + hi);
-        again = true;
-        tnew = tq;
-      }
-    }
-    if (again) {
-      t = tnew;
-      xnj = xj + tnew * dj;
-    } else {
-      if (!ok) {  // accept a sufficient-decrease point if the last trial is one, else stop
-        if (__builtin_isfinite(fn) && fn <= f + c1 * tt * dg0 && fn < f) ok = true;
-        else fin = evals >= max_evals ? 2 : 3;
-      }
-      if (ok) {   // accept the step
-        const double sj = xnj - xj, yj = gnj - gj;
-        const double sy = lb_dot(sj, yj, on), yy = lb_dot(yj, yj, on), fold = f;
-        xj = xnj;
-        gj = gnj;
-        f = fn;
-        ++iters;
-        if (sy > 1e-10 * yy) {
+        if (sy > corenav::LB_EPS * (-dg0 * t)) {
           if (hist == LB_M) {  // drop the oldest pair
             if (wr) {
 #pragma unroll
@@ -856,14 +808,12 @@ __device__ __attribute__((noinline)) void sm_lbfgs_tell_wave(corenav::LbfgsCore 
           if (lane == 0) c.rho[hist] = 1.0 / sy;
           ++hist;
         }
-        if ((fold - f) <= ftol * __builtin_fmax(__builtin_fmax(__builtin_fabs(fold), __builtin_fabs(f)), 1.0)) fin = 1;
-        else do_start = true;
+        do_start = true;
       }
     }
   }
   if (do_start) {
-    if (lb_amax(gj, on) <= pgtol) fin = 0;
-    else if (evals >= max_evals) fin = 2;
+    if (evals >= max_evals) fin = 2;
     else {
       double q = gj, al[LB_M], sv[LB_M], yv[LB_M], rh[LB_M];   // two-loop recursion; every pair read from LDS once
 #pragma unroll
@@ -898,22 +848,21 @@ __device__ __attribute__((noinline)) void sm_lbfgs_tell_wave(corenav::LbfgsCore 
       }
       dj = -q;
       dg0 = lb_dot(gj, dj, on);
-      if (!(dg0 < 0)) {  // not a descent direction: restart from steepest descent
+      bool descent = dg0 < 0;
+      if (!descent && hist > 0) {  // ascent direction: drop the memory, restart from steepest descent
         hist = 0;
         dj = -gj;
         dg0 = lb_dot(gj, dj, on);
+        descent = dg0 < 0;
       }
-      t_lo = 0;
-      f_lo = f;
-      dg_lo = dg0;
-      t_hi = f_hi = 0;
-      have_hi = 0;
-      t_prev = 0;
-      f_prev = f;
-      ls = 0;
-      const double gm = lb_amax(gj, on);
-      t = iters == 0 ? __builtin_fmin(1.0, 1.0 / __builtin_fmax(gm, 1e-300)) : 1.0;
-      xnj = xj + t * dj;
+      if (!descent) fin = 3;
+      else {
+        const double dnorm = sqrt(lb_dot(dj, dj, on));
+        t = iters == 0 ? __builtin_fmin(1.0 / dnorm, corenav::LB_STPMAX) : 1.0;
+        ls = 1;
+        mt.start(f, dg0, t);
+        xnj = xj + t * dj;
+      }
     }
   }
   if (fin >= 0) xnj = xj;
@@ -925,9 +874,9 @@ __device__ __attribute__((noinline)) void sm_lbfgs_tell_wave(corenav::LbfgsCore 
     c.dir[j] = dj;
   }
   if (lane == 0) {
-    c.f = f; c.fn = fn; c.dg0 = dg0; c.t = t; c.t_lo = t_lo; c.f_lo = f_lo; c.dg_lo = dg_lo; c.t_hi = t_hi; c.f_hi = f_hi;
-    c.t_prev = t_prev; c.f_prev = f_prev;
-    c.hist = hist; c.ls = ls; c.iters = iters; c.have_hi = have_hi; c.first = first; c.evals = evals;
+    c.f = f; c.fn = fn; c.dg0 = dg0; c.t = t;
+    c.mt = mt;
+    c.hist = hist; c.ls = ls; c.iters = iters; c.first = first; c.evals = evals;
     if (fin >= 0) {
       c.status = fin;
       c.finished = 1;

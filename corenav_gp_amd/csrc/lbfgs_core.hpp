@@ -1,10 +1,22 @@
-// lbfgs_core.hpp -- the L-BFGS state machine of lbfgs.hpp as ONE fixed-size struct that compiles for the host and for
-// the device: unconstrained limited-memory BFGS (m = 10) with a strong-Wolfe line search, the role
-// scipy.optimize.fmin_l_bfgs_b (no bounds) plays under GPy's `m.optimize()`
-// (core_navigation/script/gp_slip_node.py:36; paramz 'lbfgsb': factr 1e7, pgtol 1e-5, maxfun 1000).
-// Ask / tell: evaluate f and its gradient at xn, call tell(); repeat until done.  The host optimisers
-// (LbfgsStepper, cgp_optimize_batch) and the one-launch device optimiser of short windows (cgp_small.hpp: lane 0 of the
-// window's workgroup) run this same code.
+// lbfgs_core.hpp -- the optimiser under GPy's `m.optimize()` (core_navigation/script/gp_slip_node.py:36; paramz 'lbfgsb' =
+// scipy.optimize.fmin_l_bfgs_b, no bounds, m = 10, factr 1e7, pgtol 1e-5, maxfun 1000) restated as ONE fixed-size struct
+// that compiles for the host and for the device.  Without bounds L-BFGS-B (Byrd, Lu, Nocedal, Zhu 1995; Zhu et al. 1997,
+// version 3.0) is:
+//   direction  d = -H g, H the limited-memory BFGS inverse with H0 = (s'y / y'y) I of the newest pair (its generalised
+//              Cauchy point is x itself and the subspace step is the full quasi-Newton step; first direction -g);
+//   step       Moré & Thuente's search (MINPACK-2 dcsrch / dcstep, ACM TOMS 20, 1994) with ftol 1e-3, gtol 0.9, xtol 0.1,
+//              first trial 1 / |d| in the first iteration and 1 afterwards, at most 20 evaluations; a warning exit of the
+//              search is accepted like a converged one; a failed search or an ascent direction drops the memory and
+//              restarts from steepest descent, and stops the run if the memory was already empty;
+//   update     the pair is skipped when s'y <= eps * (-g'd) * step;
+//   stop       max |g| <= pgtol, then (f_old - f) <= factr * eps * max(|f_old|, |f|, 1) -- tested in that order after
+//              every accepted step.
+// With the same line search the run follows scipy's trajectory (same trial points to rounding, same number of
+// evaluations: tests/test_optimizer_cpu.py drives this struct and scipy on the oracle's objective).  The two-loop
+// recursion replaces L-BFGS-B's compact representation: the same matrix, different rounding.
+// Ask / tell: evaluate f and its gradient at xn, call tell(); repeat until done.  The host optimisers (LbfgsStepper,
+// cgp_optimize_batch) and the one-launch device optimiser of short windows (cgp_small.hpp, one lane per parameter) run
+// this same state machine; the line search (MtSearch) is the same code in both.
 #pragma once
 #include <math.h>
 
@@ -16,27 +28,166 @@
 
 namespace corenav {
 
-constexpr int LB_N = 16;  // parameters at most (CGP_MAX_THETA = 10; cgp_selftest_lbfgs takes up to 16)
-constexpr int LB_M = 10;  // history pairs
+constexpr int LB_N = 16;      // parameters at most (CGP_MAX_THETA = 10; cgp_selftest_lbfgs takes up to 16)
+constexpr int LB_M = 10;      // history pairs
+constexpr int LB_MAXLS = 20;  // evaluations per line search (scipy: maxls)
+constexpr double LB_EPS = 2.220446049250313e-16;
+constexpr double LB_STPMAX = 1e10;   // L-BFGS-B: `big` for a problem without bounds
+constexpr double LB_INFEASIBLE = 1e300;   // value given to a point whose matrix stays indefinite (oracle/gp_oracle.py: optimize)
+
+// One line search.  start() = the 'START' call of dcsrch, step() = every later call: 0 -> evaluate at the new stp,
+// 1 -> converged (sufficient decrease and curvature), 2 -> one of dcsrch's warnings (the caller accepts the point).
+struct MtSearch {
+  int brackt, stage;
+  double finit, ginit, gtest, width, width1, stx, fx, gx, sty, fy, gy, stmin, stmax;
+
+  static CGP_HD double mx(double a, double b) { return a > b ? a : b; }
+  static CGP_HD double mn(double a, double b) { return a < b ? a : b; }
+  static CGP_HD double ab(double a) { return a < 0 ? -a : a; }
+
+  CGP_HD void start(double f, double g, double stp) {
+    brackt = 0;
+    stage = 1;
+    finit = f;
+    ginit = g;
+    gtest = 1e-3 * g;
+    width = LB_STPMAX;
+    width1 = 2.0 * LB_STPMAX;
+    stx = sty = 0.0;
+    fx = fy = f;
+    gx = gy = g;
+    stmin = 0.0;
+    stmax = stp + 4.0 * stp;
+  }
+
+  CGP_HD int step(double f, double g, double &stp) {
+    const double gtol = 0.9, xtol = 0.1, stpmin = 0.0, stpmax = LB_STPMAX;
+    const double ftest = finit + stp * gtest;
+    if (stage == 1 && f <= ftest && g >= 0.0) stage = 2;
+    int task = 0;
+    if (brackt && (stp <= stmin || stp >= stmax)) task = 2;        // rounding errors prevent progress
+    if (brackt && stmax - stmin <= xtol * stmax) task = 2;         // xtol test satisfied
+    if (stp == stpmax && f <= ftest && g <= gtest) task = 2;
+    if (stp == stpmin && (f > ftest || g >= gtest)) task = 2;
+    if (f <= ftest && ab(g) <= gtol * (-ginit)) task = 1;
+    if (task) return task;
+    if (stage == 1 && f <= fx && f > ftest) {   // the modified function of the first stage
+      double fxm = fx - stx * gtest, fym = fy - sty * gtest, gxm = gx - gtest, gym = gy - gtest;
+      trial(stx, fxm, gxm, sty, fym, gym, stp, f - stp * gtest, g - gtest);
+      fx = fxm + stx * gtest;
+      fy = fym + sty * gtest;
+      gx = gxm + gtest;
+      gy = gym + gtest;
+    } else {
+      trial(stx, fx, gx, sty, fy, gy, stp, f, g);
+    }
+    if (brackt) {
+      if (ab(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
+      width1 = width;
+      width = ab(sty - stx);
+      stmin = mn(stx, sty);
+      stmax = mx(stx, sty);
+    } else {
+      stmin = stp + 1.1 * (stp - stx);
+      stmax = stp + 4.0 * (stp - stx);
+    }
+    stp = mn(mx(stp, stpmin), stpmax);
+    if ((brackt && (stp <= stmin || stp >= stmax)) || (brackt && stmax - stmin <= xtol * stmax)) stp = stx;
+    return 0;
+  }
+
+ private:
+  // dcstep: the safeguarded cubic / quadratic trial step and the update of the interval [stx, sty]
+  CGP_HD void trial(double &sx, double &fxv, double &dx, double &sy, double &fyv, double &dy, double &stp, double fp, double dp) {
+    const double sgnd = dp * (dx / ab(dx));
+    double stpf;
+    if (fp > fxv) {   // higher value: the minimum is bracketed
+      const double theta = 3.0 * (fxv - fp) / (stp - sx) + dx + dp;
+      const double s = mx(mx(ab(theta), ab(dx)), ab(dp));
+      double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+      if (stp < sx) gamma = -gamma;
+      const double r = ((gamma - dx) + theta) / (((gamma - dx) + gamma) + dp);
+      const double stpc = sx + r * (stp - sx);
+      const double stpq = sx + ((dx / ((fxv - fp) / (stp - sx) + dx)) / 2.0) * (stp - sx);
+      stpf = ab(stpc - sx) < ab(stpq - sx) ? stpc : stpc + (stpq - stpc) / 2.0;
+      brackt = 1;
+    } else if (sgnd < 0.0) {   // lower value, derivatives of opposite sign: bracketed
+      const double theta = 3.0 * (fxv - fp) / (stp - sx) + dx + dp;
+      const double s = mx(mx(ab(theta), ab(dx)), ab(dp));
+      double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+      if (stp > sx) gamma = -gamma;
+      const double r = ((gamma - dp) + theta) / (((gamma - dp) + gamma) + dx);
+      const double stpc = stp + r * (sx - stp);
+      const double stpq = stp + (dp / (dp - dx)) * (sx - stp);
+      stpf = ab(stpc - stp) > ab(stpq - stp) ? stpc : stpq;
+      brackt = 1;
+    } else if (ab(dp) < ab(dx)) {   // lower value, same sign, the derivative shrinks
+      const double theta = 3.0 * (fxv - fp) / (stp - sx) + dx + dp;
+      const double s = mx(mx(ab(theta), ab(dx)), ab(dp));
+      double gamma = s * sqrt(mx(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+      if (stp > sx) gamma = -gamma;
+      const double r = ((gamma - dp) + theta) / ((gamma + (dx - dp)) + gamma);
+      double stpc;
+      if (r < 0.0 && gamma != 0.0) stpc = stp + r * (sx - stp);
+      else stpc = stp > sx ? stmax : stmin;
+      const double stpq = stp + (dp / (dp - dx)) * (sx - stp);
+      if (brackt) {
+        stpf = ab(stpc - stp) < ab(stpq - stp) ? stpc : stpq;
+        stpf = stp > sx ? mn(stp + 0.66 * (sy - stp), stpf) : mx(stp + 0.66 * (sy - stp), stpf);
+      } else {
+        stpf = ab(stpc - stp) > ab(stpq - stp) ? stpc : stpq;
+        stpf = mx(stmin, mn(stmax, stpf));
+      }
+    } else {   // lower value, same sign, the derivative does not shrink
+      if (brackt) {
+        const double theta = 3.0 * (fp - fyv) / (sy - stp) + dy + dp;
+        const double s = mx(mx(ab(theta), ab(dy)), ab(dp));
+        double gamma = s * sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+        if (stp > sy) gamma = -gamma;
+        const double r = ((gamma - dp) + theta) / (((gamma - dp) + gamma) + dy);
+        stpf = stp + r * (sy - stp);
+      } else {
+        stpf = stp > sx ? stmax : stmin;
+      }
+    }
+    if (fp > fxv) {
+      sy = stp;
+      fyv = fp;
+      dy = dp;
+    } else {
+      if (sgnd < 0.0) {
+        sy = sx;
+        fyv = fxv;
+        dy = dx;
+      }
+      sx = stp;
+      fxv = fp;
+      dx = dp;
+    }
+    stp = stpf;
+  }
+};
 
 struct LbfgsCore {
   int n, max_evals, hist, ls, evals, iters, status;  // status: 0 converged (gradient), 1 converged (function decrease), 2 max evals, 3 line search failed
-  int have_hi, first, finished;
+  int first, finished;
   double pgtol, ftol;
   double x[LB_N], g[LB_N], xn[LB_N], gn[LB_N], dir[LB_N];
   double S[LB_M][LB_N], Y[LB_M][LB_N], rho[LB_M];
   double wa[LB_M], ws[LB_N], wy[LB_N];  // work vectors (members, so that on the device they live with the state in LDS, not in scratch memory)
-  double f, fn, dg0, t, t_lo, f_lo, dg_lo, t_hi, f_hi, t_prev, f_prev;
+  double f, fn, dg0, t;
+  MtSearch mt;
 
   CGP_HD void init(const double *x0, int n_, int max_evals_, double pgtol_, double factr) {
     n = n_;
     max_evals = max_evals_;
     pgtol = pgtol_;
-    ftol = factr * 2.220446049250313e-16;
+    ftol = factr * LB_EPS;
     hist = ls = evals = iters = status = 0;
-    have_hi = finished = 0;
+    finished = 0;
     first = 1;
-    f = fn = dg0 = t = t_lo = f_lo = dg_lo = t_hi = f_hi = t_prev = f_prev = 0.0;
+    f = fn = dg0 = t = 0.0;
+    mt.start(0.0, 0.0, 0.0);
     for (int i = 0; i < LB_N; ++i) {
       x[i] = xn[i] = i < n ? x0[i] : 0.0;
       g[i] = gn[i] = dir[i] = 0.0;
@@ -44,19 +195,22 @@ struct LbfgsCore {
   }
   CGP_HD bool done() const { return finished != 0; }
 
-  // Feed f(xn) and its gradient.  Non-finite f marks an infeasible point.
+  // Feed f(xn) and its gradient.  A non-finite f marks an infeasible point: it enters the search as LB_INFEASIBLE with a
+  // zero gradient.
   CGP_HD void tell(double fv, const double *gv) {
     ++evals;
-    if (!isfin(fv)) fv = INFINITY;
+    const bool feas = isfin(fv);
+    if (!feas) fv = LB_INFEASIBLE;
     if (first) {
       first = 0;
       f = fv;
       for (int i = 0; i < n; ++i) g[i] = gv[i];
-      if (!isfin(f)) return finish(3);
+      if (!feas) return finish(3);
+      if (gmax(g) <= pgtol) return finish(0);
       return start_iteration();
     }
     fn = fv;
-    for (int i = 0; i < n; ++i) gn[i] = gv[i];
+    for (int i = 0; i < n; ++i) gn[i] = feas ? gv[i] : 0.0;
     line_search_step();
   }
 
@@ -85,102 +239,49 @@ struct LbfgsCore {
   }
 
   CGP_HD void start_iteration() {
-    if (gmax(g) <= pgtol) return finish(0);
-    if (evals >= max_evals) return finish(2);
-    for (int j = 0; j < n; ++j) dir[j] = g[j];  // two-loop recursion
-    const int k = hist;
-    double *a = wa;
-    for (int i = k - 1; i >= 0; --i) {
-      a[i] = rho[i] * dot(S[i], dir);
-      for (int j = 0; j < n; ++j) dir[j] -= a[i] * Y[i][j];
-    }
-    if (k > 0) {
-      const double gam = dot(S[k - 1], Y[k - 1]) / dot(Y[k - 1], Y[k - 1]);
-      for (int j = 0; j < n; ++j) dir[j] *= gam;
-    }
-    for (int i = 0; i < k; ++i) {
-      const double be = rho[i] * dot(Y[i], dir);
-      for (int j = 0; j < n; ++j) dir[j] += S[i][j] * (a[i] - be);
-    }
-    for (int j = 0; j < n; ++j) dir[j] = -dir[j];
-    dg0 = dot(g, dir);
-    if (!(dg0 < 0)) {  // not a descent direction: restart from steepest descent
-      hist = 0;
-      for (int j = 0; j < n; ++j) dir[j] = -g[j];
+    for (;;) {
+      if (evals >= max_evals) return finish(2);
+      for (int j = 0; j < n; ++j) dir[j] = g[j];  // two-loop recursion
+      const int k = hist;
+      double *a = wa;
+      for (int i = k - 1; i >= 0; --i) {
+        a[i] = rho[i] * dot(S[i], dir);
+        for (int j = 0; j < n; ++j) dir[j] -= a[i] * Y[i][j];
+      }
+      if (k > 0) {
+        const double gam = dot(S[k - 1], Y[k - 1]) / dot(Y[k - 1], Y[k - 1]);
+        for (int j = 0; j < n; ++j) dir[j] *= gam;
+      }
+      for (int i = 0; i < k; ++i) {
+        const double be = rho[i] * dot(Y[i], dir);
+        for (int j = 0; j < n; ++j) dir[j] += S[i][j] * (a[i] - be);
+      }
+      for (int j = 0; j < n; ++j) dir[j] = -dir[j];
       dg0 = dot(g, dir);
+      if (dg0 < 0) break;
+      if (hist == 0) return finish(3);   // -g is not a descent direction: nothing left to try
+      hist = 0;                          // ascent direction: drop the memory, restart from steepest descent
     }
-    // line search state (Nocedal & Wright alg. 3.5 / 3.6, c1 = 1e-4, c2 = 0.9)
-    t_lo = 0;
-    f_lo = f;
-    dg_lo = dg0;
-    t_hi = f_hi = 0;
-    have_hi = 0;
-    t_prev = 0;
-    f_prev = f;
-    ls = 0;
-    set_trial(iters == 0 ? amin(1.0, 1.0 / amax(gmax(g), 1e-300)) : 1.0);
+    const double dnorm = sqrt(dot(dir, dir));
+    const double t0 = iters == 0 ? amin(1.0 / dnorm, LB_STPMAX) : 1.0;
+    ls = 1;
+    mt.start(f, dg0, t0);
+    set_trial(t0);
   }
 
   CGP_HD void line_search_step() {
-    const double c1 = 1e-4, c2 = 0.9;
-    const double tt = t, fnv = fn;
-    const double dgn = isfin(fnv) ? dot(gn, dir) : 0.0;
-    bool ok = false, give_up = false;
-    if (!have_hi) {
-      if (fnv > f + c1 * tt * dg0 || (ls > 0 && fnv >= f_prev)) {
-        t_lo = t_prev;
-        f_lo = f_prev;
-        t_hi = tt;
-        f_hi = fnv;
-        have_hi = 1;
-      } else if (fabs(dgn) <= -c2 * dg0) {
-        ok = true;
-      } else if (dgn >= 0) {
-        t_hi = t_prev;
-        f_hi = f_prev;
-        t_lo = tt;
-        f_lo = fnv;
-        dg_lo = dgn;
-        have_hi = 1;
-      } else {
-        t_prev = tt;
-        f_prev = fnv;
-        dg_lo = dgn;
-        ++ls;
-        if (ls >= 30 || evals >= max_evals) give_up = true;
-        else return set_trial(2.0 * tt);
+    const double gd = dot(gn, dir);
+    double tt = t;
+    const int task = mt.step(fn, gd, tt);
+    if (task == 0) {
+      if (ls >= LB_MAXLS || evals >= max_evals) {   // the search failed: back to x, without memory if there was any
+        if (evals >= max_evals) return finish(2);
+        if (hist == 0) return finish(3);
+        hist = 0;
+        return start_iteration();
       }
-    } else {
-      if (fnv > f + c1 * tt * dg0 || fnv >= f_lo) {
-        t_hi = tt;
-        f_hi = fnv;
-      } else {
-        if (fabs(dgn) <= -c2 * dg0) ok = true;
-        else {
-          if (dgn * (t_hi - t_lo) >= 0) {
-            t_hi = t_lo;
-            f_hi = f_lo;
-          }
-          t_lo = tt;
-          f_lo = fnv;
-          dg_lo = dgn;
-        }
-      }
-    }
-    if (!ok && !give_up) {
       ++ls;
-      const double lo = amin(t_lo, t_hi), hi = amax(t_lo, t_hi);
-      if (ls >= 30 || evals >= max_evals || fabs(hi - lo) < 1e-16 * amax(1.0, fabs(lo))) give_up = true;
-      else {
-        const double dt = t_hi - t_lo;  // quadratic interpolation, safeguarded by bisection
-        double tq = t_lo - 0.5 * dg_lo * dt * dt / (f_hi - f_lo - dg_lo * dt);
-        if (!isfin(tq) || tq <= lo + 0.1 * (hi - lo) || tq >= hi - 0.1 * (hi - lo)) tq = 0.5 * (lo + hi);
-        return set_trial(tq);
-      }
-    }
-    if (!ok) {  // accept a sufficient-decrease point if the last trial is one, else stop
-      if (isfin(fnv) && fnv <= f + c1 * tt * dg0 && fnv < f) ok = true;
-      else return finish(evals >= max_evals ? 2 : 3);
+      return set_trial(tt);
     }
     // accept the step
     double *s = ws, *yv = wy;
@@ -193,9 +294,11 @@ struct LbfgsCore {
       x[j] = xn[j];
       g[j] = gn[j];
     }
-    f = fnv;
+    f = fn;
     ++iters;
-    if (sy > 1e-10 * dot(yv, yv)) {
+    if (gmax(g) <= pgtol) return finish(0);
+    if ((fold - f) <= ftol * amax(amax(fabs(fold), fabs(f)), 1.0)) return finish(1);
+    if (sy > LB_EPS * (-dg0 * t)) {
       if (hist == LB_M) {  // drop the oldest pair
         for (int i = 1; i < LB_M; ++i) {
           for (int j = 0; j < n; ++j) {
@@ -213,7 +316,6 @@ struct LbfgsCore {
       rho[hist] = 1.0 / sy;
       ++hist;
     }
-    if ((fold - f) <= ftol * amax(amax(fabs(fold), fabs(f)), 1.0)) return finish(1);
     start_iteration();
   }
 };

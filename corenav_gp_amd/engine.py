@@ -27,6 +27,7 @@ STREAM_CTX = ctypes.c_void_p(-1).value   # CGP_STREAM_CTX: the context's private
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
 _vp = ctypes.c_void_p
+OBJECTIVE_FN = ctypes.CFUNCTYPE(ctypes.c_double, _dp, _dp, ctypes.c_int, ctypes.c_void_p)   # cgp_objective_fn
 
 _SIGS = {
     "cgp_create": (_vp, [ctypes.c_int] * 6),
@@ -75,6 +76,8 @@ _SIGS = {
     "cgp_optimize_batch": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
                                           ctypes.c_int, ctypes.c_int, _dp, _ip]),
     "cgp_selftest_lbfgs": (ctypes.c_int, [_dp, ctypes.c_int, ctypes.c_int, _dp]),
+    "cgp_lbfgs_minimize": (ctypes.c_int, [_vp, _vp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                          _dp, _ip, _ip, _ip]),
     "cgp_recorder_create": (_vp, []),
     "cgp_recorder_destroy": (None, [_vp]),
     "cgp_recorder_update": (ctypes.c_int, [_vp, _dp, ctypes.c_double, ctypes.c_double, _dp, _dp, _dp, ctypes.c_int, _ip]),
@@ -106,6 +109,28 @@ def load():
             raise ImportError(f"{LIB_PATH} has ABI revision {lib.cgp_abi_version()}, this binding is for {ABI_VERSION}: rebuild it")
         _lib = lib
     return _lib
+
+
+def lbfgs_minimize(fg, x0, max_evals=1000, pgtol=1e-5, factr=1e7):
+    """cgp_lbfgs_minimize (host only): the engine's optimiser state machine on a Python objective fg(x) -> (f, grad).
+    Returns (x, f, n_evals, n_iters, status)."""
+    x = _d(x0).copy()
+    n = len(x)
+
+    def cb(xp, gp, nn, _user):
+        f, g = fg(np.array([xp[i] for i in range(nn)]))
+        for i in range(nn):
+            gp[i] = g[i]
+        return float(f)
+
+    fn = OBJECTIVE_FN(cb)
+    f = ctypes.c_double()
+    nev, nit, st = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    rc = load().cgp_lbfgs_minimize(ctypes.cast(fn, _vp), None, _p(x), n, max_evals, pgtol, factr, ctypes.byref(f),
+                                   ctypes.byref(nev), ctypes.byref(nit), ctypes.byref(st))
+    if rc != 0:
+        raise CgpError(rc)
+    return x, f.value, nev.value, nit.value, st.value
 
 
 class CgpError(RuntimeError):

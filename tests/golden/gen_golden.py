@@ -18,6 +18,11 @@ Sources of the expected values, per fixture `source` field:
               50-digit arithmetic (mpmath), kernel from its definition, LU with pivoting for the inverse and the
               determinant -- no Cholesky, no numpy, nothing of oracle/ -- posterior mean, variance, log marginal
               likelihood and its gradient wrt the four parameters
+              mp_lookahead.npz: the GpPredictor look-ahead loop and llh_to_enu (gp_predictor.cpp:64-99,144-178) in the same
+              50-digit arithmetic, from the C++ source, on the inputs of lookahead_restated.npz
+  restated+scipy -- the reference's `m.optimize()` (gp_slip_node.py:36): scipy.optimize.fmin_l_bfgs_b (the optimiser GPy
+              itself calls) on the restated objective from GPy's all-ones start; optimum, logML, evaluation count and the
+              published (mean[599], sigma[599]) at the optimum
   restated -- oracle/gp_oracle.py outputs (regression vectors for the GPy-only RBF x Brownian kernel
               and for the GpPredictor look-ahead; PARITY UNPINNED vs GPy itself)
 """
@@ -298,8 +303,116 @@ def restated_cases():
                         llh=np.array(go.INIT_LLH) + np.array([2e-6, 3e-6, 4.0]), enu=e)
 
 
+def mp_lookahead():
+    """mp_lookahead.npz: independent pin of the stop-time look-ahead (rows a10 / f3).  GpPredictor::GPCallBack's loop
+    (gp_predictor/src/gp_predictor.cpp:64-99) and llh_to_enu (:144-178) restated from the C++ source in 50-digit
+    arithmetic (mpmath: matrices of mpf, LU inverse of the 4 x 4 innovation covariance, mp trigonometry) on the inputs of
+    lookahead_restated.npz -- nothing of oracle/ is used for the expected values.  Stored: the xy_err trace of every
+    propagation step up to the 3.0 m threshold, and for a ladder of thresholds the step that crosses it, the odometry
+    index i and the stop command (:102-118)."""
+    import mpmath as mp
+    mp.mp.dps = 50
+    g = np.load(os.path.join(OUT, "lookahead_restated.npz"))
+    F = lambda v: mp.mpf(float(v))
+    M15 = lambda a: mp.matrix([[F(a[r * 15 + c]) for c in range(15)] for r in range(15)])
+    P, Q, STM = M15(g["PvecData"]), M15(g["QvecData"]), M15(g["STMvecData"])
+    H = mp.matrix(4, 15)
+    for r in range(4):                       # gp_predictor.cpp:38-42 (row1*4+col1: the reference's indexing)
+        for c in range(15):
+            H[r, c] = F(g["HvecData"][r * 4 + c])
+    pos = [F(v) for v in g["PosData"]]
+    mean, sigma = [F(v) for v in g["mean"]], [F(v) for v in g["sigma"]]
+    init_llh = [F(v) for v in go.INIT_LLH]    # core_navigation/config/init_params.yaml:9-16
+    init_ecef = [F(v) for v in go.INIT_ECEF]
+
+    def llh_to_enu(lat, lon, h):             # gp_predictor.cpp:144-178
+        a, b = mp.mpf("6378137.0000"), mp.mpf("6356752.3142")
+        e = mp.sqrt(1 - (b / a) ** 2)
+        sinphi, cosphi, coslam, sinlam = mp.sin(lat), mp.cos(lat), mp.cos(lon), mp.sin(lon)
+        tmp2 = 1 - e * e
+        tmpden = mp.sqrt(1 + tmp2 * mp.tan(lat) ** 2)
+        x1 = (a * coslam) / tmpden + h * coslam * cosphi
+        y1 = (a * sinlam) / tmpden + h * sinlam * cosphi
+        z1 = (a * tmp2 * sinphi) / mp.sqrt(1 - e * e * sinphi * sinphi) + h * sinphi
+        dx, dy, dz = x1 - init_ecef[0], y1 - init_ecef[1], z1 - init_ecef[2]
+        sP, cP, sL, cL = mp.sin(init_llh[0]), mp.cos(init_llh[0]), mp.sin(init_llh[1]), mp.cos(init_llh[1])
+        return (-sL * dx + cL * dy, -sP * cL * dx - sP * sL * dy + cP * dz, cP * cL * dx + cP * sL * dy + sP * dz)
+
+    R1 = mp.matrix([[0.5, 0.5, 0, 0], [1 / mp.mpf("0.685"), -1 / mp.mpf("0.685"), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    I15 = mp.eye(15)
+    e0 = llh_to_enu(*pos)
+    i, trace, istep = 0, [], []
+    for slip_i in range(5 * len(mean)):      # :64
+        P = STM * P * STM.T + Q              # :66
+        if slip_i % 5 == 0:                  # :67
+            o = [mp.mpf("0.8") / (1 - c) for c in (mean[i], mean[i] + sigma[i], mean[i] - sigma[i])]   # :69-75
+            est = (o[0] + o[1] + o[2]) / 3
+            cov = sum((v - est) ** 2 for v in o) / 3                                                  # :78
+            f03, f05 = mp.mpf("0.03") ** 2, mp.mpf("0.05") ** 2
+            R2 = mp.diag([max(f03, cov * cov), max(f03, cov * cov), max(f05, cov * cov), f05])         # :80-83
+            R = 25 * R1 * R2 * R1.T                                                                    # :88
+            K = P * H.T * mp.inverse(H * P * H.T + R)                                                  # :90
+            IKH = I15 - K * H
+            P = IKH * P * IKH.T + K * R * K.T                                                          # :91
+            i += 1
+        e3 = llh_to_enu(pos[0] + 3 * mp.sqrt(abs(P[6, 6])), pos[1] + 3 * mp.sqrt(abs(P[7, 7])), pos[2] + 3 * mp.sqrt(abs(P[8, 8])))
+        xy = mp.sqrt((e3[0] - e0[0]) ** 2 + (e3[1] - e0[1]) ** 2)                                      # :99
+        trace.append(xy)
+        istep.append(i)
+        if xy > 3:
+            break
+    trace_f = np.array([float(v) for v in trace])
+    thresholds = np.array([0.9, 1.25, 1.5, 2.0, 2.5, 2.75, 3.0])
+    cross = np.array([next(k for k, v in enumerate(trace) if v > mp.mpf(float(t))) for t in thresholds])
+    arrival, now = float(g["arrival_time"]), float(g["now"])
+    i_at = np.array([istep[k] for k in cross])
+    stop_cmd = np.array([arrival + ii / 10.0 - now if arrival + ii / 10.0 - now >= 0 else 0.5 for ii in i_at])   # :107-118
+    # the restatement against it, before anything is written
+    fired, cmd, io, xyo, otrace = go.predict_stop(g["mean"], g["sigma"], g["PvecData"], g["QvecData"], g["STMvecData"],
+                                                  go.unpack_H(g["HvecData"], True), g["PosData"], arrival, now, return_trace=True)
+    err = np.max(np.abs(otrace - trace_f) / trace_f)
+    print(f"mp_lookahead: {len(trace_f)} steps, crossings {cross.tolist()}, i {i_at.tolist()}; oracle trace vs 50-digit: {err:.2e}")
+    assert fired and io == i_at[-1] and len(otrace) == len(trace_f) and err < 1e-7
+    np.savez_compressed(os.path.join(OUT, "mp_lookahead.npz"), source="mpmath", mean=g["mean"], sigma=g["sigma"],
+                        PvecData=g["PvecData"], QvecData=g["QvecData"], STMvecData=g["STMvecData"], HvecData=g["HvecData"],
+                        PosData=g["PosData"], arrival_time=arrival, now=now, trace=trace_f, thresholds=thresholds,
+                        cross_step=cross, i_at=i_at, xy_at=trace_f[cross], stop_cmd=stop_cmd)
+
+
+def optimised_theta_cases():
+    """SURVEY 8c, last row: what the reference node publishes for a window WITH `m.optimize()` (gp_slip_node.py:31-36,
+    45-61): all four parameters start at 1.0 (GPy defaults), paramz 'lbfgsb' = scipy.optimize.fmin_l_bfgs_b on the
+    Logexp-transformed parameters (factr 1e7, pgtol 1e-5, maxfun 1000), then the 599 published ticks at the optimum.
+    Expected values: oracle.optimize (scipy's own L-BFGS-B driving the restated objective) -- source "restated+scipy";
+    the trajectory length (n_evals) is scipy's."""
+    raw = np.loadtxt(REF_CSV, delimiter=",")
+    windows = {"slipval_window_opt": (np.round(raw[:149, 0] * 10.0), raw[:149, 1]),
+               "synth_window_opt": synth.reference_window(149, tick0=11, seed=synth.SEED_BASE)}
+    for name, (t, s) in windows.items():
+        X, Y, xtr, ytr = go.slip_node_split(t, s)
+        th, lml, nev = go.optimize(go.KERNEL_RBF_BROWNIAN, xtr, ytr[:, 0])
+        mean, sigma = go.slip_node_callback(t, s, th)
+        f = go.fit(go.KERNEL_RBF_BROWNIAN, th, xtr, ytr[:, 0])
+        assert abs(f.logml - lml) <= 1e-9 * abs(lml)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), source="restated+scipy", kernel_id=2, theta0=np.ones(4),
+                            theta=th, logml=lml, n_evals=nev, time_array=t, slip_array=s, mean=mean, sigma=sigma)
+        print(f"{name}: theta {th}  logml {lml:.12g}  evaluations {nev}  M_out {len(mean)}")
+    # an SE-ARD window (d = 3) for the large-window machinery's optimiser (host L-BFGS over device gradients)
+    Xw, yw, Xs = synth.window(192, 3, 16, seed=4242)
+    th, lml, nev = go.optimize(go.KERNEL_SE_ARD, Xw, yw, np.ones(5))
+    f = go.fit(go.KERNEL_SE_ARD, th, Xw, yw)
+    mu, var = go.predict(f, Xs)
+    np.savez_compressed(os.path.join(OUT, "synth_se_ard_n192_d3_opt.npz"), source="restated+scipy", kernel_id=1,
+                        theta0=np.ones(5), theta=th, logml=lml, n_evals=nev, X=Xw, y=yw, Xs=Xs, mean=mu, var=var)
+    print(f"synth_se_ard_n192_d3_opt: theta {th}  logml {lml:.12g}  evaluations {nev}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-opt" in sys.argv:
+        return optimised_theta_cases()
+    if "--only-mp-lookahead" in sys.argv:
+        return mp_lookahead()
     closed_forms()
     # cfg1-like (N=256,d=3 SE-iso) and smaller ARD cases, all against scikit-learn
     kid, X, y, Xs, th, _ = synth.config(1, M=64)
@@ -317,6 +430,9 @@ def main():
         mp_rbfbrownian()
     slipval_window()
     restated_cases()
+    if "--no-mp" not in sys.argv:
+        mp_lookahead()
+    optimised_theta_cases()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", tot)
 

@@ -48,3 +48,21 @@ def test_batched_lookahead_large_ensemble_consistent():
     for k in (0, 7, 123, 299):
         hf, hc, hi, hxy = e.predict_stop(means[k], sigmas[k], P[k], Q[k], STM[k], Hv[k], pos[k], 10.0, 10.0)
         assert bool(fired[k]) == hf and iout[k] == hi and cmd[k] == pytest.approx(hc, rel=1e-12)
+
+
+def test_batched_lookahead_against_the_50_digit_pin():
+    """Row f3 pinned independently of oracle/ (tests/golden/mp_lookahead.npz, 50-digit restatement of
+    gp_predictor.cpp:64-99,144-178): one trajectory per threshold of the ladder, so the device loop's early exit is
+    sampled along the whole xy_err trace."""
+    import corenav_gp_amd.engine as e
+    g = load_golden("mp_lookahead")
+    ctx = e.Context(max_n=8, max_m=8, max_d=1)
+    for th, i_at, xy_at, cmd_at in zip(g["thresholds"], g["i_at"], g["xy_at"], g["stop_cmd"]):
+        T = 3
+        tile = lambda a: np.tile(np.asarray(a, dtype=np.float64).reshape(1, -1), (T, 1))
+        fired, cmd, iout, xy = ctx.predict_stop_batch(tile(g["mean"]), tile(g["sigma"]), tile(g["PvecData"]), tile(g["QvecData"]),
+                                                      tile(g["STMvecData"]), tile(g["HvecData"]), tile(g["PosData"]),
+                                                      float(g["arrival_time"]), float(g["now"]), threshold=float(th))
+        assert fired.all() and (iout == int(i_at)).all()
+        np.testing.assert_allclose(xy, float(xy_at), rtol=1e-6)
+        np.testing.assert_allclose(cmd, float(cmd_at), rtol=1e-12)

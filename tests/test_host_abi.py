@@ -67,6 +67,20 @@ def test_predict_stop_matches_oracle(bug):
         assert got[2] == int(g["i"]) and got[1] == pytest.approx(float(g["stop_cmd"]), rel=1e-12)
 
 
+def test_predict_stop_against_the_50_digit_pin():
+    """Rows a10 / a11 pinned independently of oracle/: tests/golden/mp_lookahead.npz is the reference's loop
+    (gp_predictor.cpp:64-99) and llh_to_enu (:144-178) restated from the C++ source in 50-digit arithmetic.  A ladder of
+    thresholds samples the xy_err trace: the step that crosses each, the odometry index i, the published stop command
+    (:107-118) and the error at the crossing must be the pin's."""
+    g = load_golden("mp_lookahead")
+    for th, i_at, xy_at, cmd_at in zip(g["thresholds"], g["i_at"], g["xy_at"], g["stop_cmd"]):
+        fired, cmd, i, xy = engine.predict_stop(g["mean"], g["sigma"], g["PvecData"], g["QvecData"], g["STMvecData"],
+                                                g["HvecData"], g["PosData"], float(g["arrival_time"]), float(g["now"]),
+                                                threshold=float(th))
+        assert fired and i == int(i_at)
+        assert xy == pytest.approx(float(xy_at), rel=1e-6) and cmd == pytest.approx(float(cmd_at), rel=1e-12)
+
+
 def test_predict_stop_edge_cases():
     g = load_golden("lookahead_restated")
     args = (g["PvecData"], g["QvecData"], g["STMvecData"], g["HvecData"], g["PosData"])

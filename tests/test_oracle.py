@@ -176,6 +176,24 @@ def test_lookahead_golden():
     assert fired and cmd == 0.5
 
 
+def test_lookahead_oracle_against_the_50_digit_pin():
+    """The restatement of GpPredictor::GPCallBack's loop pinned independently: mp_lookahead.npz is the C++ source
+    (gp_predictor.cpp:64-99,144-178) restated in 50-digit arithmetic; the whole xy_err trace up to the 3.0 m threshold,
+    the crossing step, i and the stop command must agree (fp64 loses ~1e-9 in the ECEF difference)."""
+    g = load_golden("mp_lookahead")
+    H = go.unpack_H(g["HvecData"], True)
+    fired, cmd, i, xy, trace = go.predict_stop(g["mean"], g["sigma"], g["PvecData"], g["QvecData"], g["STMvecData"], H,
+                                               g["PosData"], float(g["arrival_time"]), float(g["now"]), return_trace=True)
+    assert fired and len(trace) == len(g["trace"]) and i == int(g["i_at"][-1])
+    np.testing.assert_allclose(trace, g["trace"], rtol=1e-7)
+    assert cmd == pytest.approx(float(g["stop_cmd"][-1]), rel=1e-12)
+    for th, step, i_at in zip(g["thresholds"], g["cross_step"], g["i_at"]):
+        f2, c2, i2, xy2, tr2 = go.predict_stop(g["mean"], g["sigma"], g["PvecData"], g["QvecData"], g["STMvecData"], H,
+                                               g["PosData"], float(g["arrival_time"]), float(g["now"]), threshold=float(th),
+                                               return_trace=True)
+        assert f2 and len(tr2) == int(step) + 1 and i2 == int(i_at)
+
+
 def test_llh_to_enu():
     g = load_golden("llh_to_enu_restated")
     np.testing.assert_allclose(go.llh_to_enu(*g["llh"]), g["enu"], rtol=1e-12, atol=1e-9)
