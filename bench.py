@@ -54,7 +54,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=0, help="fits timed on the host for cpu_baseline (0 = by time budget)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip config.extra (cfg3 / window / look-ahead / end-to-end lines)")
-    ap.add_argument("--streams", type=int, default=1, help="worker streams the batch is spread over")
+    ap.add_argument("--streams", type=int, default=0, help="cgp_set_streams: 0 = the engine decides (default), 1 = one group, n = n groups")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="contexts (slab sets) the steps are dealt over, one HIP stream each, so that successive calls too small "
@@ -347,7 +347,7 @@ def cfg3_strong_line(args, dry, world, rank, local, dev, cdev, use_dist, sync, t
     else:
         import corenav_gp_amd.engine as engine
         kid, X, y, Xs, th, dts = synth.config(3, batch=B, M=M_TEST, first=b0)
-        W3 = Workload(engine, torch, dev, local, kid, X, y, Xs, th, dts, 2 if 56 <= B <= 96 else 1)   # a mid-size shard: two stream groups inside the call
+        W3 = Workload(engine, torch, dev, local, kid, X, y, Xs, th, dts, 0)   # engine defaults: a 56 ... 96-fit shard is cut into two stream groups
         step = W3.step
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.1:   # working clock
@@ -370,7 +370,7 @@ def cfg3_strong_line(args, dry, world, rank, local, dev, cdev, use_dist, sync, t
         assert int(W3.dinfo.abs().sum().item()) == 0
     el = float(dt.item()) / steps
     return {"fits_per_s": total / el, "ms_per_step": el * 1e3, "fits_per_step_all_ranks": total, "fits_per_gpu_per_call": total / world,
-            "n_gpus": world, "scaling": "strong", "pipeline_depth": 1, "streams": 2 if 56 <= B <= 96 else 1, "steps": steps,
+            "n_gpus": world, "scaling": "strong", "pipeline_depth": 1, "streams": "engine default", "steps": steps,
             "workload": f"BASELINE configs[2] as written: {total} x N=1024 d=6 SE-ARD fp32, M={M_TEST}, sharded over {world} ranks, "
                         "one context per GPU; divide by config.extra.cfg3_fits_per_s of the --gpus 1 line for the speed-up"}
 
@@ -582,6 +582,10 @@ def extras(engine, torch, dev, local, W):
         ex.update(node_line(engine, local))
     except Exception as e:
         ex["node_error"] = repr(e)
+    try:
+        ex.update(replay_line(engine, local))
+    except Exception as e:
+        ex["replay_error"] = repr(e)
     return ex
 
 
@@ -618,7 +622,7 @@ def extras_cfg3(engine, torch, dev, local, W):
             # configs[2] AS WRITTEN shards the 512 fits over 8 GPUs: 64 fits per GPU and call.  The same engine on the
             # first 64 windows (its mid-size schedule), and what 8 such GPUs would make of the 1-GPU rate above -- a
             # projection from this GPU's two rates (no collective on the data path), not a measurement of 8 GPUs.
-            W64 = Workload(engine, torch, dev, local, kid, X[:64], y[:64], Xs[:64], th[:64], dts, 1)
+            W64 = Workload(engine, torch, dev, local, kid, X[:64], y[:64], Xs[:64], th[:64], dts, 0)   # default settings: the engine picks the stream groups
             tw = time.perf_counter()
             while time.perf_counter() - tw < 0.1:
                 W64.step()
@@ -632,10 +636,11 @@ def extras_cfg3(engine, torch, dev, local, W):
             ex["cfg3_fits_per_s_at_64"] = 64 / el64
             ex["cfg3_ms_per_call_at_64"] = el64 * 1e3
             ex["cfg3_strong_scaling_projection_8gpu"] = 8 * (64 / el64) / (512 / el)
-            ex["cfg3_strong_scaling_note"] = ("8 x (64-fit call rate) / (512-fit call rate) on this one GPU; measure it with "
+            ex["cfg3_strong_scaling_note"] = ("8 x (64-fit call rate) / (512-fit call rate) on this one GPU, ONE context, default settings (the engine "
+                                              "cuts a 56 ... 96-fit fp32 call into two stream groups by itself since round 5); measure it with "
                                               "`bench.py --scaling strong --config 3 --gpus 8`")
-            # ONE context, the call cut into two stream groups of 32 fits (cgp_set_streams(2)): still the speed-up of one sweep
-            W64.ctx.set_streams(2)
+            # the same call forced into ONE group (cgp_set_streams(1)): what every round before 5 reported under this key
+            W64.ctx.set_streams(1)
             for _ in range(10):
                 W64.step()
             torch.cuda.synchronize()
@@ -644,11 +649,13 @@ def extras_cfg3(engine, torch, dev, local, W):
                 W64.step()
             torch.cuda.synchronize()
             el64g = (time.perf_counter() - t0) / 20
-            W64.ctx.set_streams(1)
+            W64.ctx.set_streams(0)
             assert int(W64.dinfo.abs().sum().item()) == 0
-            ex["cfg3_ms_per_call_at_64_streams2"] = el64g * 1e3
-            ex["cfg3_fits_per_s_at_64_streams2"] = 64 / el64g
-            ex["cfg3_strong_scaling_projection_8gpu_streams2"] = 8 * (64 / el64g) / (512 / el)
+            ex["cfg3_ms_per_call_at_64_one_group"] = el64g * 1e3
+            try:
+                ex["cgp_sweep"] = sweep_line(engine, torch, dev, local, W64, kid, el64)
+            except Exception as e:
+                ex["cgp_sweep_error"] = repr(e)
             # the same 64-fit calls dealt over TWO contexts on two HIP streams (--pipeline 2):
             # successive calls overlap, the chain-bound early block steps of one beside the MFMA-bound late ones of the other
             W64b = Workload(engine, torch, dev, local, kid, X[:64], y[:64], Xs[:64], th[:64], dts, 1)
@@ -678,6 +685,88 @@ def extras_cfg3(engine, torch, dev, local, W):
     except Exception as e:
         ex["cfg3_error"] = repr(e)
     return ex
+
+
+def sweep_line(engine, torch, dev, local, W64, kid, el_ctx):
+    """The C-ABI multi-device entry (cgp_sweep_fit_predict_device: what a C++ ROS host calls; per-shard device pointers, work
+    enqueued by persistent per-device worker threads, no copy and no synchronisation inside the call) on the 64-fit
+    configs[2] shard, next to the plain context's figure: devices = [local] (must be the same call), [local, local] (two
+    contexts of 32 fits on one GPU: the one-GPU stand-in of two devices), and -- when this process sees more than one
+    GPU -- ALL visible devices from this ONE process, 64 fits each."""
+    def timed(sw, B, ptrs, reps=20):
+        def sync():
+            sw.synchronize()                    # the contexts' own streams
+            for i in range(torch.cuda.device_count()):
+                torch.cuda.synchronize(i)       # ... and whatever stream the caller passed
+        for _ in range(24):                     # back to back, as the timed calls: the engine settles its stream groups on this pattern
+            sw.fit_predict_device(B, W64.N, W64.d, M_TEST, kid, *ptrs)
+        sync()
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < 0.1:   # creating the sweep's contexts let the part idle: back to its working clock first
+            for _ in range(4):
+                sw.fit_predict_device(B, W64.N, W64.d, M_TEST, kid, *ptrs)
+            sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sw.fit_predict_device(B, W64.N, W64.d, M_TEST, kid, *ptrs)
+        sync()
+        return (time.perf_counter() - t0) / reps
+    dtype = engine.F64 if W64.dts == "f64" else engine.F32
+    out = {"workload": "64 x N=1024 d=6 fp32 (BASELINE configs[2], one GPU's shard), device-resident, cgp_sweep_fit_predict_device",
+           "context_ms_per_call": el_ctx * 1e3}
+    whole = ([W64.dX.data_ptr()], [W64.dy.data_ptr()], [W64.dXs.data_ptr()], [W64.dth.data_ptr()], None, True,
+             [W64.dmean.data_ptr()], [W64.dvar.data_ptr()], [W64.dlogml.data_ptr()], [W64.dinfo.data_ptr()])
+    sw = engine.Sweep([local], W64.N, M_TEST, W64.d, 64, dtype)
+    el1 = timed(sw, 64, (*whole, [W64.stream]))     # on the stream the context's figure was measured on
+    out["devices_1_ms_per_call"] = el1 * 1e3
+    out["devices_1_over_context"] = el1 / el_ctx
+    el1o = timed(sw, 64, whole)                     # hip_streams = NULL: the sweep's contexts' own streams
+    out["devices_1_own_stream_ms_per_call"] = el1o * 1e3
+    out["stream_note"] = ("whether the two stream groups of a 56 ... 96-fit fp32 call overlap depends on the runtime's stream -> hardware-queue "
+                          "mapping (process history); the engine times both forms per caller stream and keeps the faster, so a stream "
+                          "on which they cannot overlap runs the call as one group (cfg3_ms_per_call_at_64_one_group)")
+    sw.close()
+    h = 32
+    halves = tuple([t[:h].data_ptr(), t[h:].data_ptr()] for t in (W64.dX, W64.dy, W64.dXs, W64.dth))
+    outs = tuple([t[:h].data_ptr(), t[h:].data_ptr()] for t in (W64.dmean, W64.dvar, W64.dlogml, W64.dinfo))
+    sw = engine.Sweep([local, local], W64.N, M_TEST, W64.d, 64, dtype)
+    el2 = timed(sw, 64, (*halves, None, True, *outs))
+    out["devices_same_gpu_twice_ms_per_call"] = el2 * 1e3
+    sw.close()
+    assert int(W64.dinfo.abs().sum().item()) == 0
+    ndev = torch.cuda.device_count()
+    if ndev > 1:   # one process, every visible GPU: 64 fits per device (weak), inputs replicated device by device
+        bufs = []
+        for i in range(ndev):
+            di = torch.device("cuda", i)
+            bufs.append({k: getattr(W64, k).to(di) for k in ("dX", "dy", "dXs", "dth", "dmean", "dvar", "dlogml", "dinfo")})
+        for i in range(ndev):
+            torch.cuda.synchronize(i)
+        ptr = lambda k: [b[k].data_ptr() for b in bufs]
+        sw = engine.Sweep(list(range(ndev)), W64.N, M_TEST, W64.d, 64 * ndev, dtype)
+        eln = timed(sw, 64 * ndev, (ptr("dX"), ptr("dy"), ptr("dXs"), ptr("dth"), None, True, ptr("dmean"), ptr("dvar"), ptr("dlogml"), ptr("dinfo")))
+        out["all_visible_devices"] = {"devices": ndev, "fits_per_call": 64 * ndev, "ms_per_call": eln * 1e3,
+                                      "fits_per_s": 64 * ndev / eln, "speedup_over_one_device": (64 * ndev / eln) / (64 / el1)}
+        assert all(int(b["dinfo"].abs().sum().item()) == 0 for b in bufs)
+        sw.close()
+        torch.cuda.set_device(local)
+    return out
+
+
+def replay_line(engine, local, n_traj=64, ticks=600):
+    """The closed loop of BASELINE configs[4]'s stand-in (corenav_gp_amd/replay.py: synthetic rover -> recorder -> GP engine ->
+    batched look-ahead -> stop command -> zero updates -> next SetStopping answer) for a 64-trajectory Monte-Carlo
+    ensemble on one GPU: wall-clock per simulated second and windows fitted."""
+    from corenav_gp_amd import replay
+    ens = replay.ClosedLoopEnsemble(n_traj=n_traj, device=local)
+    t0 = time.perf_counter()
+    npub = ens.run(ticks)
+    el = time.perf_counter() - t0
+    return {"replay": {"trajectories": n_traj, "ticks": ticks, "simulated_s": ticks * replay.DT_ODO, "wall_s": el,
+                       "windows_fitted": int(npub), "stops": int(sum(t.stops for t in ens.traj)),
+                       "trajectory_seconds_per_wall_second": n_traj * ticks * replay.DT_ODO / el,
+                       "note": "host-side rover / recorder / covariance model in Python dominates the wall clock; the GPU work is "
+                               "one batched fit + predict and one batched look-ahead per published tick"}}
 
 
 def window_line(engine, torch, dev, local, W=1024, N=512, d=3, T=200):

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -57,8 +58,18 @@ struct cgp_ctx {
   hipStream_t wstream[kMaxStreams] = {nullptr};
   hipStream_t hstream = nullptr;   // highest stream priority: for a latency chain that must be dispatched AHEAD of bulk work on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr};
+  // Two stream groups or one for an fp32 call of 56 ... 96 fits?  Decided per caller stream by timing one call each way (run_schedule).
+  struct GroupTune {
+    hipStream_t stream = nullptr;
+    int state = -1;            // -1 free, else eligible calls seen on this stream so far (kTuneDecide and beyond: decided)
+    int groups = 2;
+    float ms[2] = {0.f, 0.f};
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned long long used = 0;
+  } tune[4];
+  unsigned long long tune_clock = 0;
   hipEvent_t ev_look[3 * 64] = {nullptr};  // look-ahead schedule: diag / P1 / P2 completion per step
-  int nstreams = 1;   // cgp_set_streams: worker streams a LARGE batch is cut over (measured: no gain since the diagonal tiles ride in the panel launches)
+  int nstreams = 0;   // cgp_set_streams: 0 = the engine decides (two groups for fp32 calls of 56 ... 96 fits, else one); n >= 1 = as told
   // device buffers
   void *Lw = nullptr, *Winv = nullptr, *dX = nullptr, *dXs = nullptr, *dy = nullptr;
   void *dmean = nullptr, *dvar = nullptr, *dalpha = nullptr;
@@ -223,12 +234,19 @@ constexpr size_t kOptPinIn = CGP_MAX_THETA + 8;   // doubles at the head of the 
 #define CGP_WIN_PAIRS 1   // sliding window: steady-state ticks two per pass over the factor (`make variant`: 0 = every tick on its own)
 #endif
 constexpr bool kWinPairs = CGP_WIN_PAIRS != 0;
+constexpr size_t kWinZeroCopyBytes = 16 * 1024;   // cgp_window_push blocks up to this size are read / written in pinned host memory by the kernels
 constexpr int kWinPackLds = 72 * 1024;       // pack windows into a workgroup only while two workgroups still fit a CU's LDS ...
 constexpr int kWinPackMinGroups = 512;       // ... and the chip still gets two workgroups per CU
 // fp64 mid-size calls put their extra rows on a second stream when there is enough of them: fits x block steps >= this
 // (tools/r3_xs_n.sh, same box, with / without, ms per call: N = 2048 28 fits 3.77 / 3.70, 36 fits 4.25 / 4.45, 48 fits 5.01 / 5.70;
 // N = 1536 36 fits 2.37 / 2.38, 48 fits 2.71 / 3.01; N = 1024 36 fits 1.27 / 1.17, 48 fits 1.29 / 1.31; N = 512 28 fits 0.52 / 0.42)
 constexpr int XSPLIT64_WORK = 480;
+#ifndef CGP_XSPLIT32_FITS
+#define CGP_XSPLIT32_FITS 0    // fp32 mid-size calls from this many fits: extra rows on the second stream as 64-row tiles (k_rows64); 0 = never.
+                               // Measured (round 5, ms per call without / with): 24 fits 0.629 / 0.647, 32 0.686 / 0.777, 48 0.770 / 0.791, 64 0.994 / 0.954,
+                               // 96 1.282 / 1.270 -- bitwise the one-stream results, but two stream GROUPS (0.895 at 64 fits) beat it: not taken
+#endif
+constexpr int XSPLIT32_FITS = CGP_XSPLIT32_FITS;
 constexpr int MID_FITS_ALLOC = kAbBuild ? 512 : (MID_FITS_F64 > MID_FITS_F32 ? MID_FITS_F64 : MID_FITS_F32);
 // fp64 by window length (tools/r3_mid_n2.sh, end of round 3, with the extra-row split by work; mid-size form off / on, ms per call):
 // N = 2048 64 fits 7.26 / 6.87, 96 fits 9.80 / 9.67; N = 1536 96 fits 5.14 / 4.95; N = 1024 96 fits 2.22 / 2.10; N = 768 64 fits 1.06 /
@@ -258,6 +276,9 @@ template <typename T> constexpr int paneldiag_lds_bytes() { return std::max(pane
 template <typename T> constexpr int paneldiag_mid_lds_bytes() {
   return mid_fat<T, true>() ? std::max(paneldiag_lds_bytes<T>(), potf2_lds_elems<T>() * (int)sizeof(T)) : paneldiag_lds_bytes<T>();
 }
+// the deep loop's chunk ring + z of one block column must fit what the mid-size build's launches carry
+static_assert(deep_ring<float, true>() * KT * LDST * 4 + TS * 4 <= paneldiag_mid_lds_bytes<float>() &&
+              deep_ring<double, true>() * KT * LDST * 8 + TS * 8 <= paneldiag_mid_lds_bytes<double>(), "mid-size build: ring does not fit its LDS");
 template <typename T> constexpr int potf2_lds_bytes() {
   return (TS * LDP + 8 * DB * DB + 4 * DB * DB) * (int)sizeof(T) + 16;
 }
@@ -267,8 +288,11 @@ template <typename T> constexpr int potf2_lds_bytes() {
 #endif
 // hipFuncSetAttribute applies to the CURRENT device's function object: called from cgp_create after
 // hipSetDevice, once per (device, dtype).
+// (two contexts may be created from two threads at once: the per-device "done" marks are guarded by a mutex)
+std::mutex g_attr_mutex;
 template <typename T> int set_lds_attrs(int device) {
   static bool done[64] = {false};
+  std::lock_guard<std::mutex> lk(g_attr_mutex);
   if (device >= 0 && device < 64 && done[device]) return 0;
   const int upd = upd_lds_bytes<T>(), tile = potf2_lds_bytes<T>();
   auto set = [](const void *fn, int bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; };
@@ -305,6 +329,7 @@ template <typename F> int for_each_small_kernel(F &&f) {
 inline size_t small_predict_lds(int NB, int d) { return ((small_lds_bytes(NB, d) + 15) & ~(size_t)15) + small_predict_lds_extra(NB, d); }
 int set_small_attr(int device) {
   static bool done[64] = {false};
+  std::lock_guard<std::mutex> lk(g_attr_mutex);
   if (device >= 0 && device < 64 && done[device]) return 0;
   const int rc = for_each_small_kernel([](const void *fn) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerWorkgroup) == hipSuccess ? 0 : -1;
@@ -518,11 +543,14 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   a.rows_from_extra = in_rows ? 0 : 1;
   const int upd_lds = upd_lds_bytes<T>();
   const int tile_lds = potf2_lds_bytes<T>();
-  int G = std::max(1, std::min(std::min(c->nstreams, (int)cgp_ctx::kMaxStreams), batch));
-  if (c->prof || !in_rows) G = 1;  // per-kernel timing wants isolated launches
+  const bool auto_groups = c->nstreams == 0;
+  int G = auto_groups ? 1 : std::max(1, std::min(std::min(c->nstreams, (int)cgp_ctx::kMaxStreams), batch));
   // latency schedule: a handful of fits, windows long enough for splitting to pay and short enough for the
   // diagonal tile's pre-update images (N <= 2560); anything else takes the throughput schedule
-  const bool latency = !sw.no_latency && batch <= std::min(lat_fits<T>(a.NT), c->lat_cap) && a.NT >= CGP_LAT_MIN_NT && lat_images(a.NT - 1) <= LAT_IMG_MAX;
+  // (the slab / image capacities are part of the predicate: a call they cannot hold -- only reachable with the measurement
+  // build's CGP_LAT_FITS override -- takes the mid-size or throughput schedule instead of failing after k_prep was queued)
+  const bool latency = !sw.no_latency && batch <= std::min(lat_fits<T>(a.NT), c->lat_cap) && a.NT >= CGP_LAT_MIN_NT && lat_images(a.NT - 1) <= LAT_IMG_MAX &&
+                       (size_t)batch * (a.NT + a.ET + 1) <= c->lat_units && (a.NT < 3 || batch <= c->lat_img_fits);
   const bool mid = batch <= std::min(mid_fits<T>(a.NT), c->mid_cap);  // the whole call (the images are indexed by fit)
   // A latency-schedule call is one chain; an fp64 mid-size call has its own concurrency (factorisation || extra rows, below).
   // An fp32 mid-size call honours cgp_set_streams: cut into groups on worker streams, the chain-bound early launches of
@@ -530,8 +558,87 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // above the latency schedule's range (a group that small would switch schedule: four groups of 16 measured 1.50 ms).
   // Two groups, from 56 fits (measured, ms per call at 1 / 2 / 3 groups: 48 fits 0.77 / 0.83 / 0.83, 64 fits 0.99 / 0.92 / 1.48,
   // 96 fits 1.24 / 1.17 / 1.66).
+  // Since round 5 the engine takes that split by itself (cgp_set_streams(0), the default): every caller of a 56 ... 96-fit fp32
+  // call -- cgp_sweep_*, a plain C host -- gets the 0.90 ms, not only a caller that knew to ask; cgp_set_streams(1) keeps one group.
   if (latency || (mid && sizeof(T) == 8)) G = 1;
-  if (mid && G > 1) G = batch >= 56 && batch / 2 > lat_fits<T>(a.NT) ? 2 : 1;
+  cgp_ctx::GroupTune *tune = nullptr;   // non-null: this call belongs to the tuning runs
+  hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;   // events to record on the caller's stream before / after this call
+  if (mid && sizeof(T) == 4 && (G > 1 || auto_groups)) {
+    G = batch >= 56 && batch / 2 > lat_fits<T>(a.NT) ? 2 : 1;
+    // Whether the two groups really run side by side depends on how the runtime mapped the caller's stream and the worker
+    // stream onto its few hardware queues -- the process's history, which nothing reports: the same 64-fit call took 0.89 ms
+    // on the legacy stream and 1.28 ms (the two groups in order: worse than one group's 0.98) on a fresh torch stream or on a
+    // context created later in the process (tools/sweep_probe.py, stream_probe.py; a probe with spin kernels did not predict
+    // it, both groups on the context's own streams was no better, and a single timed call does not show it: it is a
+    // steady-state effect of calls issued back to back).  So the default does not assume: per caller stream, after two
+    // warm-up calls, four eligible calls run as two groups and four as one, each run bracketed by events on the caller's
+    // stream, and from then on the faster form is used.  Results are bitwise the same either way.
+    // Every kRetune calls the two runs are repeated (a caller that first synchronises after every call and later issues calls
+    // back to back sees the other behaviour: sweep_probe.py's 1.24 ms): 8 calls in 264, half of them at the slower setting.
+    constexpr int kWarm = 2, kRun = 4, kTuneDecide = kWarm + 2 * kRun, kRetune = 256;
+    if (G == 2 && auto_groups && in_rows && !c->prof) {
+      cgp_ctx::GroupTune *t = nullptr, *lru = &c->tune[0];
+      for (auto &e : c->tune) {
+        if (e.state >= 0 && e.stream == s) t = &e;
+        if (e.used < lru->used) lru = &e;
+      }
+      if (!t) {
+        t = lru;
+        t->stream = s;
+        t->state = 0;
+        t->groups = 2;
+        for (auto &e : t->e)
+          if (!e && hipEventCreate(&e) != hipSuccess) t->state = kTuneDecide + 1;   // no events: keep the two groups
+      }
+      t->used = ++c->tune_clock;
+      if (t->state > kTuneDecide + kRetune) t->state = kWarm;
+      if (t->state == kTuneDecide) {
+        float m2 = 0.f, m1 = 0.f;
+        if (hipEventSynchronize(t->e[3]) == hipSuccess && hipEventElapsedTime(&m2, t->e[0], t->e[1]) == hipSuccess &&
+            hipEventElapsedTime(&m1, t->e[2], t->e[3]) == hipSuccess) {
+          t->ms[0] = m2;
+          t->ms[1] = m1;
+          t->groups = m2 <= m1 ? 2 : 1;
+        }
+        ++t->state;
+      }
+      if (t->state > kTuneDecide) {
+        G = t->groups;
+        ++t->state;
+      } else {
+        G = t->state < kWarm + kRun ? 2 : 1;
+        tune = t;
+        if (t->state == kWarm) tune_ev0 = t->e[0];
+        if (t->state == kWarm + kRun - 1) tune_ev1 = t->e[1];
+        if (t->state == kWarm + kRun) tune_ev0 = t->e[2];
+        if (t->state == kTuneDecide - 1) tune_ev1 = t->e[3];
+      }
+    }
+  }
+  if (c->prof || !in_rows) G = 1;  // per-kernel timing wants isolated launches
+  if (tune_ev0) HIP_TRY(c, hipEventRecord(tune_ev0, s));
+  const bool fused64 = sw.fused_diag || batch < FUSED64_BELOW;
+  const bool split_diag = sw.split_diag || !in_rows || (sizeof(T) == 8 && !fused64);
+  // Mid-size calls: the extra rows (test points and y: M + 1 of them against N - 128 (k + 1) matrix rows, i.e. most of
+  // the update work) do not feed the factorisation, only their own next block column.  They get launches of their own on
+  // a second stream -- E(k), after the launch that finished diagonal tile k -- so the chain-bound factorisation launches
+  // A(k) (few workgroups, long chains) run beside the MFMA-bound extra-row launches instead of in lock-step with them:
+  //     s :  diag(0)  A(0)  A(1)  A(2) ...            A(k): matrix tiles of step k + kinds A / B / C
+  //     sE:           E(0)  E(1)  E(2) ...            E(k) waits for A(k - 1) (W_k, row panel k) and follows E(k - 1)
+  // Measured (tools/r3_xsplit.sh, same box, variant without the split): fp64 N = 2048 48 fits 5.58 -> 4.99 ms, 32 fits 4.03 ->
+  // 3.92, 24 fits 3.48 -> 3.51, 12 fits 2.62 -> 3.45 (the call is one chain then: nothing to run beside it); fp32 N = 1024
+  // 64 fits 0.99 -> 1.01, 32 fits 0.69 -> 0.76: its launches last as long as kind A's chain at every k, so the extra rows'
+  // last launches only queue up behind it, and two contexts overlap worse (0.76 -> 0.96 ms per call).  fp64 from 28 fits.
+  // (not under cgp_profile_enable: per-launch events of two concurrent streams would overlap in time and their sum overstate the kernel)
+  // fp32: the extra rows go to the second stream as 64-row tiles (k_rows64) from XSPLIT32_FITS fits per call
+  int x32 = XSPLIT32_FITS;
+  if constexpr (kAbBuild) {   // measurement: CGP_XSPLIT32=<min fits> moves the threshold (0: never)
+    static const int x32env = [] { const char *e = getenv("CGP_XSPLIT32"); return e ? atoi(e) : -1; }();
+    if (x32env >= 0) x32 = x32env;
+  }
+  const bool xsplit_on = sizeof(T) == 8 ? batch * a.NT >= XSPLIT64_WORK : (x32 > 0 && batch >= x32);
+  const bool xsplit = mid && !latency && xsplit_on && in_rows && !split_diag && G == 1 && a.ET > 0 && !kNoExtraSplit && !c->prof;
+  constexpr bool own_main = false;   // (both halves of a concurrent call on the context's own streams: measured worse, docs/negatives.md round 5)
   std::vector<FitArgs> ga(G);
   std::vector<int> gb(G);
   std::vector<hipStream_t> gs(G);
@@ -551,21 +658,22 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   }
   hipLaunchKernelGGL(k_prep, dim3(cdiv(batch, 64)), dim3(64), 0, s, a, batch, c->dprep, in_rows ? 1 : 0,
                      (latency && in_rows) ? c->dwready : nullptr);
-  if (G > 1) {
+  if (G > 1 || own_main) {
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-    for (int g = 1; g < G; ++g) HIP_TRY(c, hipStreamWaitEvent(gs[g], c->ev_fork, 0));
+    for (int g = 0; g < G; ++g)
+      if (gs[g] != s) HIP_TRY(c, hipStreamWaitEvent(gs[g], c->ev_fork, 0));
   }
   std::vector<Launcher> L;
   for (int g = 0; g < G; ++g) L.push_back(Launcher{c, gs[g]});
   // throughput schedule: the predictive sums V z and |V|^2 accumulate inside k_panel (block column
   // k - 1 while it streams through the row fragments of step k); k_finalize then only adds the last
   // block column instead of reading all of V.
-  const bool use_acc = !latency && !sw.acc_off && a.M > 0 && !a.xid;
+  // (No memset of the sums: block step 1 -- the first that has a finished block column behind it -- WRITES them, later steps add;
+  // the two fill launches were 10 us at the head of every call.  A window of one block step has nothing to accumulate.)
+  const bool use_acc = !latency && !sw.acc_off && a.M > 0 && !a.xid && a.NT >= 2;
   if (use_acc) {
     const size_t half = (size_t)batch * a.M;
     for (int g = 0, g0 = 0; g < G; g0 += gb[g], ++g) {
-      HIP_TRY(c, hipMemsetAsync(c->dmacc + (size_t)g0 * a.M, 0, sizeof(double) * gb[g] * a.M, gs[g]));
-      HIP_TRY(c, hipMemsetAsync(c->dmacc + half + (size_t)g0 * a.M, 0, sizeof(double) * gb[g] * a.M, gs[g]));
       ga[g].macc = c->dmacc + (size_t)g0 * a.M;
       ga[g].vacc = c->dmacc + half + (size_t)g0 * a.M;
     }
@@ -675,20 +783,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   // fp64: a diagonal launch is one workgroup per fit on a latency chain whose length does not depend on the
   // batch (3.3 ms per N = 2048 schedule), so below FUSED64_BELOW fits per call the fused form wins there too
   // (batch 32 +26 %, 64 +15 %, 128 +6 %, 256 +0.2 %, 512 -0.7 %).
-  const bool fused64 = sw.fused_diag || batch < FUSED64_BELOW;
-  const bool split_diag = sw.split_diag || !in_rows || (sizeof(T) == 8 && !fused64);
-  // Mid-size calls: the extra rows (test points and y: M + 1 of them against N - 128 (k + 1) matrix rows, i.e. most of
-  // the update work) do not feed the factorisation, only their own next block column.  They get launches of their own on
-  // a second stream -- E(k), after the launch that finished diagonal tile k -- so the chain-bound factorisation launches
-  // A(k) (few workgroups, long chains) run beside the MFMA-bound extra-row launches instead of in lock-step with them:
-  //     s :  diag(0)  A(0)  A(1)  A(2) ...            A(k): matrix tiles of step k + kinds A / B / C
-  //     sE:           E(0)  E(1)  E(2) ...            E(k) waits for A(k - 1) (W_k, row panel k) and follows E(k - 1)
-  // Measured (tools/r3_xsplit.sh, same box, variant without the split): fp64 N = 2048 48 fits 5.58 -> 4.99 ms, 32 fits 4.03 ->
-  // 3.92, 24 fits 3.48 -> 3.51, 12 fits 2.62 -> 3.45 (the call is one chain then: nothing to run beside it); fp32 N = 1024
-  // 64 fits 0.99 -> 1.01, 32 fits 0.69 -> 0.76: its launches last as long as kind A's chain at every k, so the extra rows'
-  // last launches only queue up behind it, and two contexts overlap worse (0.76 -> 0.96 ms per call).  fp64 from 28 fits.
-  // (not under cgp_profile_enable: per-launch events of two concurrent streams would overlap in time and their sum overstate the kernel)
-  const bool xsplit = mid && sizeof(T) == 8 && batch * a.NT >= XSPLIT64_WORK && in_rows && !split_diag && G == 1 && a.ET > 0 && !kNoExtraSplit && !c->prof;
+  // (fused64 / split_diag / xsplit are decided above, with the stream groups)
   hipStream_t sE = c->wstream[0];
   Launcher LE{c, sE};
   for (int k = 0; k < a.NT; ++k) {
@@ -701,12 +796,13 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       }
       if (xsplit) {
         // E(k) needs W_k and the row panel k: diag(0) for k = 0, else everything up to A(k - 1), the last thing queued on s
-        HIP_TRY(c, hipEventRecord(c->ev_look[k], s));
+        HIP_TRY(c, hipEventRecord(c->ev_look[k], gs[g]));
         HIP_TRY(c, hipStreamWaitEvent(sE, c->ev_look[k], 0));
         FitArgs ae = ga[g];
         ae.rows_from_extra = 1;
         LE.begin(0, panel_flops(a.N, a.M, a.d, k, false, gb[g]), k);
         if constexpr (sizeof(T) == 8) launch_panel_rows<T>(dim3(a.ET, gb[g]), sE, ae, k);
+        else hipLaunchKernelGGL(k_rows64<T>, dim3(cdiv(a.M + 1, HR), gb[g]), dim3(256), panel_lds_bytes<T>(), sE, ae, k);
         LE.end();
       }
       if (split_diag) {
@@ -738,7 +834,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
   }
   if (xsplit) {  // join: k_finalize reads the extra rows
     HIP_TRY(c, hipEventRecord(c->ev_join[0], sE));
-    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[0], 0));
+    HIP_TRY(c, hipStreamWaitEvent(gs[0], c->ev_join[0], 0));
   }
   for (int g = 0; g < G; ++g) {
     L[g].begin(3, gb[g] * (4.0 * a.M * a.N + 2.0 * a.N));
@@ -751,13 +847,14 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     }
   }
   HIP_TRY(c, hipGetLastError());
-  if (G > 1) {
-    for (int g = 0; g < G; ++g) {
-      if (g == 0) continue;   // group 0 ran on the caller's stream itself
-      HIP_TRY(c, hipEventRecord(c->ev_join[g], gs[g]));
-      HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[g], 0));
-    }
+  for (int g = 0; g < G; ++g) {
+    if (gs[g] == s) continue;   // ran on the caller's stream itself
+    hipEvent_t ej = c->ev_join[(g + 1) % cgp_ctx::kMaxStreams];   // ([0] is the extra rows' join)
+    HIP_TRY(c, hipEventRecord(ej, gs[g]));
+    HIP_TRY(c, hipStreamWaitEvent(s, ej, 0));
   }
+  if (tune_ev1) HIP_TRY(c, hipEventRecord(tune_ev1, s));
+  if (tune) ++tune->state;
   return CGP_OK;
 }
 
@@ -902,15 +999,25 @@ const char *cgp_last_error(const cgp_ctx *ctx) { return ctx ? ctx->err.c_str() :
 double cgp_last_jitter(const cgp_ctx *ctx) { return ctx ? ctx->fjitter : 0.0; }
 
 cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, int dtype) {
-  if (max_n < 1 || max_m < 0 || max_d < 1 || max_d > CGP_MAX_D || max_batch < 1) return nullptr;
-  if (dtype != CGP_F64 && dtype != CGP_F32) return nullptr;
+  return cgp_create_ex(device, max_n, max_m, max_d, max_batch, dtype, nullptr);
+}
+
+cgp_ctx *cgp_create_ex(int device, int max_n, int max_m, int max_d, int max_batch, int dtype, int *status) {
+  auto fail = [status](int code) -> cgp_ctx * {
+    if (status) *status = code;
+    return nullptr;
+  };
+  if (status) *status = CGP_OK;
+  if (max_n < 1 || max_m < 0 || max_d < 1 || max_d > CGP_MAX_D || max_batch < 1) return fail(CGP_EINVAL);
+  if (dtype != CGP_F64 && dtype != CGP_F32) return fail(CGP_EINVAL);
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nullptr;
-  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(CGP_ENODEVICE);
+  if (hipSetDevice(device) != hipSuccess) return fail(CGP_ENODEVICE);
   // the code object holds gfx950 kernels only (MFMA f64 16x16x4, 64-bit DPP row_newbcast, 16-byte LDS-DMA)
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) return nullptr;
-  if ((dtype == CGP_F64 ? set_lds_attrs<double>(device) : set_lds_attrs<float>(device)) != 0) return nullptr;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(CGP_ENODEVICE);
+  if ((dtype == CGP_F64 ? set_lds_attrs<double>(device) : set_lds_attrs<float>(device)) != 0) return fail(CGP_EHIP);
+  (void)hipGetLastError();   // a clean slate: what the allocations below leave behind tells out-of-memory from anything else
   cgp_ctx *c = new cgp_ctx();
   c->n_cu = prop.multiProcessorCount;
   c->device = device;
@@ -994,7 +1101,7 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
       for (int NB = 1; NB <= SM_MAX_NB; ++NB) {
         c->smdeal_off[NB] = tab.size();
         tab.resize(tab.size() + small_table_elems(NB), 0);
-        for (int jb = 0; jb < NB; ++jb) sm_build_deal(tab.data() + c->smdeal_off[NB], NB, jb);
+        for (int jb = 0; jb < NB; ++jb) ok = sm_build_deal(tab.data() + c->smdeal_off[NB], NB, jb) && ok;   // false: the deal outgrew sm_eval's lists
         sm_build_rowmap(tab.data() + c->smdeal_off[NB] + (size_t)NB * SM_NH * SM_DEAL, NB);
       }
       ok = ok && hipMalloc((void **)&c->dsmdeal, tab.size() * sizeof(unsigned short)) == hipSuccess;
@@ -1003,8 +1110,9 @@ cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, 
     ok = ok && set_small_attr(device) == 0;
   }
   if (!ok) {
+    const hipError_t e = hipGetLastError();
     cgp_destroy(c);
-    return nullptr;
+    return fail(e == hipErrorOutOfMemory ? CGP_ENOMEM : CGP_EHIP);
   }
   return c;
 }
@@ -1033,6 +1141,9 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipStreamDestroy(c->hstream);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  for (auto &t : c->tune)
+    for (auto e : t.e)
+      if (e) (void)hipEventDestroy(e);
   for (auto e : c->ev_look)
     if (e) (void)hipEventDestroy(e);
   for (void *wb : c->winbuf)
@@ -1107,7 +1218,7 @@ int cgp_synchronize(cgp_ctx *c) {
 }
 
 int cgp_set_streams(cgp_ctx *c, int n) {
-  if (!c || n < 1 || n > cgp_ctx::kMaxStreams) return CGP_EINVAL;
+  if (!c || n < 0 || n > cgp_ctx::kMaxStreams) return CGP_EINVAL;
   c->nstreams = n;
   return CGP_OK;
 }
@@ -1819,7 +1930,10 @@ void small_mark_fitted(cgp_ctx *c, const double *X, const double *y, int N, int 
 // evaluation needed) are on the device, the factor panel is not -- run the fit schedule once, GPy's jitter ladder around it
 int ensure_fitted(cgp_ctx *c) {
   if (!c->lazy_fit) return CGP_OK;
+  // nothing counts as fitted until the schedule below has succeeded: an early return (upload, copy, launch error) must not
+  // leave have_fit set over a factor panel that was never built for this window
   c->lazy_fit = false;
+  c->have_fit = false;
   hipStream_t s = c->stream;
   {   // the window was evaluated where the caller's copy was staged: bring it (and theta) to slot 0 now
     int rc = upload_window(c, c->lazy_win.data(), c->lazy_win.data() + (size_t)c->fN * c->fd, c->fN, c->fd, s);
@@ -1840,14 +1954,18 @@ int ensure_fitted(cgp_ctx *c) {
   a.info = c->dinfo;
   double jit = c->fjitter;
   int info = 0;
-  for (int attempt = 0; attempt <= 5; ++attempt) {
+  // GPy's jitchol: one attempt without jitter, then five rungs mean(diag) 1e-6 10^r.  The short-window kernel may already
+  // have climbed to rung `rung` (its jitter is kept bit for bit); the refit continues from there and never passes rung 5.
+  const double base = mean_diag_from(c->fkernel, c->ftheta, c->fd, c->f_meandiag_x) * 1e-6;
+  int rung = jit > 0.0 && base > 0.0 ? 1 + (int)std::lround(std::log10(jit / base)) : 0;
+  for (; rung <= 5; ++rung) {
     HIP_TRY(c, hipMemcpyAsync(c->djitter, &jit, sizeof(double), hipMemcpyHostToDevice, s));
     int rc = run(c, a, 1, true, false, s);
     if (rc != CGP_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(&info, c->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     if (info == 0) break;
-    jit = jit == 0.0 ? mean_diag_from(c->fkernel, c->ftheta, c->fd, c->f_meandiag_x) * 1e-6 : jit * 10.0;
+    jit = jit == 0.0 ? base : jit * 10.0;
   }
   c->have_fit = info == 0;
   c->fjitter = info == 0 ? jit : 0.0;
@@ -2103,12 +2221,23 @@ extern "C" int cgp_window_init(cgp_ctx *c, int nwin, int N, int d, int kid, cons
   return CGP_OK;
 }
 
+namespace {
+int window_push_impl(cgp_ctx *c, int T, const double *dxs, const double *dys, int include_noise, double *dpm, double *dpv, double *dl,
+                     int *info_out, hipStream_t ws);
+}
 extern "C" int cgp_window_push_device(cgp_ctx *c, int T, const double *dxs, const double *dys, int include_noise,
                                       double *dpm, double *dpv, double *dl, void *hip_stream) {
   if (!c || c->nwin < 1) return CGP_ESTATE;
   if (T < 1 || !dxs || !dys || !dpm || !dpv || !dl) return CGP_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
+  return window_push_impl(c, T, dxs, dys, include_noise, dpm, dpv, dl, nullptr, pick_stream(c, hip_stream));
+}
+namespace {
+// info_out: [nwin] ints the kernels mirror every window's status word into (pinned host memory for the per-tick entry), or null
+int window_push_impl(cgp_ctx *c, int T, const double *dxs, const double *dys, int include_noise, double *dpm, double *dpv, double *dl,
+                     int *info_out, hipStream_t ws) {
   WindowArgs a = c->win;
+  a.info_out = info_out;
   a.xs = dxs;
   a.ys = dys;
   a.pred_mean = dpm;
@@ -2132,7 +2261,6 @@ extern "C" int cgp_window_push_device(cgp_ctx *c, int T, const double *dxs, cons
     const int v = e ? atoi(e) : 0;
     if ((v == 1 || v == 2 || v == 4) && c->nwin % v == 0 && v * lds2 <= 150 * 1024) wpw = v;
   }
-  hipStream_t ws = pick_stream(c, hip_stream);
   const int N = a.N, CAP = a.CAP;
   if (c->win_o < 0) {   // the mirror was invalidated by a failed push: read the windows' state back (they advance in lock-step)
     int st[4];
@@ -2179,6 +2307,7 @@ extern "C" int cgp_window_push_device(cgp_ctx *c, int T, const double *dxs, cons
   c->win_n = n;
   return CGP_OK;
 }
+}  // namespace
 
 extern "C" int cgp_window_push(cgp_ctx *c, int T, const double *xs, const double *ys, int include_noise, double *pm,
                                double *pv, double *logml) {
@@ -2196,6 +2325,22 @@ extern "C" int cgp_window_push(cgp_ctx *c, int T, const double *xs, const double
   memcpy(h, xs, nx * 8);
   memcpy(h + nx, ys, ny * 8);
   hipStream_t s = c->stream;
+  if (bytes <= kWinZeroCopyBytes) {
+    // A tick or a handful of them (configs[3] is "streamed per IMU tick"): no copy command at all.  The kernels read the
+    // samples where they were staged (pinned host memory is device-visible at its host address) and write the tick's
+    // outputs and every window's status word back there; one synchronisation.  (Round 4: one H2D, two D2H, 176 us per tick of
+    // one N = 512 window, ~30 us of it the three copy commands; the tick itself is 147 us of one workgroup's serial chains.)
+    for (size_t w = 0; w < W; ++w) hst[w] = 0;
+    int rc0 = window_push_impl(c, T, h, h + nx, include_noise, h + nx + ny, h + nx + 2 * ny, h + nx + 3 * ny, hst, s);
+    if (rc0 != CGP_OK) return rc0;
+    HIP_TRY(c, hipStreamSynchronize(s));
+    memcpy(pm, h + nx + ny, ny * 8);
+    memcpy(pv, h + nx + 2 * ny, ny * 8);
+    memcpy(logml, h + nx + 3 * ny, ny * 8);
+    for (size_t w = 0; w < W; ++w)
+      if (hst[w] != 0) return hst[w];
+    return CGP_OK;
+  }
   HIP_TRY(c, hipMemcpyAsync(d, h, (nx + ny) * 8, hipMemcpyHostToDevice, s));
   int rc = cgp_window_push_device(c, T, d, d + nx, include_noise, d + nx + ny, d + nx + 2 * ny, d + nx + 3 * ny, s);
   if (rc != CGP_OK) return rc;

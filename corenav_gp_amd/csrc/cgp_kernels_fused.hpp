@@ -146,13 +146,23 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
 // nchunk is a multiple of 4 (k * 128 / 16).  The Gram staging area (smem + 2 chunk buffers) is
 // buffer 2 / 3, first written after the barrier of iteration 0, i.e. after every wave's Gram phase.
 // --------------------------------------------------------------------------------------------------
-template <typename T> struct RowFrag {
+// R = slots of the chunk ring (row fragments in registers, column-panel chunks in LDS), D = chunks in flight ahead of the one
+// being multiplied: (4, 2).  The loop is written for any (R, D) with 8 % R == 0, D < R, (D - 1) x loads per chunk <= 63; (8, 5)
+// in the fp32 mid-size build was measured in round 5 (tools/phase_clock.py had shown 3.6-4.6 k ticks per chunk inside a 64-fit
+// call against 2.05 k of MFMA time): 24 / 32 / 48 / 64 / 96 fits 0.608 / 0.671 / 0.767 / 1.035 / 1.293 ms per call against 0.63 /
+// 0.684 / 0.770 / 0.985 / 1.27 -- those ticks are two co-resident workgroups sharing the MFMA pipes (2 x 2.05 k), not memory latency.
+template <typename T, int R = 4> struct RowFrag {
   using vec2 = T __attribute__((ext_vector_type(2)));
-  vec2 r[4][KT / 4];
+  vec2 r[R][KT / 4];
 };
+#ifndef CGP_MID_RING
+#define CGP_MID_RING 4   // `make variant` A/B: 8 = ring of eight / five chunks ahead in the fp32 mid-size build (measured: no gain)
+#endif
+template <typename T, bool MID> constexpr int deep_ring() { return (MID && sizeof(T) == 4) ? CGP_MID_RING : 4; }
+template <int R> constexpr int deep_dist() { return R == 4 ? 2 : 5; }
 
-template <typename T, int SLOT>
-__device__ __forceinline__ void rfrag_load(RowFrag<T> &f, const T *gRl, size_t ldR, int chunk, int lq) {
+template <typename T, int SLOT, int R>
+__device__ __forceinline__ void rfrag_load(RowFrag<T, R> &f, const T *gRl, size_t ldR, int chunk, int lq) {
   // Issued as raw instructions: with an LDS-DMA load in flight the compiler's waitcnt pass treats
   // every later use of a loaded register as "flat pending" and inserts vmcnt(0), which would wait
   // for the whole prefetch queue.  The hand-placed vmcnt waits in rdirect_step cover these loads.
@@ -185,18 +195,19 @@ __device__ __forceinline__ void cpanel_stage(const T *gC, size_t ldC, int chunk,
   }
 }
 
-template <typename T>
-__device__ __forceinline__ void rdirect_prologue(RowFrag<T> &f, const T *gR, size_t ldR, const T *gC, size_t ldC,
+template <typename T, int R = 4>
+__device__ __forceinline__ void rdirect_prologue(RowFrag<T, R> &f, const T *gR, size_t ldR, const T *gC, size_t ldC,
                                                  int nchunk, T *smem, int tid) {
   constexpr int CH = KT * LDST;
-  if (nchunk <= 0) return;
+  if (nchunk <= 0) return;   // (otherwise nchunk >= 8 > D)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const T *gRl = gR + wave * 32 + 2 * (lane & 15);
-  cpanel_stage<T>(gC, ldC, 0, smem, lane, wave);
-  rfrag_load<T, 0>(f, gRl, ldR, 0, lane >> 4);
-  cpanel_stage<T>(gC, ldC, 1, smem + CH, lane, wave);
-  rfrag_load<T, 1>(f, gRl, ldR, 1, lane >> 4);
+  static_for<0, deep_dist<R>()>([&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    cpanel_stage<T>(gC, ldC, J, smem + J * CH, lane, wave);
+    rfrag_load<T, J>(f, gRl, ldR, J, lane >> 4);
+  });
 }
 
 // ISSUE / LAST are compile-time so that no data-dependent branch sits between a load and its use:
@@ -206,26 +217,25 @@ __device__ __forceinline__ void rdirect_prologue(RowFrag<T> &f, const T *gR, siz
 // folded into the running sums  ms[j] += V z,  ms[2 + j] += V^2  (rows 2 l15 + j; zs = z of that block
 // column, 16 values per chunk) -- the predictive mean / variance accumulate here instead of in a
 // separate pass over V.
-template <typename T, int S, bool ISSUE, bool LAST, bool ACC = false>
-__device__ __forceinline__ void rdirect_step(typename Prec<T>::acc_t (&acc)[NCB][2], RowFrag<T> &f, const T *gRl, size_t ldR,
+template <typename T, int R, int S, bool ISSUE, int WAITN, bool ACC = false>
+__device__ __forceinline__ void rdirect_step(typename Prec<T>::acc_t (&acc)[NCB][2], RowFrag<T, R> &f, const T *gRl, size_t ldR,
                                              const T *gC, size_t ldC, int c, T *smem, int lane, int wave,
                                              const T *zs = nullptr, T *ms = nullptr) {
   using P = Prec<T>;
   constexpr int CH = KT * LDST;
+  constexpr int D = deep_dist<R>();
   const int l15 = lane & 15, lq = lane >> 4;
-  // everything but the loads of chunk c + 1 (cpanel_loads + 4 row fragments) has landed
-  if constexpr (LAST) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  else if constexpr (sizeof(T) == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
-  static_assert(cpanel_loads<double>() + KT / 4 == 8 && cpanel_loads<float>() + KT / 4 == 12, "vmcnt constants");
-  // The row fragments were loaded by raw instructions two steps ago; to the compiler they were ready
+  // everything but the loads of the WAITN / (cpanel_loads + 4 row fragments) chunks behind chunk c has landed
+  static_assert(WAITN >= 0 && WAITN <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+  // The row fragments were loaded by raw instructions D steps ago; to the compiler they were ready
   // at once.  Pin every use of this step's fragments behind the wait above (volatile asm statements
   // keep their order), or a use that depends on nothing else -- the V^2 sums -- is hoisted over it.
 #pragma unroll
   for (int ks = 0; ks < KT / 4; ++ks) asm volatile("" : "+v"(f.r[S][ks]));
   if constexpr (ISSUE) {
-    cpanel_stage<T>(gC, ldC, c + 2, smem + ((S + 2) & 3) * CH, lane, wave);
-    rfrag_load<T, (S + 2) & 3>(f, gRl, ldR, c + 2, lq);
+    cpanel_stage<T>(gC, ldC, c + D, smem + ((S + D) % R) * CH, lane, wave);
+    rfrag_load<T, (S + D) % R>(f, gRl, ldR, c + D, lq);
   }
   // column fragments one k-step ahead of the MFMAs that consume them (two register sets)
   const T *cur = smem + S * CH + lq * LDST + l15;
@@ -238,7 +248,7 @@ __device__ __forceinline__ void rdirect_step(typename Prec<T>::acc_t (&acc)[NCB]
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) fa[(ks + 1) & 1][cb] = cur[(ks + 1) * 4 * LDST + cb * DB];
     }
-    const typename RowFrag<T>::vec2 fb = f.r[S][ks];
+    const typename RowFrag<T, R>::vec2 fb = f.r[S][ks];
     if constexpr (ACC) {
       const T zv = zs[ks * 4 + lq];
       ms[0] = __builtin_fma(fb[0], zv, ms[0]);
@@ -254,30 +264,32 @@ __device__ __forceinline__ void rdirect_step(typename Prec<T>::acc_t (&acc)[NCB]
   }
 }
 
-template <typename T>
-__device__ __forceinline__ void mfma_rowpanel_loop_rdirect(typename Prec<T>::acc_t (&acc)[NCB][2], RowFrag<T> &f, const T *gR,
+// nchunk is a multiple of 8 (k * 128 / 16, or the 8 chunks of the newest block column): whole groups of R steps that all
+// issue, then the last 8 chunks -- the newest block column, whose sums ride along -- with the issue and wait pattern of a
+// draining queue (chunk j of the tail has min(D - 1, 7 - j) chunks in flight behind it).
+template <typename T, int R = 4>
+__device__ __forceinline__ void mfma_rowpanel_loop_rdirect(typename Prec<T>::acc_t (&acc)[NCB][2], RowFrag<T, R> &f, const T *gR,
                                                            size_t ldR, const T *gC, size_t ldC, int nchunk, T *smem, int tid,
                                                            const T *zs, T (&ms)[4]) {
   if (nchunk <= 0) return;
+  constexpr int D = deep_dist<R>();
+  constexpr int L = cpanel_loads<T>() + KT / 4;   // vector-memory instructions per wave and chunk
+  static_assert((D - 1) * L <= 63 && D < R && 8 % R == 0, "ring / distance / vmcnt");
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const T *gRl = gR + wave * 32 + 2 * (lane & 15);
   int c = 0;
-  for (; c + 8 < nchunk; c += 4) {
-    rdirect_step<T, 0, true, false>(acc, f, gRl, ldR, gC, ldC, c, smem, lane, wave);
-    rdirect_step<T, 1, true, false>(acc, f, gRl, ldR, gC, ldC, c + 1, smem, lane, wave);
-    rdirect_step<T, 2, true, false>(acc, f, gRl, ldR, gC, ldC, c + 2, smem, lane, wave);
-    rdirect_step<T, 3, true, false>(acc, f, gRl, ldR, gC, ldC, c + 3, smem, lane, wave);
+  for (; c + 8 < nchunk; c += R) {
+    static_for<0, R>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      rdirect_step<T, R, J, true, (D - 1) * L>(acc, f, gRl, ldR, gC, ldC, c + J, smem, lane, wave);
+    });
   }
-  // the last 8 chunks are the newest block column (nchunk is a multiple of 8): sums ride along
-  rdirect_step<T, 0, true, false, true>(acc, f, gRl, ldR, gC, ldC, c, smem, lane, wave, zs, ms);
-  rdirect_step<T, 1, true, false, true>(acc, f, gRl, ldR, gC, ldC, c + 1, smem, lane, wave, zs + KT, ms);
-  rdirect_step<T, 2, true, false, true>(acc, f, gRl, ldR, gC, ldC, c + 2, smem, lane, wave, zs + 2 * KT, ms);
-  rdirect_step<T, 3, true, false, true>(acc, f, gRl, ldR, gC, ldC, c + 3, smem, lane, wave, zs + 3 * KT, ms);
-  rdirect_step<T, 0, true, false, true>(acc, f, gRl, ldR, gC, ldC, c + 4, smem, lane, wave, zs + 4 * KT, ms);
-  rdirect_step<T, 1, true, false, true>(acc, f, gRl, ldR, gC, ldC, c + 5, smem, lane, wave, zs + 5 * KT, ms);
-  rdirect_step<T, 2, false, false, true>(acc, f, gRl, ldR, gC, ldC, c + 6, smem, lane, wave, zs + 6 * KT, ms);
-  rdirect_step<T, 3, false, true, true>(acc, f, gRl, ldR, gC, ldC, c + 7, smem, lane, wave, zs + 7 * KT, ms);
+  static_for<0, 8>([&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    constexpr int behind = (D - 1) < (7 - J) ? (D - 1) : (7 - J);
+    rdirect_step<T, R, J % R, (J + D < 8), behind * L, true>(acc, f, gRl, ldR, gC, ldC, c + J, smem, lane, wave, zs + J * KT, ms);
+  });
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -411,8 +423,10 @@ constexpr int GK = 12;  // augmented point length: MAXD coordinates, 2 norm slot
 // so it is produced by three MFMA 16x16x4 per 16x16 block straight into the accumulator layout; the
 // VALU then only evaluates exp.  (This is the x^2 + x'^2 - 2xx' expansion GPy itself uses for r^2;
 // its rounding error is ~1e-16 |x|^2 absolute in the exponent.)  FAST = interior tile: no selects.
-template <typename T, bool BROWN, bool FAST, bool TRI = false>
-__device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2],
+// NR = 16-row blocks per wave: 2 (rows 2 l15 + j of the wave's 32-row slab; TRI: block rows `wave` and `7 - wave`) or 1 (row
+// l15 of the wave's 16-row slab: the 64-row tiles of k_rows64).
+template <typename T, bool BROWN, bool FAST, bool TRI = false, int NR = 2>
+__device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][NR],
                                                 const T *__restrict__ xrT, const T *__restrict__ xcT,
                                                 const T *__restrict__ xraw, const T *__restrict__ craw,
                                                 const T *__restrict__ yc, bool extra, int rowbase, int colbase, T amp,
@@ -424,17 +438,19 @@ __device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<
   ec.load();
   // local rows of this lane: 2 l15 + {0, 1} of the wave's 32-row slab, or (TRI, diagonal tile) row
   // l15 of the 16-row blocks `wave` and `7 - wave`, of which only column blocks <= the row block exist
+  static_assert(NR == 2 || (NR == 1 && !TRI), "row blocks per wave");
   const int rbj[2] = {TRI ? wave : 0, TRI ? NCB - 1 - wave : 0};
-  const int rl[2] = {TRI ? rbj[0] * DB + l15 : wave * 32 + 2 * l15, TRI ? rbj[1] * DB + l15 : wave * 32 + 2 * l15 + 1};
-  T fb[2][GK / 4];
+  const int rl[2] = {TRI ? rbj[0] * DB + l15 : (NR == 2 ? wave * 32 + 2 * l15 : wave * DB + l15),
+                     TRI ? rbj[1] * DB + l15 : wave * 32 + 2 * l15 + 1};
+  T fb[NR][GK / 4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NR; ++j)
 #pragma unroll
     for (int s = 0; s < GK / 4; ++s) fb[j][s] = xrT[(4 * s + lq) * TS + rl[j]];
   T xrw[2] = {T(0), T(0)};
   if (BROWN) {
     xrw[0] = xraw[rl[0]];
-    xrw[1] = xraw[rl[1]];
+    if (NR == 2) xrw[1] = xraw[rl[1]];
   }
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
@@ -443,7 +459,7 @@ __device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<
 #pragma unroll
     for (int s = 0; s < GK / 4; ++s) fa[s] = xcT[(4 * s + lq) * TS + cb * DB + l15];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NR; ++j) {
       if (TRI && cb > rbj[j]) continue;
       acc_t e = acc_t{0, 0, 0, 0};
 #pragma unroll
@@ -524,8 +540,9 @@ template <typename T> struct GramPre {
   T yv;
 };
 
+// row0 >= 0: the tile's first row inside its block (matrix rows, or extra rows when rt >= NT) instead of the 128-row tile rt's
 template <typename T>
-__device__ __forceinline__ void gram_prefetch(const FitArgs &p, int b, int k, int rt, int tid, GramPre<T> &g) {
+__device__ __forceinline__ void gram_prefetch(const FitArgs &p, int b, int k, int rt, int tid, GramPre<T> &g, int row0 = -1) {
   const int d = p.d, N = p.N, M = p.M;
   const bool extra = rt >= p.NT;
   const T *__restrict__ Xb = reinterpret_cast<const T *>(p.X) + (size_t)b * d * N;
@@ -536,8 +553,8 @@ __device__ __forceinline__ void gram_prefetch(const FitArgs &p, int b, int k, in
   const T *src = Xb;
   int idx, len = N;
   if (isrow) {
-    if (!extra) idx = rt * TS + r;
-    else { src = Xsb; idx = (rt - p.NT) * TS + r; len = M; }
+    if (!extra) idx = (row0 >= 0 ? row0 : rt * TS) + r;
+    else { src = Xsb; idx = (row0 >= 0 ? row0 : (rt - p.NT) * TS) + r; len = M; }
   } else idx = k * TS + r;
   const bool ok = idx < len;
 #pragma unroll
@@ -547,10 +564,10 @@ __device__ __forceinline__ void gram_prefetch(const FitArgs &p, int b, int k, in
 
 // Stages the augmented points of tile (rt, k) in LDS ([GK][128], component-major) and applies
 // acc <- G - acc.
-template <typename T, bool TRI = false>
-__device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
+template <typename T, bool TRI = false, int NR = 2>
+__device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][NR], T *__restrict__ smem,
                                            int b, int k, int rt, int tid, const GramPre<T> &g, PhaseClock *pc = nullptr,
-                                           int slot = 0) {
+                                           int slot = 0, int row0 = -1) {
   const double *__restrict__ pr = p.prep + (size_t)b * PREP_N;
   const int kid = p.kernel_id, N = p.N, M = p.M;
   const bool extra = rt >= p.NT;
@@ -586,18 +603,19 @@ __device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::a
   __syncthreads();
   if (pc) pc->lap(p, slot);  // inputs fetched and staged
   const T amp = T(pr[9]), amp_b = T(pr[10]), diag_add = T(pr[11]);
-  const int rowbase = extra ? (rt - p.NT) * TS : rt * TS;
+  const int rowbase = row0 >= 0 ? row0 : (extra ? (rt - p.NT) * TS : rt * TS);
   const int colbase = k * TS;
-  const bool fast = (colbase + TS <= N) && (extra ? (rowbase + TS <= M && !p.xid) : (rt != k && rowbase + TS <= N));
+  constexpr int ROWS = NR == 2 ? TS : TS / 2;   // rows of the tile
+  const bool fast = (colbase + TS <= N) && (extra ? (rowbase + ROWS <= M && !p.xid) : (rt != k && rowbase + ROWS <= N));
   if constexpr (TRI) {  // diagonal tile: never "fast" (it carries the noise diagonal)
     if (brown) gram_apply_tile<T, true, false, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
     else gram_apply_tile<T, false, false, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
   } else if (brown) {
-    if (fast) gram_apply_tile<T, true, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
-    else gram_apply_tile<T, true, false>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
+    if (fast) gram_apply_tile<T, true, true, false, NR>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
+    else gram_apply_tile<T, true, false, false, NR>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
   } else {
-    if (fast) gram_apply_tile<T, false, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
-    else gram_apply_tile<T, false, false>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
+    if (fast) gram_apply_tile<T, false, true, false, NR>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
+    else gram_apply_tile<T, false, false, false, NR>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
   }
 }
 
@@ -1022,13 +1040,15 @@ __device__ __forceinline__ void panel_partial(const FitArgs &p, typename Prec<T>
   GramPre<T> gp;
   gram_prefetch<T>(p, b, kc, rt, tid, gp);
   if constexpr (DEEP) {
-    RowFrag<T> rf;
-    T *zs = smem + 4 * KT * LDST;  // the loop folds its newest block column into running sums nobody reads here
+    constexpr int R = deep_ring<T, true>();   // kind C only exists in the mid-size build
+    RowFrag<T, R> rf;
+    T *zs = smem + R * KT * LDST;  // the loop folds its newest block column into running sums nobody reads here
     if (tid < TS) zs[tid] = T(0);
     T ms[4] = {T(0), T(0), T(0), T(0)};
-    rdirect_prologue<T>(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
-    gram_apply<T>(p, acc, smem + CH2, b, kc, rt, tid, gp);
-    mfma_rowpanel_loop_rdirect<T>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
+    rdirect_prologue<T, R>(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+    // the Gram inputs are staged in the ring slots the prologue leaves free (first written after iteration 0's barrier)
+    gram_apply<T>(p, acc, smem + (R - 2) * KT * LDST, b, kc, rt, tid, gp);
+    mfma_rowpanel_loop_rdirect<T, R>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
   } else {
     if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
     gram_apply<T>(p, acc, smem + CH2, b, kc, rt, tid, gp);
@@ -1066,20 +1086,21 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
   // running predictive sums (extra tiles, throughput schedule): z of the newest block column
   // (k - 1) goes to LDS behind the chunk ring; zeros when nothing is to be accumulated
   const bool accm = p.macc != nullptr && rt >= p.NT && k > 0;
-  T *zs = smem + 4 * KT * LDST;
+  constexpr int R = DEEP ? deep_ring<T, MID>() : 4;   // chunk ring of the deep loop (the register-staged loop has two buffers)
+  T *zs = smem + R * KT * LDST;
   if (tid < TS) zs[tid] = accm ? Lw[(size_t)((k - 1) * TS + tid) * ld + (size_t)p.NT * TS + p.M] : T(0);
   T ms[4] = {T(0), T(0), T(0), T(0)};
   if constexpr (DEEP) {
-    RowFrag<T> rf;
+    RowFrag<T, R> rf;
     {
       GramPre<T> gp;
       if (!(MID && from_image)) gram_prefetch<T>(p, b, k, rt, tid, gp);
-      rdirect_prologue<T>(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
+      rdirect_prologue<T, R>(rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid);
       if (MID && from_image) acc_image<T, false, false>(acc, const_cast<T *>(pimg), tid);
-      else gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
+      else gram_apply<T>(p, acc, smem + (R - 2) * KT * LDST, b, k, rt, tid, gp, &pc, ps + 6);   // ring slots the prologue leaves free
     }
     pc.lap(p, ps + 0);
-    mfma_rowpanel_loop_rdirect<T>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
+    mfma_rowpanel_loop_rdirect<T, R>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
   } else {
     {
       GramPre<T> gp;
@@ -1116,9 +1137,10 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
         if (m < p.M) {
           // agent-scope accesses: neighbouring rows' sums share cache lines with other workgroups' rows, and in the one-launch
           // schedule the previous block step's writer of THIS row may have run on another XCD (whose L2 is not coherent with ours)
+          // block step 1 starts the sums (nothing zeroed them), later steps add
           double *pm = p.macc + (size_t)b * p.M + m, *pv = p.vacc + (size_t)b * p.M + m;
-          const double om = __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const double ov = __hip_atomic_load(pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double om = k == 1 ? 0.0 : __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double ov = k == 1 ? 0.0 : __hip_atomic_load(pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(pm, om + (double)ms[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(pv, ov + (double)ms[2 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1158,7 +1180,7 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
 #endif
 constexpr int F32_FULL_OCC = CGP_F32_FULL_OCC;
 template <typename T, bool DIAGNEXT = false, bool DEEP = sizeof(T) == 8, bool MID = false>
-__global__ __launch_bounds__(256, sizeof(T) == 4 ? (DEEP ? 3 : F32_FULL_OCC) : 2) void k_panel(FitArgs p, int k) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? (DEEP ? ((MID && CGP_MID_RING > 4) ? 2 : 3) : F32_FULL_OCC) : 2) void k_panel(FitArgs p, int k) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1230,6 +1252,157 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (DEEP ? 3 : F32_FULL_OCC) : 2
   sc.leave(p, k, tid);
 }
 
+// --------------------------------------------------------------------------------------------------
+// k_rows64: the EXTRA rows (test points and y) of block step k in 64-row tiles -- four waves of 16 rows -- for the fp32
+// mid-size calls (BASELINE configs[2] as sharded: 64 fits per GPU), whose extra-row launches E(k) run on a second stream
+// beside the factorisation launches (run_schedule).  A mid-size launch is a handful of equal workgroups per CU and lasts as
+// long as the CU with the most of them: E(k) as 128-row tiles is 5 x 64 = 320 workgroups on 256 CUs -- 64 CUs take two, the
+// launch lasts two tile times for 1.25 tile times of work (E(7): 143 us against an MFMA floor of 67; round 5 timeline,
+// profiles/r05_mid_timelines.txt).  Half-height tiles halve the quantum: 640 workgroups, at most three per CU.
+// Same arithmetic per element, in the same order, as panel_tile_body (rows are independent): bitwise the 128-row result.
+//   acc[cb][reg] = C[row = 16 wave + (lane & 15)][col = 16 cb + drow(lane, reg)]
+// Column panel through the LDS-DMA ring (4 slots, two chunks ahead), a wave's own 16 rows straight to registers.
+// --------------------------------------------------------------------------------------------------
+constexpr int HR = TS / 2;   // rows of a half tile
+template <typename T, int SLOT>
+__device__ __forceinline__ void r16_load(T (&f)[4][KT / 4], const T *gRl, size_t ldR, int chunk, int lq) {
+#pragma unroll
+  for (int ks = 0; ks < KT / 4; ++ks) {
+    const T *src = gRl + (size_t)(chunk * KT + ks * 4 + lq) * ldR;
+    if constexpr (sizeof(T) == 8) asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(f[SLOT][ks]) : "v"(src));
+    else asm volatile("global_load_dword %0, %1, off" : "=&v"(f[SLOT][ks]) : "v"(src));
+  }
+}
+template <typename T, int S, bool ISSUE, int WAITN, bool ACC>
+__device__ __forceinline__ void r16_step(typename Prec<T>::acc_t (&acc)[NCB][1], T (&f)[4][KT / 4], const T *gRl, size_t ldR, const T *gC,
+                                         size_t ldC, int c, T *smem, int lane, int wave, const T *zs, T *ms) {
+  using P = Prec<T>;
+  constexpr int CH = KT * LDST;
+  const int l15 = lane & 15, lq = lane >> 4;
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+#pragma unroll
+  for (int ks = 0; ks < KT / 4; ++ks) asm volatile("" : "+v"(f[S][ks]));
+  if constexpr (ISSUE) {
+    cpanel_stage<T>(gC, ldC, c + 2, smem + ((S + 2) & 3) * CH, lane, wave);
+    r16_load<T, (S + 2) & 3>(f, gRl, ldR, c + 2, lq);
+  }
+  const T *cur = smem + S * CH + lq * LDST + l15;
+  T fa[2][NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) fa[0][cb] = cur[cb * DB];
+#pragma unroll
+  for (int ks = 0; ks < KT / 4; ++ks) {
+    if (ks + 1 < KT / 4) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) fa[(ks + 1) & 1][cb] = cur[(ks + 1) * 4 * LDST + cb * DB];
+    }
+    const T fb = f[S][ks];
+    if constexpr (ACC) {
+      const T zv = zs[ks * 4 + lq];
+      ms[0] = __builtin_fma(fb, zv, ms[0]);
+      ms[1] = __builtin_fma(fb, fb, ms[1]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = P::mfma(fa[ks & 1][cb], fb, acc[cb][0]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void k_rows64(FitArgs p, int k) {
+  using P = Prec<T>;
+  using acc_t = typename P::acc_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int h, b;
+  tile_fit_of_block(h, b);                     // a fit's half tiles on one XCD: they share the column panel
+  const int row0 = h * HR;                     // first extra row of this half tile (rows > M are padding, row M is y)
+  T *Lw = reinterpret_cast<T *>(p.Lw) + (size_t)b * p.lw_stride;
+  const int ld = p.ld;
+  constexpr int CH = KT * LDST, L = cpanel_loads<T>() + KT / 4;
+  const size_t rb = (size_t)p.NT * TS + row0;  // first row of the tile in the factor panel
+  const T *gR = Lw + rb, *gC = Lw + (size_t)k * TS;
+  const int nchunk = k * (TS / KT);
+  const bool accm = p.macc != nullptr && k > 0;
+  T *zs = smem + 4 * CH;
+  if (tid < TS) zs[tid] = accm ? Lw[(size_t)((k - 1) * TS + tid) * ld + (size_t)p.NT * TS + p.M] : T(0);
+  T ms[2] = {T(0), T(0)};
+  acc_t acc[NCB][1];
+  T rf[4][KT / 4];
+  const T *gRl = gR + wave * DB + l15;
+  {
+    GramPre<T> gp;
+    gram_prefetch<T>(p, b, k, p.NT, tid, gp, row0);
+    if (nchunk > 0) {
+      cpanel_stage<T>(gC, (size_t)ld, 0, smem, lane, wave);
+      r16_load<T, 0>(rf, gRl, (size_t)ld, 0, lq);
+      cpanel_stage<T>(gC, (size_t)ld, 1, smem + CH, lane, wave);
+      r16_load<T, 1>(rf, gRl, (size_t)ld, 1, lq);
+    }
+    gram_apply<T, false, 1>(p, acc, smem + 2 * CH, b, k, p.NT, tid, gp, nullptr, 0, row0);
+  }
+  if (nchunk > 0) {
+    int c = 0;
+    for (; c + 8 < nchunk; c += 4) {
+      r16_step<T, 0, true, L, false>(acc, rf, gRl, (size_t)ld, gC, (size_t)ld, c, smem, lane, wave, nullptr, nullptr);
+      r16_step<T, 1, true, L, false>(acc, rf, gRl, (size_t)ld, gC, (size_t)ld, c + 1, smem, lane, wave, nullptr, nullptr);
+      r16_step<T, 2, true, L, false>(acc, rf, gRl, (size_t)ld, gC, (size_t)ld, c + 2, smem, lane, wave, nullptr, nullptr);
+      r16_step<T, 3, true, L, false>(acc, rf, gRl, (size_t)ld, gC, (size_t)ld, c + 3, smem, lane, wave, nullptr, nullptr);
+    }
+    static_for<0, 8>([&](auto jc) {   // the newest block column: the predictive sums ride along
+      constexpr int J = decltype(jc)::value;
+      r16_step<T, J & 3, (J + 2 < 8), (J < 7 ? L : 0), true>(acc, rf, gRl, (size_t)ld, gC, (size_t)ld, c + J, smem, lane, wave, zs + J * KT, ms);
+    });
+  }
+  if (accm) {
+    ms[0] += __shfl_xor(ms[0], 16);
+    ms[0] += __shfl_xor(ms[0], 32);
+    ms[1] += __shfl_xor(ms[1], 16);
+    ms[1] += __shfl_xor(ms[1], 32);
+    const int m = row0 + wave * DB + lane;
+    if (lane < 16 && m < p.M) {
+      double *pm = p.macc + (size_t)b * p.M + m, *pv = p.vacc + (size_t)b * p.M + m;
+      const double om = k == 1 ? 0.0 : __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double ov = k == 1 ? 0.0 : __hip_atomic_load(pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(pm, om + (double)ms[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(pv, ov + (double)ms[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();   // every wave is done with the staged inputs before W_k overwrites them
+  // L(:, k) = S W_k^T in registers (trmm_in_registers with one row block per wave)
+  const T *__restrict__ Wk = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * WIMG;
+  {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    constexpr int PER = 1024 / (int)sizeof(T), NI = WIMG / PER / 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int off = (i * 4 + wave) * PER;
+      __builtin_amdgcn_global_load_lds((gbl_void *)(Wk + off + lane * (16 / (int)sizeof(T))), (lds_void *)(smem + off), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+#pragma unroll
+  for (int cb = NCB - 1; cb >= 0; --cb) {
+    acc_t t0 = acc_t{0, 0, 0, 0};
+    const T *wrow = smem + (cb * (cb + 1) / 2) * DB * DB + l15;
+#pragma unroll
+    for (int qb = 0; qb <= cb; ++qb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t0 = P::mfma(wrow[qb * DB * DB + P::drow(lane, r) * DB], acc[qb][0][r], t0);
+    }
+    acc[cb][0] = t0;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  T *__restrict__ out = Lw + (size_t)(k * TS) * ld + rb + wave * DB + l15;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(size_t)(cb * DB + P::drow(lane, r)) * ld] = acc[cb][0][r];
+}
+
 #ifdef CGP_AB
 // --------------------------------------------------------------------------------------------------
 // k_sched: a whole mid-size call (a few dozen fits: BASELINE configs[2] as sharded over 8 GPUs is 64 per GPU) in ONE launch.
@@ -1293,7 +1466,7 @@ __device__ __attribute__((noinline)) void sched_run_panel_partial(const FitArgs 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_sched(FitArgs p, SchedArgs q) {
+__global__ __launch_bounds__(256, 2) void k_sched(FitArgs p, SchedArgs q) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   __shared__ int s_task, s_ok;

@@ -148,21 +148,29 @@ struct SmClock {
 // deal[jb][helper] = {count, items...}; depends on the number of block rows only: the host builds the table of every NB once
 // per context (a thread building its list in the kernel indexes load[] / cnt[] dynamically, i.e. in scratch memory: 39 us of
 // a 77 us launch when it was done there) and a launch copies its 2 KB into LDS.
-__host__ __device__ inline void sm_build_deal(unsigned short *deal, int NB, int jb) {
-  int load[SM_NH], cnt[SM_NH];
-  for (int h = 0; h < SM_NH; ++h) load[h] = cnt[h] = 0;
+// Returns false when the deal does not fit what sm_eval can hold -- a list longer than SM_DEAL - 1 items, or more than two W
+// blocks (code 0x100 | j) for one helper: sm_eval keeps two pending W blocks per helper (wres[2] / wj[2]).  Holds for every
+// NB <= SM_MAX_NB with the shipped SM_HELPERS; cgp_create checks it for the tables it builds and refuses the context
+// otherwise (SM_HELPERS is a `make variant` knob), instead of a wrong factor with no error.
+__host__ __device__ inline bool sm_build_deal(unsigned short *deal, int NB, int jb) {
+  int load[SM_NH], cnt[SM_NH], nw[SM_NH];
+  bool fits = true;
+  for (int h = 0; h < SM_NH; ++h) load[h] = cnt[h] = nw[h] = 0;
   unsigned short *base = deal + jb * SM_NH * SM_DEAL;
   auto give = [&](int code, int cost) {
     int h = 0;
     for (int hh = 1; hh < SM_NH; ++hh) h = load[hh] < load[h] ? hh : h;
     load[h] += cost;
+    if (code & 0x100) fits = fits && ++nw[h] <= 2;
     if (cnt[h] < SM_DEAL - 1) base[h * SM_DEAL + 1 + cnt[h]++] = (unsigned short)code;
+    else fits = false;
   };
   const int jp = jb - 1;
   for (int j = 0; j < jp; ++j) give(0x100 | j, jp - j + 1);
   for (int bi = jb + 1; bi < NB; ++bi)          // panel jp applied to every block below / right of the diagonal block jb,
     for (int bj = jb; bj <= bi; ++bj) give(bi << 4 | bj, 1);   // column jb (rows >= jb + 1) included: block (jb, jb) is the chain's
   for (int h = 0; h < SM_NH; ++h) base[h * SM_DEAL] = (unsigned short)cnt[h];
+  return fits;
 }
 
 // Cross-lane sums on the VALU's DPP path instead of ds_bpermute (what __shfl_xor compiles to: an LDS round trip per step, ~100
@@ -995,8 +1003,11 @@ __global__ __launch_bounds__(SM_THREADS) void k_small(SmallArgs p) {
       sm_eval<BROWN, DMAX>(s, d, N, NB, tid);
       const int bad = s.flag[0];
       const int attempt = s.flag[2];
-      if (bad == 0 || attempt >= 5) break;
+      // every wave has latched the two flags before anybody rewrites them: wave 0 runs ahead from here (L-BFGS step, next
+      // trial point, which reset flag[0] / flag[2]), and a wave still reading would otherwise see the old pivot with the
+      // new attempt count on an exhausted ladder and take the retry branch alone (barrier mismatch)
       __syncthreads();
+      if (bad == 0 || attempt >= 5) break;
       if (tid == 0) {
         const double noise = s.sc[nth - 1] + 1e-8;
         const double md = BROWN ? s.sc[0] * s.sc[2] * s.sc[23] + noise : s.sc[0] + noise;

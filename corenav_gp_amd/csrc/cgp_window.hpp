@@ -48,6 +48,7 @@ struct WindowArgs {
   double *pred_mean, *pred_var, *logml;  // [nwin][T]
   int N, CAP, d, kernel_id, T, include_noise;
   int t0, nt;       // this launch handles ticks [t0, t0 + nt) of the block (k_window_pairs: nt even)
+  int *info_out;    // [nwin] or nullptr: a copy of state[2] (first failing tick) where the host can read it without a copy command
 };
 
 // Covariance of two points (raw coordinates), direct formulas.
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
     st[1] = n;
     st[2] = bad;
     st[3] += p.nt;
+    if (p.info_out) p.info_out[w] = bad;
   }
 }
 
@@ -382,6 +384,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
   // launch, an earlier push that returned early) is flagged (state[2] = -1) and left untouched instead of being swept.
   if (p.state[w0 * 4 + 1] != N || o + N + 1 >= CAP) {
     if (tid < WPW && p.state[(w0 + tid) * 4 + 2] == 0) p.state[(w0 + tid) * 4 + 2] = -1;
+    if (tid < WPW && p.info_out) p.info_out[w0 + tid] = p.state[(w0 + tid) * 4 + 2];
     return;
   }
   const int m = N - 1;
@@ -702,6 +705,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
     st[1] = N;
     st[2] = bad;
     st[3] += p.nt;
+    if (p.info_out) p.info_out[w0 + tid] = bad;
   }
 }
 

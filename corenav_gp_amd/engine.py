@@ -31,6 +31,7 @@ OBJECTIVE_FN = ctypes.CFUNCTYPE(ctypes.c_double, _dp, _dp, ctypes.c_int, ctypes.
 
 _SIGS = {
     "cgp_create": (_vp, [ctypes.c_int] * 6),
+    "cgp_create_ex": (_vp, [ctypes.c_int] * 6 + [_ip]),
     "cgp_destroy": (None, [_vp]),
     "cgp_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "cgp_last_error": (ctypes.c_char_p, [_vp]),
@@ -43,6 +44,9 @@ _SIGS = {
     "cgp_sweep_shard": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _ip, _ip]),
     "cgp_sweep_fit_predict": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5 + [_dp, _dp, _dp, _dp, ctypes.c_int,
                                                                           ctypes.c_int, _dp, _dp, _dp, _ip, _dp]),
+    "cgp_sweep_fit_predict_device": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5 + [_vp] * 5 + [ctypes.c_int] + [_vp] * 5),
+    "cgp_sweep_synchronize": (ctypes.c_int, [_vp]),
+    "cgp_sweep_context": (_vp, [_vp, ctypes.c_int]),
     "cgp_fit": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp]),
     "cgp_predict": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
     "cgp_get_alpha": (ctypes.c_int, [_vp, _dp]),
@@ -154,10 +158,11 @@ class Context:
     def __init__(self, device=0, max_n=2048, max_m=640, max_d=MAX_D, max_batch=1, dtype=F64):
         self.lib = load()
         self.dtype = dtype
-        self.h = self.lib.cgp_create(device, max_n, max_m, max_d, max_batch, dtype)
+        st = ctypes.c_int(0)
+        self.h = self.lib.cgp_create_ex(device, max_n, max_m, max_d, max_batch, dtype, ctypes.byref(st))
         if not self.h:
-            raise RuntimeError("cgp_create failed: no usable gfx950 device or out of device memory "
-                               "(the engine has no CPU fallback)")
+            raise RuntimeError(f"cgp_create failed ({st.value}: {self.lib.cgp_strerror(st.value).decode()}): no usable gfx950 "
+                               "device, an argument out of range, or out of device memory (the engine has no CPU fallback)")
 
     def close(self):
         if getattr(self, "h", None):
@@ -411,6 +416,34 @@ class Sweep:
         if rc < 0:
             raise CgpError(rc)
         return rc, mean, var, logml, info, summ
+
+    def fit_predict_device(self, B, N, d, M, kernel_id, dX, dy, dXs, dtheta, djitter, include_noise, dmean, dvar, dlogml,
+                           dinfo, streams=None):
+        """cgp_sweep_fit_predict_device: every argument a list of ndev per-shard device pointers (ints), shard i's fits
+        only; `streams` a list of hipStream_t handles (ints; None = the contexts' own streams).  Enqueues and returns."""
+        def arr(ptrs):
+            if ptrs is None:
+                return None
+            a = (ctypes.c_void_p * self.ndev)(*[ctypes.c_void_p(int(p) if p else 0) for p in ptrs])
+            return ctypes.cast(a, _vp)
+        keep = [arr(x) for x in (dX, dy, dXs, dtheta, djitter, dmean, dvar, dlogml, dinfo, streams)]
+        rc = self.lib.cgp_sweep_fit_predict_device(self.h, B, N, d, M, kernel_id, keep[0], keep[1], keep[2], keep[3], keep[4],
+                                                   int(include_noise), keep[5], keep[6], keep[7], keep[8], keep[9])
+        if rc < 0:
+            raise CgpError(rc)
+        return rc
+
+    def synchronize(self):
+        rc = self.lib.cgp_sweep_synchronize(self.h)
+        if rc:
+            raise CgpError(rc)
+
+    def set_streams(self, n):
+        """cgp_set_streams on every shard's context."""
+        for i in range(self.ndev):
+            rc = self.lib.cgp_set_streams(self.lib.cgp_sweep_context(self.h, i), n)
+            if rc:
+                raise CgpError(rc)
 
 
 INIT_LLH = (0.693457963620326, -1.39498384275845, 334.993517334743)   # init_params.yaml:13-16

@@ -6,6 +6,7 @@ BASELINE configs[4]: the Pathfinder bag is not obtainable, so the sensor stream 
         --/core_nav/core_nav/gp_result-->  GpPredictor [gp_predictor.cpp, C++]  <-- stopping_service
         --/core_nav/core_nav/stop_cmd-->   SlipRecorder.stopCallback + DriveStraightWithStop FSM
                                            (pathfinder_control/src/drive_straight_with_stop.cpp:28-66)
+        rover stopped --> zero updates shrink P (FilterCovariance) --> the NEXT window's SetStopping answer
 
 An ensemble of trajectories (Monte-Carlo) is stepped in lock-step; the windows published at a tick
 are fitted together through the batched C ABI.
@@ -60,14 +61,69 @@ class DriveStraightWithStop:
         return 0.0 if self.state == "stopped" else 1.0
 
 
+IMU_PER_ODO = 5         # parameters.yaml:46-47: IMU 50 Hz, odometry 10 Hz (gp_predictor.cpp:64 walks 5 steps per prediction too)
+# CoreNav::Init, CoreNav.cpp:1026-1059: the zero-update measurement model (ZARU on the gyro-bias states 12..14, ZUPT on the
+# velocity states 3..5) and its noise
+_H_ZERO = np.zeros((6, 15))
+for _r, _c in enumerate((12, 13, 14, 3, 4, 5)):
+    _H_ZERO[_r, _c] = -1.0
+_R_ZERO = np.diag([0.01 ** 2, 0.01 ** 2, 0.0025 ** 2, 0.02 ** 2, 0.02 ** 2, 1.0 ** 2])
+# the odometry measurement noise at zero slip variance: gp_predictor.cpp:80-88 with chi_UT_est_cov = 0 (the floors 0.03^2,
+# 0.03^2, 0.05^2, 0.05^2 through R_IP_1, times 25) -- what the look-ahead itself assumes when the GP predicts no slip
+_R1 = np.array([[0.5, 0.5, 0.0, 0.0], [1 / 0.685, -1 / 0.685, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+_R_ODO = 25.0 * _R1 @ np.diag([0.03 ** 2, 0.03 ** 2, 0.05 ** 2, 0.05 ** 2]) @ _R1.T
+
+
+class FilterCovariance:
+    """The part of CoreNav's covariance bookkeeping the SetStopping answer depends on -- NOT the EKF (out of
+    scope; no state, no mechanisation, fixed synthetic STM / Q / H per trajectory): per odometry tick the 15 x 15 error
+    covariance is propagated IMU_PER_ODO times, `P = STM P STM' + Q` (CoreNav::Propagate, CoreNav.cpp:104); while the
+    rover drives the tick ends with the odometry update in Joseph form (CoreNav::Update, :190-242 -- with the filter's own
+    H and the zero-slip R above: the recursion the reference's look-ahead itself runs, gp_predictor.cpp:66-91); while it
+    stands still every IMU step applies the zero-velocity / zero-angular-rate update instead (CoreNav.cpp:139-142,
+    zeroUpdate :390-409).  `snapshot()` is what CoreNav::Update keeps at the stopRecording tick (`P_pred = P_`, :291-292)
+    for setStopping_ to serve (:652-676).  So the uncertainty a look-ahead starts from grows over the mission, and a stop
+    takes out what the zero updates can observe (velocity error and the position error correlated with it): the stop ->
+    ZUPT -> smaller P -> later next stop feedback of the reference's loop."""
+
+    def __init__(self, P, Q, STM, H, zero_updates_enabled=True):
+        self.P = np.array(P, dtype=np.float64).reshape(15, 15)
+        self.Q = np.asarray(Q, dtype=np.float64).reshape(15, 15)
+        self.STM = np.asarray(STM, dtype=np.float64).reshape(15, 15)
+        self.H = np.asarray(H, dtype=np.float64).reshape(4, 15)
+        self.P_pred = self.P.copy()
+        self.zero_updates = 0
+        self.zero_updates_enabled = zero_updates_enabled   # False: the control of the feedback test (a stop that corrects nothing)
+
+    @staticmethod
+    def _joseph(P, H, R):
+        K = P @ H.T @ np.linalg.inv(H @ P @ H.T + R)
+        IKH = np.eye(15) - K @ H
+        return IKH @ P @ IKH.T + K @ R @ K.T
+
+    def odometry_tick(self, stopped):
+        for _ in range(IMU_PER_ODO):
+            self.P = self.STM @ self.P @ self.STM.T + self.Q
+            if stopped and self.zero_updates_enabled:   # |rearVel_| < 0.005 (CoreNav.cpp:139): the commanded stop holds the wheels
+                self.P = self._joseph(self.P, _H_ZERO, _R_ZERO)
+                self.zero_updates += 1
+        if not stopped:
+            self.P = self._joseph(self.P, self.H, _R_ODO)
+
+    def snapshot(self):
+        self.P_pred = self.P.copy()
+
+
 class Trajectory:
-    def __init__(self, seed):
+    def __init__(self, seed, evolve_filter=True, zero_updates=True):
         self.sim = RoverSim(seed)
         self.rec = engine.SlipRecorder()
         self.drv = DriveStraightWithStop()
-        fs = synth.filter_state(seed)
-        self.P, self.Q, self.STM, self.Hvec, self.pos = fs
+        self.P, self.Q, self.STM, self.Hvec, self.pos, H = synth.filter_state(seed, with_H=True)
+        # evolve_filter = False: the round-4 stand-in (every window answered from the same static snapshot)
+        self.cov = FilterCovariance(self.P, self.Q, self.STM, H, zero_updates) if evolve_filter else None
         self.windows, self.results, self.stop_cmds, self.stops = [], [], [], 0
+        self.served = []   # per published window: (the P_pred served, zero updates applied so far)
         self._was_stopped = False
 
     def tick(self, now):
@@ -77,12 +133,21 @@ class Trajectory:
         self._was_stopped = cmd == 0.0
         self.rec.cmd_callback(cmd)
         wheels, vlin = self.sim.step(cmd != 0.0)
-        return self.rec.update(*wheels, vlin, cmd)
+        if self.cov is not None:
+            self.cov.odometry_tick(cmd == 0.0)
+        win = self.rec.update(*wheels, vlin, cmd)
+        if win is not None and self.cov is not None:
+            # CoreNav.cpp:289-305: the snapshot is taken at the tick that publishes the window
+            self.cov.snapshot()
+            self.P = self.cov.P_pred.reshape(225).copy()
+            self.served.append((self.P.copy(), self.cov.zero_updates))
+        return win
 
 
 class ClosedLoopEnsemble:
-    def __init__(self, n_traj, theta=(0.5, 30.0, 0.01, 0.002), optimize=False, device=0, seed=synth.SEED_BASE + 5):
-        self.traj = [Trajectory(seed + 31 * i) for i in range(n_traj)]
+    def __init__(self, n_traj, theta=(0.5, 30.0, 0.01, 0.002), optimize=False, device=0, seed=synth.SEED_BASE + 5,
+                 evolve_filter=True, zero_updates=True):
+        self.traj = [Trajectory(seed + 31 * i, evolve_filter, zero_updates) for i in range(n_traj)]
         self.theta = np.asarray(theta, dtype=np.float64)
         self.optimize = optimize
         self.ctx = engine.Context(device=device, max_n=256, max_m=1024, max_d=1, max_batch=max(n_traj, 1))   # max_m >= N: optimiser needs it

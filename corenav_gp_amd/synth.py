@@ -87,7 +87,7 @@ def reference_window(n=149, tick0=11, seed=SEED_BASE):
     return t, _slip_series(rng, t)
 
 
-def filter_state(seed):
+def filter_state(seed, with_H=False):
     """A plausible 15-state filter snapshot for the SetStopping response (P, Q, STM row-major 225
     each, HvecData[60] packed with the reference's r*4+c indexing, LLH position): position error
     grows through the velocity states so the 3 m horizontal threshold is crossed after some tens of
@@ -108,4 +108,6 @@ def filter_state(seed):
         for c in range(15):
             hvec[r * 4 + c] = H[r, c]
     pos = np.array([0.693457963620326, -1.39498384275845, 334.993517334743]) + np.array([1e-6, -2e-6, 1.5])
+    if with_H:   # the filter's own 4 x 15 measurement matrix (the packed form above loses most of it: SURVEY 8a quirks)
+        return P.reshape(225), Q.reshape(225), STM.reshape(225), hvec, pos, H
     return P.reshape(225), Q.reshape(225), STM.reshape(225), hvec, pos

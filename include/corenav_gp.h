@@ -58,6 +58,10 @@ enum {
  * Returns NULL on failure (device index out of range, device is not gfx950 -- the architecture name
  * is checked: the code object holds gfx950 kernels only -- or out of memory): no CPU fallback. */
 cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, int dtype);
+/* The same, telling WHY it failed: *status (may be NULL) = CGP_OK, CGP_EINVAL (an argument out of range), CGP_ENODEVICE
+ * (device index out of range or not a gfx950 part), CGP_ENOMEM (a device allocation failed: the context is sized by
+ * max_batch x max_n^2) or CGP_EHIP (any other runtime failure). */
+cgp_ctx *cgp_create_ex(int device, int max_n, int max_m, int max_d, int max_batch, int dtype, int *status);
 void cgp_destroy(cgp_ctx *ctx);
 const char *cgp_strerror(int code);
 /* Text of the last HIP error seen by this context ("" if none). */
@@ -106,7 +110,11 @@ int cgp_nll_grad(cgp_ctx *ctx, const double *X, const double *y, int N, int d, i
  * parameters theta = log(1 + exp(x)) (GPy's default positivity constraint) with L-BFGS, starting from
  * theta_inout (GPy starts every parameter at 1.0), at most max_evals objective evaluations (GPy:
  * 1000).  Writes the optimum to theta_inout, its log marginal likelihood to *logml, the number of
- * evaluations to *n_evals, and leaves the context fitted at the optimum (cgp_predict may follow). */
+ * evaluations to *n_evals, and leaves the context fitted at the optimum (cgp_predict may follow).
+ * *n_evals: windows of at most 160 samples (one-launch device optimiser) report the optimiser's own evaluations (what
+ * scipy reports as nfev for the same run); longer windows (host optimiser over device gradients) report those + 1,
+ * the refit at the optimum that leaves the factor panel resident.  The optimiser is scipy's L-BFGS-B without bounds
+ * (csrc/lbfgs_core.hpp): same line search, same stopping tests, same trajectory to rounding. */
 int cgp_optimize(cgp_ctx *ctx, const double *X, const double *y, int N, int d, int kernel_id,
                  double *theta_inout, int max_evals, double *logml, int *n_evals);
 
@@ -203,13 +211,33 @@ int cgp_sweep_fit_predict(cgp_sweep *sweep, int batch, int N, int d, int M, int 
                           const double *y, const double *Xs, const double *theta, int theta_stride,
                           int include_noise, double *mean, double *var, double *logml, int *info,
                           double *summary);
+/* Device-resident form: shard i's inputs already live on device i in the layout of cgp_fit_predict_batch_device
+ * (its (stop_i - start_i) fits only), every argument an array of ndev per-shard device pointers -- dX[i] (n_i, d, N),
+ * dy[i], dXs[i], dtheta[i] (n_i, CGP_MAX_THETA) fp64, djitter[i] or a NULL array, outputs dmean[i], dvar[i], dlogml[i],
+ * dinfo[i]; hip_streams[i] the stream of device i to enqueue on (a NULL ARRAY = every context's own stream, an element
+ * follows the hip_stream convention above).  Returns when every shard's work has been ENQUEUED, without synchronising:
+ * no PCIe copy and no host round trip inside the call (a 64-fit shard is 0.8 ms of device time).  Wait with the streams
+ * you passed, or cgp_sweep_synchronize for the contexts' own streams.  No jitter retry, as cgp_fit_predict_batch_device.
+ * Threads: shard 0 is issued by the calling thread, the others by persistent worker threads created with the sweep (no
+ * thread is created per call); a sweep over ONE device is exactly that context's call. */
+int cgp_sweep_fit_predict_device(cgp_sweep *sweep, int batch, int N, int d, int M, int kernel_id, const void *const *dX,
+                                 const void *const *dy, const void *const *dXs, const double *const *dtheta,
+                                 const double *const *djitter, int include_noise, void *const *dmean, void *const *dvar,
+                                 double *const *dlogml, int *const *dinfo, void *const *hip_streams);
+int cgp_sweep_synchronize(cgp_sweep *sweep);
+/* The engine context of shard i (owned by the sweep): for cgp_set_streams, cgp_last_error, cgp_profile_* on a shard. */
+cgp_ctx *cgp_sweep_context(const cgp_sweep *sweep, int i);
 
-/* Number of worker streams a batch is spread over (1..8, default 1): the batch is cut into that
- * many groups whose launch schedules run concurrently (HIP streams + events, forked from and
- * joined to the caller's stream), so latency-bound launches of one group overlap MFMA-bound
- * launches of another.  Full-batch calls (hundreds of fits) gain nothing measurable; an fp32 call of 56 ... 96 fits
- * (BASELINE configs[2] as sharded over 8 GPUs: 64 per GPU) is cut into TWO groups when n >= 2: 0.99 -> 0.92 ms per
- * 64-fit call on one context.  Results do not depend on the setting (a fit's arithmetic is the same in any group). */
+/* Stream groups of a batch.  n = 0 (the default): the engine decides -- an fp32 call of 56 ... 96 fits (BASELINE configs[2] as
+ * sharded over 8 GPUs: 64 per GPU) is cut into TWO groups whose launch schedules run concurrently, group 0 on the caller's
+ * stream and group 1 on one of the context's worker streams, forked from / joined to the caller's stream with events, so
+ * the chain-bound early launches of one group run beside the MFMA-bound ones of the other (0.99 -> 0.90 ms per 64-fit
+ * call on one context); every other call is one group.  Whether two streams really overlap depends on how the runtime mapped
+ * them onto its hardware queues (the process's history), so the engine MEASURES: per caller stream, after two warm-up calls,
+ * four such calls run as two groups and four as one (events on the caller's stream; the call that reads them waits once
+ * for the previous call), the faster form is kept and re-checked every 256 calls.  n = 1: always one group.  n = 2..8: up to n groups for full-batch
+ * calls too (hundreds of fits gain nothing measurable).  Results do not depend on the setting (a fit's arithmetic is the
+ * same in any group). */
 int cgp_set_streams(cgp_ctx *ctx, int n);
 
 /* Development aid (-DCGP_ABLATION builds; all zero otherwise): in-kernel s_memtime sums.  [0, 8) potf2
@@ -217,16 +245,16 @@ int cgp_set_streams(cgp_ctx *ctx, int n);
  * over all workgroups, slot 7 of each group = workgroup count (CGP_DBG & 1024).  Reading resets them. */
 #define CGP_DEBUG_SLOTS 512
 int cgp_debug_read(cgp_ctx *ctx, long long out[CGP_DEBUG_SLOTS]);
-/* Development aid: device addresses and byte sizes of the context's large buffers, as pairs
- * out[2 i] = address, out[2 i + 1] = bytes for i = 0 factor panels (Lw), 1 W images (Winv), 2 diagonal-tile images,
- * 3 panel-tile images, 4 inputs X, 5 running predictive sums, 6 latency partial tiles, 7 latency images
- * (tools/ctx_placement.py prints them next to the timings of a context). */
 /* Development aid: the raw result record of the last short-window launch (cgp_nll_grad / cgp_optimize* of a window of at
  * most 160 samples in an fp64 context, csrc/cgp_small.hpp): [0] logML, [1] evaluations, [2] L-BFGS status, [3] iterations,
  * [4] info, [5] jitter, [8..18) gradient, [20..30) theta, [32..48) per-phase s_memtime sums (-DCGP_ABLATION builds; zero
  * otherwise: tools/small_phases.py). */
 #define CGP_SMALL_OUT 48
 int cgp_debug_small(cgp_ctx *ctx, double out[CGP_SMALL_OUT]);
+/* Development aid: device addresses and byte sizes of the context's large buffers, as pairs
+ * out[2 i] = address, out[2 i + 1] = bytes for i = 0 factor panels (Lw), 1 W images (Winv), 2 diagonal-tile images,
+ * 3 panel-tile images, 4 inputs X, 5 running predictive sums, 6 latency partial tiles, 7 latency images
+ * (tools/ctx_placement.py prints them next to the timings of a context). */
 #define CGP_DEBUG_BUFFERS 8
 int cgp_debug_buffers(cgp_ctx *ctx, unsigned long long out[2 * CGP_DEBUG_BUFFERS]);
 

@@ -53,6 +53,10 @@ def test_bench_extra_lines():
     assert 0 < ex["node_callback_us"] < 5000 and 0 < ex["node_callback_opt_ms"] < 500   # the reference node's own work item
     # configs[2] as written (64 fits per GPU at 8 GPUs): the 64-fit call rate and the projection from this GPU's two rates
     assert ex["cfg3_fits_per_s_at_64"] > 0 and 0 < ex["cfg3_strong_scaling_projection_8gpu"] <= 8.5
+    # the C-ABI multi-device entry on the same shard: over one device it IS the context's call (shard 0 runs on the caller's thread)
+    sw = ex["cgp_sweep"]
+    assert 0.9 < sw["devices_1_over_context"] < 1.15 and sw["devices_same_gpu_twice_ms_per_call"] > 0
+    assert ex["replay"]["windows_fitted"] >= 64 and ex["replay"]["stops"] >= 1
     assert ex["cfg3_strong"]["n_gpus"] == 1 and ex["cfg3_strong"]["fits_per_s"] == ex["cfg3_fits_per_s"]
 
 

@@ -336,11 +336,13 @@ def test_config3_as_sharded_64_fits_fp32(engine):
     rc, m2, v2, l2, i2 = ctx.fit_predict_batch(X[perm], y[perm], Xs[perm], th[perm], kid)
     assert rc == 0 and not i2.any()
     assert np.array_equal(m2, mean[perm]) and np.array_equal(v2, var[perm]) and np.array_equal(l2, logml[perm])
-    # cgp_set_streams(2): the same call as two stream groups of 32 fits on worker streams -- bitwise the same results
-    ctx.set_streams(2)
-    rc, m3, v3, l3, i3 = ctx.fit_predict_batch(X, y, Xs, th, kid)
-    assert rc == 0 and not i3.any()
-    assert np.array_equal(m3, mean) and np.array_equal(v3, var) and np.array_equal(l3, logml)
+    # stream groups: by default the engine cuts this call into two groups of 32 fits (caller's stream + one worker stream);
+    # cgp_set_streams(1) keeps one group, (2) asks for two -- bitwise the same results every way
+    for ns in (1, 2, 0):
+        ctx.set_streams(ns)
+        rc, m3, v3, l3, i3 = ctx.fit_predict_batch(X, y, Xs, th, kid)
+        assert rc == 0 and not i3.any()
+        assert np.array_equal(m3, mean) and np.array_equal(v3, var) and np.array_equal(l3, logml), ns
 
 
 @pytest.mark.parametrize("dtype_name,N,small,large", [("F32", 640, 64, 100), ("F32", 1024, 40, 97), ("F64", 640, 48, 52)])
@@ -691,3 +693,50 @@ def test_sweep_matches_single_context(engine, devices):
     assert rc == 0 and not i2.any()
     assert np.array_equal(m2, mean) and np.array_equal(v2, var) and np.array_equal(l2, logml)
     assert np.array_equal(summ[:, 0], logml) and np.allclose(summ[:, 1], 2 * np.sqrt(var.max(1))) and not summ[:, 2].any()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_sweep_device_entry_matches_single_context(engine, devices):
+    """cgp_sweep_fit_predict_device: per-shard DEVICE pointers, work enqueued without synchronising (shard 0 issued by the
+    calling thread, the others by the sweep's persistent worker threads) -- bitwise the single context's results in fp64,
+    call after call (the workers are reused), on the contexts' own streams and on caller streams."""
+    import torch
+    kid, X, y, Xs, th, _ = synth.config(2, batch=90, N=300, M=77)
+    B, N, d = X.shape
+    M = Xs.shape[1]
+    ctx = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=B)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    assert rc == 0
+    sw = engine.Sweep(devices, N, M, d, B)
+    dev = torch.device("cuda", 0)
+    thp = np.zeros((B, engine.MAX_THETA))
+    thp[:, :th.shape[1]] = th
+    bufs = []
+    for i in range(sw.ndev):
+        a, b = sw.shard(B, i)
+        t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+        bufs.append(dict(X=t(X[a:b].transpose(0, 2, 1)), y=t(y[a:b]), Xs=t(Xs[a:b].transpose(0, 2, 1)), th=t(thp[a:b]),
+                         mean=torch.zeros(b - a, M, dtype=torch.float64, device=dev), var=torch.zeros(b - a, M, dtype=torch.float64, device=dev),
+                         logml=torch.zeros(b - a, dtype=torch.float64, device=dev), info=torch.full((b - a,), -7, dtype=torch.int32, device=dev)))
+    torch.cuda.synchronize()
+    ptr = lambda k: [bf[k].data_ptr() for bf in bufs]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(sw.ndev)]
+    for rep, st in enumerate([None, None, [s.cuda_stream for s in streams]]):
+        for bf in bufs:
+            bf["mean"].zero_(); bf["logml"].zero_(); bf["info"].fill_(-7)
+        torch.cuda.synchronize()
+        rc = sw.fit_predict_device(B, N, d, M, kid, ptr("X"), ptr("y"), ptr("Xs"), ptr("th"), None, True, ptr("mean"), ptr("var"),
+                                   ptr("logml"), ptr("info"), st)
+        assert rc == 0
+        sw.synchronize()
+        torch.cuda.synchronize()
+        m2 = np.concatenate([bf["mean"].cpu().numpy() for bf in bufs])
+        v2 = np.concatenate([bf["var"].cpu().numpy() for bf in bufs])
+        l2 = np.concatenate([bf["logml"].cpu().numpy() for bf in bufs])
+        i2 = np.concatenate([bf["info"].cpu().numpy() for bf in bufs])
+        assert not i2.any(), rep
+        assert np.array_equal(m2, mean) and np.array_equal(v2, var) and np.array_equal(l2, logml), rep
+    # the host-buffer entry on the same (reused) workers
+    for _ in range(3):
+        rc, m3, v3, l3, i3, summ = sw.fit_predict(X, y, Xs, th, kid)
+        assert rc == 0 and np.array_equal(m3, mean) and np.array_equal(l3, logml)

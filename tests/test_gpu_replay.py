@@ -73,3 +73,33 @@ def test_replay_ensemble_two_ranks_match_one():
     # size; the stop times are compared to 1e-9 s all the same, the counts exactly)
     assert np.allclose(np.array(a["per_trajectory"]), np.array(b["per_trajectory"]), rtol=0, atol=1e-9)
     assert a["windows"] == b["windows"] >= 6 and a["stops"] == b["stops"]
+
+
+def test_stop_feedback_closes_the_loop():
+    """BASELINE configs[4] stand-in, the feedback the reference's loop exists for (CoreNav.cpp:139-142,291-292,390-409,
+    652-676): the SetStopping answer evolves -- P is propagated while a window is recorded and corrected by the zero
+    updates while DriveStraightWithStop holds the rover -- so every window is served another snapshot, the stop times
+    differ window to window, and a stop LOWERS the xy_err trace of the next window's look-ahead: compared with a control
+    ensemble (same seeds, same stops, zero updates switched off) the second look-ahead starts lower and crosses later."""
+    from corenav_gp_amd import replay
+    ens = replay.ClosedLoopEnsemble(n_traj=4)
+    ctl = replay.ClosedLoopEnsemble(n_traj=4, zero_updates=False)
+    ens.run(1100)
+    ctl.run(1100)
+    for tr, tc in zip(ens.traj, ctl.traj):
+        assert len(tr.windows) >= 2 and tr.stops >= 1 and tr.cov.zero_updates >= 5 * 40 and tc.cov.zero_updates == 0
+        assert len(tr.served) == len(tr.windows) and not np.allclose(tr.served[0][0], tr.served[1][0])
+        assert abs(tr.stop_cmds[0] - tr.stop_cmds[1]) > 1e-3                      # not the same answer twice
+        # until the first stop both runs are the same run
+        np.testing.assert_array_equal(tr.windows[0][0], tc.windows[0][0])
+        np.testing.assert_array_equal(tr.served[0][0], tc.served[0][0])
+        assert tr.stop_cmds[0] == tc.stop_cmds[0]
+        np.testing.assert_array_equal(tr.windows[1][1], tc.windows[1][1])        # same second window (same first stop)
+        # the second look-ahead, restated by the oracle on what each run served
+        (mean, sigma, th) = tr.results[1]
+        H = go.unpack_H(tr.Hvec, True)
+        f1, c1, i1, xy1, trace1 = go.predict_stop(mean, sigma, tr.served[1][0], tr.Q, tr.STM, H, tr.pos, return_trace=True)
+        f0, c0, i0, xy0, trace0 = go.predict_stop(mean, sigma, tc.served[1][0], tc.Q, tc.STM, H, tc.pos, return_trace=True)
+        n = min(len(trace0), len(trace1))
+        assert np.all(trace1[:n] < trace0[:n]) and i1 >= i0                      # the stop lowered the trace
+        assert f1 and tr.stop_cmds[1] == pytest.approx(c1, rel=1e-9)             # and the engine published the oracle's answer

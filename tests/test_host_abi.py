@@ -35,6 +35,20 @@ def test_no_device_fails_loudly():
         engine.Context()
 
 
+def test_create_ex_tells_why_it_failed():
+    """cgp_create returns a bare NULL; cgp_create_ex distinguishes an argument out of range from a missing / foreign device
+    (and, on a GPU box, from out-of-memory)."""
+    import ctypes
+    lib = engine.load()
+    st = ctypes.c_int(12345)
+    assert not lib.cgp_create_ex(0, 0, 8, 1, 1, engine.F64, ctypes.byref(st)) and st.value == -1            # max_n < 1: CGP_EINVAL
+    assert not lib.cgp_create_ex(0, 64, 8, engine.MAX_D + 1, 1, engine.F64, ctypes.byref(st)) and st.value == -1
+    assert not lib.cgp_create_ex(0, 64, 8, 1, 1, 7, ctypes.byref(st)) and st.value == -1                    # unknown dtype
+    assert not lib.cgp_create_ex(9999, 64, 8, 1, 1, engine.F64, ctypes.byref(st))
+    assert lib.cgp_strerror(st.value) == b"no usable gfx950 device"
+    assert not lib.cgp_create_ex(9999, 64, 8, 1, 1, engine.F64, None)                                        # status may be NULL
+
+
 def test_strerror():
     lib = engine.load()
     assert lib.cgp_strerror(0) == b"ok"
