@@ -425,7 +425,13 @@ constexpr int GK = 12;  // augmented point length: MAXD coordinates, 2 norm slot
 // its rounding error is ~1e-16 |x|^2 absolute in the exponent.)  FAST = interior tile: no selects.
 // NR = 16-row blocks per wave: 2 (rows 2 l15 + j of the wave's 32-row slab; TRI: block rows `wave` and `7 - wave`) or 1 (row
 // l15 of the wave's 16-row slab: the 64-row tiles of k_rows64).
-template <typename T, bool BROWN, bool FAST, bool TRI = false, int NR = 2>
+// DIFF1 (fp32, one input dimension, SE kernels): the exponent comes from the DIFFERENCE of the two raw coordinates, as the
+// Brownian form's does.  The inner-product expansion carries ~1e-7 |x|^2 / ell^2 of absolute error in the exponent in single
+// precision -- 60 x the rounding of a Gram entry -- and dense one-dimensional inputs are exactly the windows whose conditioning
+// amplifies it: tests/fuzz/fuzz_parity.py found 1 window in 2 000 (d = 1, N = 255 ... 1000) at 1.05-1.3 of the 1e-3 bar where
+// single-precision LAPACK on the exact Gram matrix is at 5e-5.  For d >= 2 the expansion stays (d subtractions and FMAs per
+// entry on the VALU would cost more than the Gram phase has; no window of the sweeps needs it).
+template <typename T, bool BROWN, bool FAST, bool TRI = false, int NR = 2, bool DIFF1 = false>
 __device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][NR],
                                                 const T *__restrict__ xrT, const T *__restrict__ xcT,
                                                 const T *__restrict__ xraw, const T *__restrict__ craw,
@@ -447,8 +453,9 @@ __device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<
   for (int j = 0; j < NR; ++j)
 #pragma unroll
     for (int s = 0; s < GK / 4; ++s) fb[j][s] = xrT[(4 * s + lq) * TS + rl[j]];
+  static_assert(!DIFF1 || (!BROWN && sizeof(T) == 4), "the difference form is for the fp32 SE kernels");
   T xrw[2] = {T(0), T(0)};
-  if (BROWN) {
+  if (BROWN || DIFF1) {
     xrw[0] = xraw[rl[0]];
     if (NR == 2) xrw[1] = xraw[rl[1]];
   }
@@ -462,15 +469,20 @@ __device__ __forceinline__ void gram_apply_tile(const FitArgs &p, typename Prec<
     for (int j = 0; j < NR; ++j) {
       if (TRI && cb > rbj[j]) continue;
       acc_t e = acc_t{0, 0, 0, 0};
+      if constexpr (!DIFF1) {
 #pragma unroll
-      for (int s = 0; s < GK / 4; ++s) e = P::mfma(fa[s], fb[j][s], e);
+        for (int s = 0; s < GK / 4; ++s) e = P::mfma(fa[s], fb[j][s], e);
+      }
       const int grow = rowbase + rl[j];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int cl = cb * DB + P::drow(lane, r);
         const int gcol = colbase + cl;
         T g;
-        if (!BROWN) {
+        if constexpr (DIFF1) {
+          const T df = (xrw[j] - craw[cl]) * inv_ell;
+          g = amp * exp_gen(T(-0.5) * df * df, ec);
+        } else if (!BROWN) {
           g = CGP_DBG_ON(p, 128) ? e[r] : exp_gen(e[r], ec);
         } else {
           const T x = xrw[j], xp = craw[cl];
@@ -607,6 +619,14 @@ __device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::a
   const int colbase = k * TS;
   constexpr int ROWS = NR == 2 ? TS : TS / 2;   // rows of the tile
   const bool fast = (colbase + TS <= N) && (extra ? (rowbase + ROWS <= M && !p.xid) : (rt != k && rowbase + ROWS <= N));
+  if constexpr (sizeof(T) == 4) {
+    if (!brown && p.d == 1) {   // fp32, one input dimension: exponent from the coordinate difference (DIFF1)
+      if constexpr (TRI) gram_apply_tile<T, false, false, true, NR, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
+      else if (fast) gram_apply_tile<T, false, true, false, NR, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
+      else gram_apply_tile<T, false, false, false, NR, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
+      return;
+    }
+  }
   if constexpr (TRI) {  // diagonal tile: never "fast" (it carries the noise diagonal)
     if (brown) gram_apply_tile<T, true, false, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
     else gram_apply_tile<T, false, false, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave);
