@@ -350,8 +350,9 @@ def cfg3_strong_line(args, dry, world, rank, local, dev, cdev, use_dist, sync, t
         W3 = Workload(engine, torch, dev, local, kid, X, y, Xs, th, dts, 0)   # engine defaults: a 56 ... 96-fit shard is cut into two stream groups
         step = W3.step
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < 0.1:   # working clock
-            step()
+        while time.perf_counter() - t0 < 0.1:   # working clock; bursts issued back to back as the timed steps are (a mid-size shard: the
+            for _ in range(8):                   # engine settles its stream groups on the pattern it sees)
+                step()
             sync()
     if use_dist:
         dist.barrier()
@@ -624,8 +625,9 @@ def extras_cfg3(engine, torch, dev, local, W):
             # projection from this GPU's two rates (no collective on the data path), not a measurement of 8 GPUs.
             W64 = Workload(engine, torch, dev, local, kid, X[:64], y[:64], Xs[:64], th[:64], dts, 0)   # default settings: the engine picks the stream groups
             tw = time.perf_counter()
-            while time.perf_counter() - tw < 0.1:
-                W64.step()
+            while time.perf_counter() - tw < 0.1:   # bursts issued back to back, as the timed calls are: the engine settles its stream groups on this pattern
+                for _ in range(8):
+                    W64.step()
                 torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(20):
