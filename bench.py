@@ -814,9 +814,14 @@ def window_line(engine, torch, dev, local, W=1024, N=512, d=3, T=200):
     for i in range(5, 5 + nt):
         c1.window_push(X[:1, N + i:N + i + 1], y[:1, N + i:N + i + 1])
     host_tick_us = (time.perf_counter() - t1) / nt * 1e6
-    return {"window_ticks_per_s": W * T / el, "window_hbm_frac": gbps / HBM_PEAK_GBPS, "window_host_tick_us": host_tick_us,
-            "window_traffic_note": "frac = algorithmic bytes per tick (factor read + written once) x ticks/s / 8 TB/s; the kernel takes "
-                                   "steady-state ticks two per pass, so measured HBM traffic is about half the algorithmic figure",
+    # counter traffic of the same command (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, profiles/r05_window_pmc_summary.json): 275.9 GB for
+    # 430 GB algorithmic -- the HBM pipe itself is at 0.64 of the algorithmic fraction
+    kCounterOverAlgorithmic = 275.9 / 429.5
+    return {"window_ticks_per_s": W * T / el, "window_hbm_frac": gbps / HBM_PEAK_GBPS,
+            "window_hbm_frac_counter_traffic": gbps / HBM_PEAK_GBPS * kCounterOverAlgorithmic, "window_host_tick_us": host_tick_us,
+            "window_traffic_note": "window_hbm_frac = ALGORITHMIC bytes per tick (factor read + written once) x ticks/s / 8 TB/s; the kernel takes "
+                                   "steady-state ticks two per pass, so the traffic the PMC counters see is 0.64 of that "
+                                   "(profiles/r05_window_pmc_summary.json): window_hbm_frac_counter_traffic is what the HBM pipe carries",
             "window_workload": f"BASELINE configs[3]: {W} windows x N={N} d={d} fp64, {T} ticks, algorithmic {gbps:.0f} GB/s of {HBM_PEAK_GBPS:.0f}"}
 
 

@@ -21,6 +21,11 @@
 
 namespace cgp {
 
+#ifndef CGP_SKIP_DEAD_WAVE
+#define CGP_SKIP_DEAD_WAVE 1   // fp32 full-batch tiles: a wave whose rows are all padding issues no MFMA (round 5, same box, three alternations:
+                               // 102.2-102.5 k -> 103.5-104.1 k fits/s at 512 x N = 1024, k_panel 0.676 -> 0.688 of peak; `make variant EXTRA=-DCGP_SKIP_DEAD_WAVE=0`)
+#endif
+constexpr bool kSkipDeadWave = CGP_SKIP_DEAD_WAVE != 0;
 
 // acc[cb][j][reg] = C[row = wave*32 + 2*(lane&15) + j][col = cb*16 + drow(lane, reg)].
 // Rows are interleaved (2*l15 + j) so one lane owns two adjacent rows: 16-byte stores, and the two
@@ -50,10 +55,12 @@ __device__ __forceinline__ void stage_first_chunk(const T *gR, size_t ldR, const
 
 // zs / ms (optional): z of the newest block column (the last 8 chunks) and the running sums
 // ms[j] += V z, ms[2 + j] += V^2 for rows 2 l15 + j, as in rdirect_step.
+// live = false (wave-uniform): this wave's 32 rows are padding beyond the last extra row (CGP_SKIP_DEAD_WAVE) -- it stages and
+// keeps the barriers, and issues no MFMA.
 template <typename T, bool PRESTAGED = false>
 __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc)[NCB][2], const T *gR, size_t ldR,
                                                    const T *gC, size_t ldC, int nchunk, T *smem, int tid,
-                                                   const T *zs = nullptr, T *ms = nullptr) {
+                                                   const T *zs = nullptr, T *ms = nullptr, bool live = true) {
   using P = Prec<T>;
   using vec8 = T __attribute__((ext_vector_type(8)));
   using vec2 = T __attribute__((ext_vector_type(2)));
@@ -63,6 +70,7 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
   const int l15 = lane & 15, lq = lane >> 4;
 
   auto compute = [&](const T *cur, int c) {
+    if (!live) return;
     const T *zc = (zs && c >= nchunk - TS / KT) ? zs + (c - (nchunk - TS / KT)) * KT : nullptr;  // block-uniform
 #pragma unroll
     for (int ks = 0; ks < KT / 4; ++ks) {
@@ -579,7 +587,7 @@ __device__ __forceinline__ void gram_prefetch(const FitArgs &p, int b, int k, in
 template <typename T, bool TRI = false, int NR = 2>
 __device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][NR], T *__restrict__ smem,
                                            int b, int k, int rt, int tid, const GramPre<T> &g, PhaseClock *pc = nullptr,
-                                           int slot = 0, int row0 = -1) {
+                                           int slot = 0, int row0 = -1, bool live = true) {
   const double *__restrict__ pr = p.prep + (size_t)b * PREP_N;
   const int kid = p.kernel_id, N = p.N, M = p.M;
   const bool extra = rt >= p.NT;
@@ -619,6 +627,7 @@ __device__ __forceinline__ void gram_apply(const FitArgs &p, typename Prec<T>::a
   const int colbase = k * TS;
   constexpr int ROWS = NR == 2 ? TS : TS / 2;   // rows of the tile
   const bool fast = (colbase + TS <= N) && (extra ? (rowbase + ROWS <= M && !p.xid) : (rt != k && rowbase + ROWS <= N));
+  if (!live) return;   // (wave-uniform; no barrier below)
   if constexpr (sizeof(T) == 4) {
     if (!brown && p.d == 1) {   // fp32, one input dimension: exponent from the coordinate difference (DIFF1)
       if constexpr (TRI) gram_apply_tile<T, false, false, true, NR, true>(p, acc, xrT, xcT, xraw, craw, yc, extra, rowbase, colbase, amp, amp_b, diag_add, lane, wave, T(pr[0]));
@@ -963,7 +972,7 @@ __global__ __launch_bounds__(256, 2) void k_diag_lean(FitArgs p, int k) {
 // Every wave must be done with `smem` before the call.
 template <typename T>
 __device__ __forceinline__ void trmm_in_registers(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
-                                                  int b, int k, int tid, PhaseClock *pc = nullptr, int wslot = 0) {
+                                                  int b, int k, int tid, PhaseClock *pc = nullptr, int wslot = 0, bool live = true) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
   const int lane = tid & 63, l15 = lane & 15;
@@ -986,6 +995,7 @@ __device__ __forceinline__ void trmm_in_registers(const FitArgs &p, typename Pre
   }
   __syncthreads();
   if (pc) pc->lap(p, wslot);  // W_k staged
+  if (!live) return;
 
   // in-register triangular product, descending column blocks so L(:, cb) may overwrite S(:, cb)
 #pragma unroll
@@ -1106,6 +1116,11 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
   // running predictive sums (extra tiles, throughput schedule): z of the newest block column
   // (k - 1) goes to LDS behind the chunk ring; zeros when nothing is to be accumulated
   const bool accm = p.macc != nullptr && rt >= p.NT && k > 0;
+  // the last extra tile of a fit is partly padding (601 rows in five tiles of 128): a wave whose 32 rows all lie beyond the y row
+  // has nothing to compute.  Register-staged fp32 loop only (four workgroups per CU: the SIMD the idle wave frees serves three
+  // other waves; in fp64, two per CU, skipping it measured 1.2 % SLOWER in round 2).
+  const bool live = !(kSkipDeadWave && !DEEP && sizeof(T) == 4 && rt >= p.NT && !p.xid &&
+                      (rt - p.NT) * TS + __builtin_amdgcn_readfirstlane(tid >> 6) * 32 > p.M);
   constexpr int R = DEEP ? deep_ring<T, MID>() : 4;   // chunk ring of the deep loop (the register-staged loop has two buffers)
   T *zs = smem + R * KT * LDST;
   if (tid < TS) zs[tid] = accm ? Lw[(size_t)((k - 1) * TS + tid) * ld + (size_t)p.NT * TS + p.M] : T(0);
@@ -1134,10 +1149,10 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[cb][j][r] = gp.v[0];
       } else if (MID && from_image) acc_image<T, false, false>(acc, const_cast<T *>(pimg), tid);
-      else gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6);
+      else gram_apply<T>(p, acc, smem + CH2, b, k, rt, tid, gp, &pc, ps + 6, -1, live);
     }
     pc.lap(p, ps + 0);
-    mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, accm ? zs : nullptr, ms);
+    mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, accm ? zs : nullptr, ms, live);
   }
   pc.lap(p, ps + 1);
   if (accm) {
@@ -1169,9 +1184,9 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
   }
   __syncthreads();  // every wave is done with the staged inputs before W_k overwrites them
   pc.lap(p, ps + 2);
-  if (!CGP_DBG_ON(p, 64)) trmm_in_registers<T>(p, acc, smem, b, k, tid, &pc, ps + 3);
+  if (!CGP_DBG_ON(p, 64)) trmm_in_registers<T>(p, acc, smem, b, k, tid, &pc, ps + 3, live);
   pc.lap(p, ps + 4);
-  if (!CGP_DBG_ON(p, 32768) || acc[0][0][0] == T(12345.678))  // timing probe: no store
+  if (live && (!CGP_DBG_ON(p, 32768) || acc[0][0][0] == T(12345.678)))  // timing probe: no store
   store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
   pc.lap(p, ps + 5);
   pc.count(p, ps + 7);
