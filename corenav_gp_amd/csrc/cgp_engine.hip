@@ -270,7 +270,11 @@ template <typename T> inline int lat_fits(int NT) {     // ablation build: CGP_L
 
 inline size_t alpha_lds_bytes(int NT) { return (size_t)(NT * TS + TS) * sizeof(double); }
 template <typename T> constexpr int upd_lds_bytes() { return 4 * KT * LDST * (int)sizeof(T); }
-template <typename T> constexpr int panel_lds_bytes() { return upd_lds_bytes<T>() + TS * (int)sizeof(T); }  // + z of one block column
+template <typename T> constexpr int panel_lds_bytes() {   // + z of one block column; fp32 with the bf16 planes: planes + Gram inputs + z
+  return (kF32Bf16x6 && sizeof(T) == 4) ? (BX_FLOATS + 2 * GK * TS + 3 * TS + TS) * 4 : upd_lds_bytes<T>() + TS * (int)sizeof(T);
+}
+static_assert(panel_lds_bytes<float>() >= WIMG * 4 && panel_lds_bytes<float>() >= upd_lds_bytes<float>() + TS * 4,
+              "the panel kernels stage W_k's image (and k_rows64 its chunk buffers) over the loop's LDS");
 template <typename T> constexpr int paneldiag_lds_bytes() { return std::max(panel_lds_bytes<T>(), diag_lds_elems<T>() * (int)sizeof(T)); }
 // mid-size build: fp32 factors the diagonal tile in the fat form (potf2_tile), see mid_fat
 template <typename T> constexpr int paneldiag_mid_lds_bytes() {
