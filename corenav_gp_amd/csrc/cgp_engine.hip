@@ -271,7 +271,7 @@ template <typename T> inline int lat_fits(int NT) {     // ablation build: CGP_L
 inline size_t alpha_lds_bytes(int NT) { return (size_t)(NT * TS + TS) * sizeof(double); }
 template <typename T> constexpr int upd_lds_bytes() { return 4 * KT * LDST * (int)sizeof(T); }
 template <typename T> constexpr int panel_lds_bytes() {   // + z of one block column; fp32 with the bf16 planes: planes + Gram inputs + z
-  return (kF32Bf16x6 && sizeof(T) == 4) ? (BX_FLOATS + 2 * GK * TS + 3 * TS + TS) * 4 : upd_lds_bytes<T>() + TS * (int)sizeof(T);
+  return (kF32Bf16x6 && sizeof(T) == 4) ? (bx_z_offset<false>() + TS) * 4 : upd_lds_bytes<T>() + TS * (int)sizeof(T);
 }
 static_assert(panel_lds_bytes<float>() >= WIMG * 4 && panel_lds_bytes<float>() >= upd_lds_bytes<float>() + TS * 4,
               "the panel kernels stage W_k's image (and k_rows64 its chunk buffers) over the loop's LDS");
@@ -280,6 +280,7 @@ template <typename T> constexpr int paneldiag_lds_bytes() { return std::max(pane
 template <typename T> constexpr int paneldiag_mid_lds_bytes() {
   return mid_fat<T, true>() ? std::max(paneldiag_lds_bytes<T>(), potf2_lds_elems<T>() * (int)sizeof(T)) : paneldiag_lds_bytes<T>();
 }
+static_assert(!kF32Bf16x6 || (bx_z_offset<true>() + TS) * 4 <= paneldiag_mid_lds_bytes<float>(), "mid-size build: the two plane buffers do not fit its LDS");
 // the deep loop's chunk ring + z of one block column must fit what the mid-size build's launches carry
 static_assert(deep_ring<float, true>() * KT * LDST * 4 + TS * 4 <= paneldiag_mid_lds_bytes<float>() &&
               deep_ring<double, true>() * KT * LDST * 8 + TS * 8 <= paneldiag_mid_lds_bytes<double>(), "mid-size build: ring does not fit its LDS");

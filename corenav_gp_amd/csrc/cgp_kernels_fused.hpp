@@ -156,9 +156,13 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
 // during the products.  Terms are added smallest first.
 // --------------------------------------------------------------------------------------------------
 #ifndef CGP_F32_BF16X6
-#define CGP_F32_BF16X6 0
+#define CGP_F32_BF16X6 1
 #endif
 constexpr bool kF32Bf16x6 = CGP_F32_BF16X6 != 0;
+#ifndef CGP_BX_MID_SETS
+#define CGP_BX_MID_SETS 4
+#endif
+constexpr int kBxMidSets = CGP_BX_MID_SETS;   // chunks in flight (register sets) of the mid-size build's bf16-plane loop
 constexpr int BXS = 16;                      // bf16 elements per staged row (32 bytes, no padding: the two 16-byte halves are swizzled instead)
 constexpr int BX_PLANE = TS * BXS;           // bf16 elements of one plane of one panel
 constexpr int BX_FLOATS = 6 * BX_PLANE / 2;  // floats the six planes occupy
@@ -202,14 +206,14 @@ __device__ __forceinline__ void bx_split_store(const float (&x)[8], unsigned sho
     *reinterpret_cast<bxu4 *>(plane0 + pl * BX_PLANE + off) = v;
   }
 }
-struct BxStage {   // what a thread stages per chunk: row (tid & 127) of both panels, columns 8 (tid >> 7) .. + 7
+template <int D> struct BxStage {   // what a thread stages per chunk: row (tid & 127) of both panels, columns 8 (tid >> 7) .. + 7; D chunks in flight
   // buffer loads: the row of the chunk goes into the scalar offset, the lane's place in it is a constant VGPR -- no per-load
   // address arithmetic on the VALU, which the split already fills
   __amdgpu_buffer_rsrc_t rR, rC;
   int ldR4, ldC4;         // leading dimensions in bytes
   int vR, vC;             // this lane's byte offset inside a chunk
   int offR, offC;         // where its 8 values go in a plane
-  float xr[8], xc[8];
+  float xr[D][8], xc[D][8];
   float pz = 0.f, pv = 0.f;   // running V z and V^2 of this thread's row over its 8 of every 16 columns (newest block column only)
   __device__ __forceinline__ void init(const float *gR, size_t ldR, const float *gC, size_t ldC, int nchunk, int tid) {
     const int r = tid & (TS - 1), h = tid >> 7;
@@ -223,24 +227,24 @@ struct BxStage {   // what a thread stages per chunk: row (tid & 127) of both pa
     offR = bx_pos(bx_row_slot(r), h);
     offC = bx_pos(r, h);
   }
-  __device__ __forceinline__ void load(int chunk) {
+  template <int S> __device__ __forceinline__ void load(int chunk) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, vR, (chunk * KT + i) * ldR4, 0));
-      xc[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rC, vC, (chunk * KT + i) * ldC4, 0));
+      xr[S][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, vR, (chunk * KT + i) * ldR4, 0));
+      xc[S][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rC, vC, (chunk * KT + i) * ldC4, 0));
     }
   }
-  __device__ __forceinline__ void store(float *smem, const float *z8 = nullptr) {
-    unsigned short *sp = reinterpret_cast<unsigned short *>(smem);
+  template <int S> __device__ __forceinline__ void store(float *planes, const float *z8 = nullptr) {
+    unsigned short *sp = reinterpret_cast<unsigned short *>(planes);
     if (z8) {   // wave-uniform address: one broadcast read
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        pz = __builtin_fmaf(xr[i], z8[i], pz);
-        pv = __builtin_fmaf(xr[i], xr[i], pv);
+        pz = __builtin_fmaf(xr[S][i], z8[i], pz);
+        pv = __builtin_fmaf(xr[S][i], xr[S][i], pv);
       }
     }
-    bx_split_store(xr, sp, offR);
-    bx_split_store(xc, sp + 3 * BX_PLANE, offC);
+    bx_split_store(xr[S], sp, offR);
+    bx_split_store(xc[S], sp + 3 * BX_PLANE, offC);
   }
 };
 // One chunk of products out of the planes.  The full-rate bf16 MFMA of gfx950 is the K = 32 form (v_mfma_f32_16x16x32_bf16: 16
@@ -286,10 +290,33 @@ __device__ __forceinline__ void bx6_compute(Prec<float>::acc_t (&acc)[NCB][2], c
     }
   }
 }
-// `st` arrives with chunk 0 in its registers (loaded before the Gram phase).  One register set: the next chunk's loads are issued
-// before the products of the current one and consumed after them (three workgroups per CU cover the rest of the latency); a
-// second set spilled (168 VGPRs at three per CU), and a spill's scratch traffic drains the load queue at every reload.
-__device__ __forceinline__ void bx6_loop(Prec<float>::acc_t (&acc)[NCB][2], BxStage &st, int nchunk, float *smem, int tid, const float *zs, float *ms,
+// `st` arrives with chunks 0 .. D - 1 in flight (bx6_prologue, before the Gram phase); set c % D holds chunk c.  D = 1, one plane
+// buffer, two barriers per chunk: the full-batch build (three workgroups per CU cover the rest of the latency; a second set would
+// spill -- 168 VGPRs -- and a spill's scratch traffic drains the load queue at every reload; a second plane buffer measured the
+// same).  D = 4, two plane buffers, one barrier per chunk: the mid-size build, whose CUs hold one or two workgroups (chunk c + 1 is
+// split into the buffer chunk c - 1 was read from, which every wave left before the barrier of iteration c; the Gram inputs lie
+// over buffer 1, first overwritten after the barrier of iteration 0).
+template <int D> __device__ __forceinline__ void bx6_prologue(BxStage<D> &st, int nchunk) {
+  static_assert(D == 1 || D == 2 || D == 4, "register sets");
+  if (0 < nchunk) st.template load<0>(0);
+  if (D > 1 && 1 < nchunk) st.template load<1 % D>(1);
+  if (D > 2 && 2 < nchunk) st.template load<2 % D>(2);
+  if (D > 2 && 3 < nchunk) st.template load<3 % D>(3);
+}
+template <int D, bool DBL, int S>   // S = c % D: the set the split of chunk c emptied takes chunk c + D
+__device__ __forceinline__ void bx6_iter(Prec<float>::acc_t (&acc)[NCB][2], BxStage<D> &st, int c, int nchunk, float *smem, const unsigned short *const (&pa)[2],
+                                         const unsigned short *const (&pb)[2], int hi, const float *zs, int zfirst, int h8, bool live) {
+  if (c + D < nchunk) st.template load<S>(c + D);
+  lds_barrier();                         // chunk c is in its planes (DBL: and chunk c - 1 is done with)
+  const int bo = DBL ? (c & 1) * 6 * BX_PLANE : 0;
+  const unsigned short *const qa[2] = {pa[0] + bo, pa[1] + bo}, *const qb[2] = {pb[0] + bo, pb[1] + bo};
+  if (live) bx6_compute(acc, qa, qb, hi);
+  if (!DBL) lds_barrier();               // every wave is done with it
+  if (c + 1 < nchunk)
+    st.template store<(S + 1) % D>(smem + (DBL ? ((c + 1) & 1) * BX_FLOATS : 0), (zs && c + 1 >= zfirst) ? zs + (c + 1 - zfirst) * KT + h8 : nullptr);
+}
+template <int D, bool DBL>
+__device__ __forceinline__ void bx6_loop(Prec<float>::acc_t (&acc)[NCB][2], BxStage<D> &st, int nchunk, float *smem, int tid, const float *zs, float *ms,
                                          bool live) {
   if (nchunk <= 0) return;
   const unsigned short *sp = reinterpret_cast<const unsigned short *>(smem);
@@ -300,13 +327,12 @@ __device__ __forceinline__ void bx6_loop(Prec<float>::acc_t (&acc)[NCB][2], BxSt
   const unsigned short *const pb[2] = {sp + bx_pos(wave * 32 + l15, lq & 1), sp + bx_pos(wave * 32 + DB + l15, lq & 1)};
   const unsigned short *const pa[2] = {sp + 3 * BX_PLANE + bx_pos(l15, lq & 1), sp + 3 * BX_PLANE + bx_pos(DB + l15, lq & 1) - DB * BXS};
   const int h8 = 8 * __builtin_amdgcn_readfirstlane(tid >> 7), zfirst = nchunk - TS / KT;   // the newest block column = the last 8 chunks
-  st.store(smem, (zs && zfirst <= 0) ? zs + (0 - zfirst) * KT + h8 : nullptr);   // chunk 0
-  for (int c = 0; c < nchunk; ++c) {
-    if (c + 1 < nchunk) st.load(c + 1);
-    lds_barrier();                         // chunk c is in the planes
-    if (live) bx6_compute(acc, pa, pb, hi);
-    lds_barrier();                         // every wave is done with it
-    if (c + 1 < nchunk) st.store(smem, (zs && c + 1 >= zfirst) ? zs + (c + 1 - zfirst) * KT + h8 : nullptr);
+  st.template store<0>(smem, (zs && zfirst <= 0) ? zs + (0 - zfirst) * KT + h8 : nullptr);   // chunk 0
+  for (int c0 = 0; c0 < nchunk; c0 += D) {
+    bx6_iter<D, DBL, 0>(acc, st, c0, nchunk, smem, pa, pb, hi, zs, zfirst, h8, live);
+    if (D > 1 && c0 + 1 < nchunk) bx6_iter<D, DBL, 1 % D>(acc, st, c0 + 1, nchunk, smem, pa, pb, hi, zs, zfirst, h8, live);
+    if (D > 2 && c0 + 2 < nchunk) bx6_iter<D, DBL, 2 % D>(acc, st, c0 + 2, nchunk, smem, pa, pb, hi, zs, zfirst, h8, live);
+    if (D > 2 && c0 + 3 < nchunk) bx6_iter<D, DBL, 3 % D>(acc, st, c0 + 3, nchunk, smem, pa, pb, hi, zs, zfirst, h8, live);
   }
   __syncthreads();
   if (zs) {   // hand the row sums over in the layout the fp32 loop leaves them in: lanes 0-15 of wave w, rows 32 w + 2 lane + {0, 1}
@@ -607,6 +633,10 @@ __device__ __forceinline__ double exp_gen(double x, const ExpC &e) { return exp_
 __device__ __forceinline__ float exp_gen(float x, const ExpC &) { return __expf(fmaxf(x, -104.f)); }
 
 constexpr int GK = 12;  // augmented point length: MAXD coordinates, 2 norm slots, padded to a multiple of 4
+// floats in front of the newest block column's z in the bf16-plane loops: the plane buffer and the Gram inputs behind it, or (DBL) two
+// plane buffers, the Gram inputs over the second
+template <bool DBL> constexpr int bx_z_offset() { return DBL ? 2 * BX_FLOATS : BX_FLOATS + 2 * GK * TS + 3 * TS; }
+static_assert(2 * GK * TS + 3 * TS <= BX_FLOATS, "Gram inputs fit the second plane buffer");
 
 // acc <- -G, in registers (the MFMA loop then adds L L^T, so acc ends as -S).  The covariance exponent e_ij = -0.5 |a_i - b_j|^2 (+ log amplitude)
 // is itself an inner product of augmented points
@@ -1305,12 +1335,15 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
   const bool live = !(kSkipDeadWave && !DEEP && sizeof(T) == 4 && rt >= p.NT && !p.xid &&
                       (rt - p.NT) * TS + __builtin_amdgcn_readfirstlane(tid >> 6) * 32 > p.M);
   constexpr int R = DEEP ? deep_ring<T, MID>() : 4;   // chunk ring of the deep loop (the register-staged loop has two buffers)
-  constexpr bool BX6 = kF32Bf16x6 && !DEEP && sizeof(T) == 4;   // full-batch fp32: products on the bf16 matrix cores (bx6_loop)
-  constexpr int GRAM_OFF = BX6 ? BX_FLOATS : CH2;               // where the Gram inputs are staged
-  T *zs = smem + (BX6 ? BX_FLOATS + 2 * GK * TS + 3 * TS : R * KT * LDST);
+  // fp32, full-batch and mid-size builds: products on the bf16 matrix cores (bx6_loop); BXD chunks in flight, two plane buffers in the mid-size build
+  constexpr bool BX6 = kF32Bf16x6 && sizeof(T) == 4 && (!DEEP || MID);
+  constexpr bool BXDBL = DEEP;
+  constexpr int BXD = DEEP ? kBxMidSets : 1;
+  constexpr int GRAM_OFF = BX6 ? BX_FLOATS : CH2;               // where the Gram inputs are staged (BXDBL: over the second plane buffer)
+  T *zs = smem + (BX6 ? bx_z_offset<BXDBL>() : R * KT * LDST);
   if (tid < TS) zs[tid] = accm ? Lw[(size_t)((k - 1) * TS + tid) * ld + (size_t)p.NT * TS + p.M] : T(0);
   T ms[4] = {T(0), T(0), T(0), T(0)};
-  if constexpr (DEEP) {
+  if constexpr (DEEP && !BX6) {
     RowFrag<T, R> rf;
     {
       GramPre<T> gp;
@@ -1322,14 +1355,14 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
     pc.lap(p, ps + 0);
     mfma_rowpanel_loop_rdirect<T, R>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
   } else {
-    BxStage bxs;   // (only the bf16-plane build uses it)
+    BxStage<BXD> bxs;   // (only the bf16-plane build uses it)
     {
       GramPre<T> gp;
       if (!(MID && from_image)) gram_prefetch<T>(p, b, k, rt, tid, gp);
       if (nchunk > 0) {
         if constexpr (BX6) {
           bxs.init(gR, (size_t)ld, gC, (size_t)ld, nchunk, tid);
-          bxs.load(0);   // in flight through the Gram phase
+          bx6_prologue(bxs, nchunk);   // in flight through the Gram phase
         } else stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
       }
       if (CGP_DBG_ON(p, 16384)) {  // timing probe: no Gram tile
@@ -1343,7 +1376,7 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
       else gram_apply<T>(p, acc, smem + GRAM_OFF, b, k, rt, tid, gp, &pc, ps + 6, -1, live);
     }
     pc.lap(p, ps + 0);
-    if constexpr (BX6) bx6_loop(acc, bxs, nchunk, smem, tid, accm ? zs : nullptr, ms, live);
+    if constexpr (BX6) bx6_loop<BXD, BXDBL>(acc, bxs, nchunk, smem, tid, accm ? zs : nullptr, ms, live);
     else mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, accm ? zs : nullptr, ms, live);
   }
   pc.lap(p, ps + 1);
@@ -1407,7 +1440,7 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
 #endif
 constexpr int F32_FULL_OCC = CGP_F32_FULL_OCC;
 template <typename T, bool DIAGNEXT = false, bool DEEP = sizeof(T) == 8, bool MID = false>
-__global__ __launch_bounds__(256, sizeof(T) == 4 ? (DEEP ? ((MID && CGP_MID_RING > 4) ? 2 : 3) : F32_FULL_OCC) : 2) void k_panel(FitArgs p, int k) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? (DEEP ? ((MID && (CGP_MID_RING > 4 || CGP_F32_BF16X6)) ? 2 : 3) : F32_FULL_OCC) : 2) void k_panel(FitArgs p, int k) {
   using P = Prec<T>;
   using acc_t = typename P::acc_t;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
