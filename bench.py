@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix (= vector) peak; absent from the local
                                # guide, re-measured by tools/mfma_peak (see DESIGN.md "Measurement")
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak (same guide; the 2:1-sparsity headline figure is twice this)
 HBM_PEAK_GBPS = 8000.0         # same guide, "HBM3E peak BW" (spec)
 M_TEST = 599                   # gp_slip_node.py:45,59: arange(min, max+600)[n:] -> 599 points
 
@@ -464,6 +465,13 @@ class Workload:
                       "100 ms of untimed steps (not the timed steps: per-launch events serialise the launches)",
               "avg_launch_ms": upd["ms"] / max(upd["launches"], 1), "launches": upd["launches"],
               "algorithmic_flops_per_launch": upd["flops"] / max(upd["launches"], 1)}
+        if self.dts == "f32" and not (self.engine.load().cgp_build_flags() & self.engine.BUILD_F32_NATIVE):
+            # the fp32 tile loops run on the bf16 matrix cores (cgp_kernels_fused.hpp, bx6_compute): `peak` stays the fp32-input
+            # MFMA peak -- the instruction a plain fp32 kernel has -- and the bf16 form's own ceiling is stated beside it
+            rf["mfma_path"] = ("bf16x6: every fp32 product = six bf16 products (x = x0 + x1 + x2 by truncation), three K=32 bf16 MFMAs per "
+                               "16x16x16 block; results at fp32 rounding level (tests/fuzz/fuzz_parity.py)")
+            rf["bf16x6_bound_tflops"] = BF16_MFMA_PEAK_TFLOPS / 6.0
+            rf["frac_of_bf16x6_bound"] = achieved / (BF16_MFMA_PEAK_TFLOPS / 6.0)
         return rf, {k: v["ms"] / nprof for k, v in prof.items()}
 
 

@@ -1212,6 +1212,7 @@ int cgp_build_flags(void) {
 #ifdef CGP_AB
   f |= CGP_BUILD_AB;
 #endif
+  if (!kF32Bf16x6) f |= CGP_BUILD_F32_NATIVE;
   return f;
 }
 

@@ -143,17 +143,19 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
 }
 
 // --------------------------------------------------------------------------------------------------
-// fp32 products on the bf16 matrix cores (CGP_F32_BF16X6; the full-batch fp32 loop).  gfx950 runs an fp32-input MFMA at the
-// VECTOR rate -- 1/16 of the bf16 MFMA rate -- and has no xf32 form.  An fp32 value splits EXACTLY into three bf16 values by
-// truncation, x = x0 + x1 + x2 (8 + 8 + 8 mantissa bits, same exponent range), and
+// fp32 products on the bf16 matrix cores (CGP_F32_BF16X6, default on: the tile loops of the full-batch and mid-size fp32 builds).
+// gfx950 runs an fp32-input MFMA at the VECTOR rate -- 1/16 of the bf16 MFMA rate -- and has no xf32 form.  An fp32 value splits
+// EXACTLY into three bf16 values by truncation, x = x0 + x1 + x2 (8 + 8 + 8 mantissa bits, same exponent range), and
 //     a b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) + O(2^-24 |a b|)
-// so SIX bf16 MFMAs with fp32 accumulation reproduce the fp32 product to fp32's own rounding level (every partial product of two
-// 8-bit mantissas is exact in fp32; what is dropped -- a1 b2, a2 b1, a2 b2 -- is below 2^-24 relative) at 6/16 of the fp32 MFMA's time.
-// Per 16-column chunk and 16 x 16 block: 6 x v_mfma_f32_16x16x16_bf16 (8 cycles each) instead of 4 x v_mfma_f32_16x16x4_f32
-// (32 cycles each).  The split happens once, when a chunk is staged: three bf16 planes per panel in LDS, rows padded to 24
-// elements (48 bytes: a wave's 8-byte fragment reads hit 64 distinct banks).  One chunk buffer, two LDS barriers per chunk
-// (six planes are 36 KB; a second buffer would leave two workgroups per CU); the next chunk's global loads are in flight
-// during the products.  Terms are added smallest first.
+// so SIX bf16 products with fp32 accumulation reproduce the fp32 product to fp32's own rounding level (every partial product of two
+// 8-bit mantissas is exact in fp32; what is dropped -- a1 b2, a2 b1, a2 b2 -- is below 2^-24 relative).  Terms are added smallest
+// first.  The split happens once, when a chunk is staged: three bf16 planes per panel in LDS (bx_pos: unpadded 32-byte rows, halves
+// swizzled); bx6_compute pairs the terms into three K = 32 MFMAs per 16 x 16 block (48 cycles against the fp32 form's 128).
+// Measured (round 5, configs[3], 512 fits): 104 k -> 123 k fits/s; the 64-fit call 0.89 -> 0.73 ms.  What bounds the loops now is
+// HBM: a 128 x 128 tile reads two 128 x K panels for 2 x 128 x 128 x K flops -- 32 flop per byte, 64 with the column panel served by
+// L2 -- and the panel launches run at 3.2-3.3 TB/s (profiles/r05_pmc_summary_f32.json) of the ~6.3 TB/s a streaming kernel reaches:
+// a second register set, an L2 prefetch three chunks ahead, a second plane buffer and the row panel loaded straight into B-operand
+// registers were each measured and none was faster (docs/negatives.md, round 5).
 // --------------------------------------------------------------------------------------------------
 #ifndef CGP_F32_BF16X6
 #define CGP_F32_BF16X6 1
@@ -262,33 +264,105 @@ __device__ __forceinline__ void bx6_compute(Prec<float>::acc_t (&acc)[NCB][2], c
   const int p01 = hi ? BX_PLANE : 0, p02 = hi ? 2 * BX_PLANE : 0;          // [x0 | x1], [x0 | x2]
   const int p10 = hi ? 0 : BX_PLANE, p20 = hi ? 0 : 2 * BX_PLANE;          // [x1 | x0], [x2 | x0]
   // pass 1: the smallest pair of terms, [a0 | a2] . [b2 | b0]; pass 2: [a0 | a1] . [b1 | b0] and [a0 | a1] . [b0 | b1].  Two passes
-  // so that only the B operands of a pass are live (8 / 16 VGPRs instead of 24): at three workgroups per CU the kernel has 168.
-  {
-    const bf8 b20[2] = {bx_ld8(pb[0] + p20), bx_ld8(pb[1] + p20)};
+  // so that only the B operands of a pass are live.  The A operands are read one pair of column blocks AHEAD of the pair being
+  // multiplied (the mid-size build has one wave per SIMD: nobody else covers an LDS read issued right in front of its MFMA).
+  bf8 a[2][2];
+  a[0][0] = bx_ld8(pa[0] + p02);
+  a[0][1] = bx_ld8(pa[1] + p02 + DB * BXS);
+  const bf8 b20[2] = {bx_ld8(pb[0] + p20), bx_ld8(pb[1] + p20)};
+  bf8 b10[2], b01[2];
 #pragma unroll
-    for (int cb = 0; cb < NCB; cb += 2) {
-      const bf8 a0 = bx_ld8(pa[0] + p02 + cb * DB * BXS), a1 = bx_ld8(pa[1] + p02 + (cb + 1) * DB * BXS);
-      acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b20[0], acc[cb][0], 0, 0, 0);
-      acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b20[1], acc[cb][1], 0, 0, 0);
-      acc[cb + 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b20[0], acc[cb + 1][0], 0, 0, 0);
-      acc[cb + 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b20[1], acc[cb + 1][1], 0, 0, 0);
+  for (int cb = 0; cb < NCB; cb += 2) {
+    const int u = (cb >> 1) & 1;
+    if (cb + 2 < NCB) {
+      a[u ^ 1][0] = bx_ld8(pa[0] + p02 + (cb + 2) * DB * BXS);
+      a[u ^ 1][1] = bx_ld8(pa[1] + p02 + (cb + 3) * DB * BXS);
+    } else {   // the first pair of pass 2 and its B operands
+      a[u ^ 1][0] = bx_ld8(pa[0] + p01);
+      a[u ^ 1][1] = bx_ld8(pa[1] + p01 + DB * BXS);
+      b10[0] = bx_ld8(pb[0] + p10);
+      b10[1] = bx_ld8(pb[1] + p10);
+      b01[0] = bx_ld8(pb[0] + p01);
+      b01[1] = bx_ld8(pb[1] + p01);
     }
+    acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][0], b20[0], acc[cb][0], 0, 0, 0);
+    acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][0], b20[1], acc[cb][1], 0, 0, 0);
+    acc[cb + 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][1], b20[0], acc[cb + 1][0], 0, 0, 0);
+    acc[cb + 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][1], b20[1], acc[cb + 1][1], 0, 0, 0);
   }
-  {
-    const bf8 b10[2] = {bx_ld8(pb[0] + p10), bx_ld8(pb[1] + p10)}, b01[2] = {bx_ld8(pb[0] + p01), bx_ld8(pb[1] + p01)};
 #pragma unroll
-    for (int cb = 0; cb < NCB; cb += 2) {
-      const bf8 a0 = bx_ld8(pa[0] + p01 + cb * DB * BXS), a1 = bx_ld8(pa[1] + p01 + (cb + 1) * DB * BXS);
-      acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b10[0], acc[cb][0], 0, 0, 0);
-      acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b10[1], acc[cb][1], 0, 0, 0);
-      acc[cb + 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b10[0], acc[cb + 1][0], 0, 0, 0);
-      acc[cb + 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b10[1], acc[cb + 1][1], 0, 0, 0);
-      acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b01[0], acc[cb][0], 0, 0, 0);
-      acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b01[1], acc[cb][1], 0, 0, 0);
-      acc[cb + 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b01[0], acc[cb + 1][0], 0, 0, 0);
-      acc[cb + 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b01[1], acc[cb + 1][1], 0, 0, 0);
+  for (int cb = 0; cb < NCB; cb += 2) {
+    const int u = (cb >> 1) & 1;   // (pass 1 left the first pair of pass 2 in a[0])
+    if (cb + 2 < NCB) {
+      a[u ^ 1][0] = bx_ld8(pa[0] + p01 + (cb + 2) * DB * BXS);
+      a[u ^ 1][1] = bx_ld8(pa[1] + p01 + (cb + 3) * DB * BXS);
     }
+    acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][0], b10[0], acc[cb][0], 0, 0, 0);
+    acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][0], b10[1], acc[cb][1], 0, 0, 0);
+    acc[cb + 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][1], b10[0], acc[cb + 1][0], 0, 0, 0);
+    acc[cb + 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][1], b10[1], acc[cb + 1][1], 0, 0, 0);
+    acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][0], b01[0], acc[cb][0], 0, 0, 0);
+    acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][0], b01[1], acc[cb][1], 0, 0, 0);
+    acc[cb + 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][1], b01[0], acc[cb + 1][0], 0, 0, 0);
+    acc[cb + 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][1], b01[1], acc[cb + 1][1], 0, 0, 0);
   }
+}
+// The same products for a workgroup that has its CU to itself (mid-size build: one wave per SIMD, nobody else to cover an LDS read
+// issued right in front of its MFMA -- which is where the compiler puts every one of them, re-using one register quad).  Reads and
+// waits are written out: up to three pairs of A operands in flight, `s_waitcnt lgkmcnt` counted by hand (LDS reads return in
+// order; the "+v" operands tie each wait to the MFMAs that consume what it waited for).
+__device__ __forceinline__ bxu4 bx_rd(unsigned addr, int off) {
+  bxu4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+  return v;
+}
+#define BX_WAIT2(n, x, y) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(n))
+#define BX_WAIT4(n, x, y, z, w) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "n"(n))
+#define BX_WAIT6(n, x, y, z, w, u, t) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(x), "+v"(y), "+v"(z), "+v"(w), "+v"(u), "+v"(t) : "n"(n))
+__device__ __forceinline__ void bx_mm4(Prec<float>::acc_t (&acc)[NCB][2], int cb, const bxu4 &a0, const bxu4 &a1, const bxu4 &b0, const bxu4 &b1) {
+  const bf8 x0 = __builtin_bit_cast(bf8, a0), x1 = __builtin_bit_cast(bf8, a1), y0 = __builtin_bit_cast(bf8, b0), y1 = __builtin_bit_cast(bf8, b1);
+  acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, y0, acc[cb][0], 0, 0, 0);
+  acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, y1, acc[cb][1], 0, 0, 0);
+  acc[cb + 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, y0, acc[cb + 1][0], 0, 0, 0);
+  acc[cb + 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, y1, acc[cb + 1][1], 0, 0, 0);
+}
+template <int BO>   // BO: byte offset of the plane buffer
+__device__ __forceinline__ void bx6_compute_pipe(Prec<float>::acc_t (&acc)[NCB][2], const unsigned (&la)[2], const unsigned (&lb)[2], int hi) {
+  constexpr int PB = 2 * BX_PLANE, CBB = 2 * DB * BXS;   // bytes of a plane, of a column block
+  // the plane a lane reads is part of its address: [x0 | x2] / [x0 | x1] for A, [x2 | x0] / [x1 | x0] / [x0 | x1] for B
+  const unsigned a2[2] = {la[0] + (hi ? 2 * PB : 0), la[1] + (hi ? 2 * PB : 0)}, a1[2] = {la[0] + (hi ? PB : 0), la[1] + (hi ? PB : 0)};
+  const unsigned q20[2] = {lb[0] + (hi ? 0 : 2 * PB), lb[1] + (hi ? 0 : 2 * PB)}, q10[2] = {lb[0] + (hi ? 0 : PB), lb[1] + (hi ? 0 : PB)};
+  const unsigned q01[2] = {lb[0] + (hi ? PB : 0), lb[1] + (hi ? PB : 0)};
+  bxu4 b20a = bx_rd(q20[0], BO), b20b = bx_rd(q20[1], BO);
+  bxu4 p0 = bx_rd(a2[0], BO + 0 * CBB), p1 = bx_rd(a2[1], BO + 1 * CBB);
+  bxu4 p2 = bx_rd(a2[0], BO + 2 * CBB), p3 = bx_rd(a2[1], BO + 3 * CBB);
+  bxu4 p4 = bx_rd(a2[0], BO + 4 * CBB), p5 = bx_rd(a2[1], BO + 5 * CBB);
+  BX_WAIT4(4, b20a, b20b, p0, p1);
+  bx_mm4(acc, 0, p0, p1, b20a, b20b);
+  bxu4 p6 = bx_rd(a2[0], BO + 6 * CBB), p7 = bx_rd(a2[1], BO + 7 * CBB);
+  BX_WAIT2(4, p2, p3);
+  bx_mm4(acc, 2, p2, p3, b20a, b20b);
+  bxu4 b10a = bx_rd(q10[0], BO), b10b = bx_rd(q10[1], BO), b01a = bx_rd(q01[0], BO), b01b = bx_rd(q01[1], BO);
+  bxu4 r0 = bx_rd(a1[0], BO + 0 * CBB), r1 = bx_rd(a1[1], BO + 1 * CBB);
+  BX_WAIT2(8, p4, p5);
+  bx_mm4(acc, 4, p4, p5, b20a, b20b);
+  bxu4 r2 = bx_rd(a1[0], BO + 2 * CBB), r3 = bx_rd(a1[1], BO + 3 * CBB);
+  BX_WAIT2(8, p6, p7);
+  bx_mm4(acc, 6, p6, p7, b20a, b20b);
+  bxu4 r4 = bx_rd(a1[0], BO + 4 * CBB), r5 = bx_rd(a1[1], BO + 5 * CBB);
+  BX_WAIT6(4, b10a, b10b, b01a, b01b, r0, r1);
+  bx_mm4(acc, 0, r0, r1, b10a, b10b);
+  bx_mm4(acc, 0, r0, r1, b01a, b01b);
+  bxu4 r6 = bx_rd(a1[0], BO + 6 * CBB), r7 = bx_rd(a1[1], BO + 7 * CBB);
+  BX_WAIT2(4, r2, r3);
+  bx_mm4(acc, 2, r2, r3, b10a, b10b);
+  bx_mm4(acc, 2, r2, r3, b01a, b01b);
+  BX_WAIT2(2, r4, r5);
+  bx_mm4(acc, 4, r4, r5, b10a, b10b);
+  bx_mm4(acc, 4, r4, r5, b01a, b01b);
+  BX_WAIT2(0, r6, r7);
+  bx_mm4(acc, 6, r6, r7, b10a, b10b);
+  bx_mm4(acc, 6, r6, r7, b01a, b01b);
 }
 // `st` arrives with chunks 0 .. D - 1 in flight (bx6_prologue, before the Gram phase); set c % D holds chunk c.  D = 1, one plane
 // buffer, two barriers per chunk: the full-batch build (three workgroups per CU cover the rest of the latency; a second set would
@@ -298,19 +372,24 @@ __device__ __forceinline__ void bx6_compute(Prec<float>::acc_t (&acc)[NCB][2], c
 // over buffer 1, first overwritten after the barrier of iteration 0).
 template <int D> __device__ __forceinline__ void bx6_prologue(BxStage<D> &st, int nchunk) {
   static_assert(D == 1 || D == 2 || D == 4, "register sets");
-  if (0 < nchunk) st.template load<0>(0);
-  if (D > 1 && 1 < nchunk) st.template load<1 % D>(1);
-  if (D > 2 && 2 < nchunk) st.template load<2 % D>(2);
-  if (D > 2 && 3 < nchunk) st.template load<3 % D>(3);
+  st.template load<0>(0);
+  if (D > 1) st.template load<1 % D>(1);
+  if (D > 2) st.template load<2 % D>(2);
+  if (D > 2) st.template load<3 % D>(3);
 }
 template <int D, bool DBL, int S>   // S = c % D: the set the split of chunk c emptied takes chunk c + D
 __device__ __forceinline__ void bx6_iter(Prec<float>::acc_t (&acc)[NCB][2], BxStage<D> &st, int c, int nchunk, float *smem, const unsigned short *const (&pa)[2],
                                          const unsigned short *const (&pb)[2], int hi, const float *zs, int zfirst, int h8, bool live) {
-  if (c + D < nchunk) st.template load<S>(c + D);
+  // UNCONDITIONAL: past the last chunk the buffer descriptor's bound answers with zeros and no memory access.  A load behind a branch
+  // is one the compiler cannot count on when it computes the vmcnt of an OLDER load's wait -- every wait then drained the queue
+  // (vmcnt(0) at each split: one chunk in flight however many sets there were).
+  st.template load<S>(c + D);
   lds_barrier();                         // chunk c is in its planes (DBL: and chunk c - 1 is done with)
-  const int bo = DBL ? (c & 1) * 6 * BX_PLANE : 0;
-  const unsigned short *const qa[2] = {pa[0] + bo, pa[1] + bo}, *const qb[2] = {pb[0] + bo, pb[1] + bo};
-  if (live) bx6_compute(acc, qa, qb, hi);
+  if constexpr (DBL) {   // (the set index and the buffer of a chunk have the same parity: D is even)
+    static_assert(!DBL || D % 2 == 0, "plane buffer by set parity");
+    const unsigned la[2] = {(unsigned)(size_t)pa[0], (unsigned)(size_t)pa[1]}, lb[2] = {(unsigned)(size_t)pb[0], (unsigned)(size_t)pb[1]};
+    if (live) bx6_compute_pipe<(S & 1) * 12 * BX_PLANE>(acc, la, lb, hi);
+  } else if (live) bx6_compute(acc, pa, pb, hi);
   if (!DBL) lds_barrier();               // every wave is done with it
   if (c + 1 < nchunk)
     st.template store<(S + 1) % D>(smem + (DBL ? ((c + 1) & 1) * BX_FLOATS : 0), (zs && c + 1 >= zfirst) ? zs + (c + 1 - zfirst) * KT + h8 : nullptr);
@@ -328,11 +407,11 @@ __device__ __forceinline__ void bx6_loop(Prec<float>::acc_t (&acc)[NCB][2], BxSt
   const unsigned short *const pa[2] = {sp + 3 * BX_PLANE + bx_pos(l15, lq & 1), sp + 3 * BX_PLANE + bx_pos(DB + l15, lq & 1) - DB * BXS};
   const int h8 = 8 * __builtin_amdgcn_readfirstlane(tid >> 7), zfirst = nchunk - TS / KT;   // the newest block column = the last 8 chunks
   st.template store<0>(smem, (zs && zfirst <= 0) ? zs + (0 - zfirst) * KT + h8 : nullptr);   // chunk 0
-  for (int c0 = 0; c0 < nchunk; c0 += D) {
+  for (int c0 = 0; c0 < nchunk; c0 += D) {   // nchunk is a multiple of 8 (whole block columns): the body is straight-line code
     bx6_iter<D, DBL, 0>(acc, st, c0, nchunk, smem, pa, pb, hi, zs, zfirst, h8, live);
-    if (D > 1 && c0 + 1 < nchunk) bx6_iter<D, DBL, 1 % D>(acc, st, c0 + 1, nchunk, smem, pa, pb, hi, zs, zfirst, h8, live);
-    if (D > 2 && c0 + 2 < nchunk) bx6_iter<D, DBL, 2 % D>(acc, st, c0 + 2, nchunk, smem, pa, pb, hi, zs, zfirst, h8, live);
-    if (D > 2 && c0 + 3 < nchunk) bx6_iter<D, DBL, 3 % D>(acc, st, c0 + 3, nchunk, smem, pa, pb, hi, zs, zfirst, h8, live);
+    if (D > 1) bx6_iter<D, DBL, 1 % D>(acc, st, c0 + 1, nchunk, smem, pa, pb, hi, zs, zfirst, h8, live);
+    if (D > 2) bx6_iter<D, DBL, 2 % D>(acc, st, c0 + 2, nchunk, smem, pa, pb, hi, zs, zfirst, h8, live);
+    if (D > 2) bx6_iter<D, DBL, 3 % D>(acc, st, c0 + 3, nchunk, smem, pa, pb, hi, zs, zfirst, h8, live);
   }
   __syncthreads();
   if (zs) {   // hand the row sums over in the layout the fp32 loop leaves them in: lanes 0-15 of wave w, rows 32 w + 2 lane + {0, 1}

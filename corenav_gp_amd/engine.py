@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CGP_LIB") or os.path.join(_HERE, "libcorenav_gp.so")
 DEBUG_SLOTS = 512
 ABI_VERSION = 2   # include/corenav_gp.h CGP_ABI_VERSION: load() refuses a library of another revision
-BUILD_ABLATION, BUILD_AB = 1, 2
+BUILD_ABLATION, BUILD_AB, BUILD_F32_NATIVE = 1, 2, 4
 STREAM_CTX = ctypes.c_void_p(-1).value   # CGP_STREAM_CTX: the context's private stream
 
 _dp = ctypes.POINTER(ctypes.c_double)
