@@ -79,7 +79,7 @@ int cgp_abi_version(void);
  * design, bench.py refuses to report such a build as a measurement.  CGP_BUILD_AB (-DCGP_AB): the
  * alternative schedules of DESIGN.md section 13 are compiled in and selectable by environment.
  * CGP_BUILD_F32_NATIVE (-DCGP_F32_BF16X6=0): the fp32 tile loops use the fp32-input MFMA instead of the shipped form (every
- * fp32 product as six bf16 products on the bf16 matrix cores, same fp32 rounding level: DESIGN.md section 6). */
+ * fp32 product as six bf16 products on the bf16 matrix cores, same fp32 rounding level: DESIGN.md section 4). */
 enum { CGP_BUILD_ABLATION = 1, CGP_BUILD_AB = 2, CGP_BUILD_F32_NATIVE = 4 };
 int cgp_build_flags(void);
 /* Blocks until everything enqueued on the context's private stream has finished. */
