@@ -165,6 +165,10 @@ constexpr bool kF32Bf16x6 = CGP_F32_BF16X6 != 0;
 #define CGP_BX_MID_SETS 4
 #endif
 constexpr int kBxMidSets = CGP_BX_MID_SETS;   // chunks in flight (register sets) of the mid-size build's bf16-plane loop
+#ifndef CGP_BX_TRI
+#define CGP_BX_TRI 1
+#endif
+constexpr bool kBxTri = CGP_BX_TRI != 0;      // the diagonal-tile update of the deep fp32 builds on the bf16 matrix cores too
 constexpr int BXS = 16;                      // bf16 elements per staged row (32 bytes, no padding: the two 16-byte halves are swizzled instead)
 constexpr int BX_PLANE = TS * BXS;           // bf16 elements of one plane of one panel
 constexpr int BX_FLOATS = 6 * BX_PLANE / 2;  // floats the six planes occupy
@@ -316,6 +320,7 @@ __device__ __forceinline__ bxu4 bx_rd(unsigned addr, int off) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
   return v;
 }
+__device__ __forceinline__ void bx_tie(bxu4 &x) { asm volatile("" : "+v"(x)); }   // a use of x stays behind the (volatile) wait in front of this
 #define BX_WAIT2(n, x, y) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(n))
 #define BX_WAIT4(n, x, y, z, w) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "n"(n))
 #define BX_WAIT6(n, x, y, z, w, u, t) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(x), "+v"(y), "+v"(z), "+v"(w), "+v"(u), "+v"(t) : "n"(n))
@@ -704,6 +709,112 @@ template <typename T, bool DEEP = sizeof(T) == 8>
 __device__ __forceinline__ void tri_prologue(const T *gR, size_t ldR, int nchunk, T *smem, int tid) {
   if (nchunk > 0) stage_chunk_tri<T, DEEP>(gR, ldR, 0, smem + tri_buf(0), tid);
   if (DEEP && nchunk > 1) stage_chunk_tri<T, DEEP>(gR, ldR, 1, smem + tri_buf(1), tid);
+}
+
+// --------------------------------------------------------------------------------------------------
+// The triangular (diagonal-tile) update on the bf16 matrix cores -- bx6_loop's arithmetic (see there) for mfma_syrk_tri_loop's
+// accumulator layout, for the builds whose diagonal tiles sit on the critical path of a block step (mid-size fp32: kind A's
+// finish is 16 chunks behind the tile it has just stored, a lone workgroup on its CU).  One panel, three planes per chunk
+// buffer, two buffers, D chunks in flight in registers (unconditional buffer loads, zeros past the end), one barrier per chunk.
+// Row block rb's [x0 | x1] B operand is the [x0 | x1] A operand of column block rb: 2 + (RB1 + 1) + 2 + (RB1 + 1) reads of 16
+// bytes per lane and chunk for 27 MFMAs (9 blocks x 3), issued ahead of the MFMAs with hand-counted waits (bx6_compute_pipe).
+// --------------------------------------------------------------------------------------------------
+constexpr int BXT_FLOATS = 3 * BX_PLANE / 2;   // floats of one triangular chunk buffer (three planes)
+template <int D> struct BxTriStage {
+  __amdgpu_buffer_rsrc_t rR;
+  int ldR4, vR, offR;
+  float xr[D][8];
+  __device__ __forceinline__ void init(const float *gR, size_t ldR, int nchunk, int tid) {
+    const int r = tid & (TS - 1), h = tid >> 7;
+    rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gR), 0, (int)(((size_t)(nchunk > 0 ? nchunk : 0) * KT * ldR) * sizeof(float)), 0x00020000);
+    ldR4 = (int)ldR * 4;
+    vR = 4 * r + 8 * h * ldR4;
+    offR = bx_pos(r, h);
+  }
+  template <int S> __device__ __forceinline__ void load(int chunk) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xr[S][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, vR, (chunk * KT + i) * ldR4, 0));
+  }
+  template <int S> __device__ __forceinline__ void store(float *planes) { bx_split_store(xr[S], reinterpret_cast<unsigned short *>(planes), offR); }
+};
+template <int D> __device__ __forceinline__ void bx6_tri_prologue(BxTriStage<D> &st) {
+  static_assert(D == 2 || D == 4, "register sets (the plane buffer of a chunk follows the parity of its set)");
+  st.template load<0>(0);
+  st.template load<1>(1);
+  if (D > 2) st.template load<2 % D>(2);
+  if (D > 2) st.template load<3 % D>(3);
+}
+template <int W, int BO>
+__device__ __forceinline__ void bx6_tri_compute(Prec<float>::acc_t (&acc)[NCB][2], const unsigned (&e)[2], bool hi) {
+  constexpr int RB0 = W, RB1 = NCB - 1 - W, PB = 2 * BX_PLANE, CBB = 2 * DB * BXS;
+  const unsigned o02 = hi ? 2 * PB : 0, o01 = hi ? PB : 0, o20 = hi ? 0 : 2 * PB, o10 = hi ? 0 : PB;
+  bxu4 a02[RB1 + 1], a01[RB1 + 1];
+  bxu4 b20[2] = {bx_rd(e[RB0 & 1] + o20, BO + RB0 * CBB), bx_rd(e[RB1 & 1] + o20, BO + RB1 * CBB)};
+  static_for<0, RB1 + 1>([&](auto cc) {
+    constexpr int CB = decltype(cc)::value;
+    a02[CB] = bx_rd(e[CB & 1] + o02, BO + CB * CBB);
+  });
+  bxu4 b10[2] = {bx_rd(e[RB0 & 1] + o10, BO + RB0 * CBB), bx_rd(e[RB1 & 1] + o10, BO + RB1 * CBB)};
+  asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(b20[0]), "+v"(b20[1]));
+  static_for<0, RB1 + 1>([&](auto cc) { bx_tie(a02[decltype(cc)::value]); });
+  static_for<0, RB1 + 1>([&](auto cc) {
+    constexpr int CB = decltype(cc)::value;
+    a01[CB] = bx_rd(e[CB & 1] + o01, BO + CB * CBB);
+  });
+  const bf8 c20[2] = {__builtin_bit_cast(bf8, b20[0]), __builtin_bit_cast(bf8, b20[1])};
+  static_for<0, RB1 + 1>([&](auto cc) {   // the smallest pair of terms first
+    constexpr int CB = decltype(cc)::value;
+    const bf8 a = __builtin_bit_cast(bf8, a02[CB]);
+    if constexpr (CB <= RB0) acc[CB][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, c20[0], acc[CB][0], 0, 0, 0);
+    acc[CB][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, c20[1], acc[CB][1], 0, 0, 0);
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b10[0]), "+v"(b10[1]));
+  static_for<0, RB1 + 1>([&](auto cc) { bx_tie(a01[decltype(cc)::value]); });
+  const bf8 c10[2] = {__builtin_bit_cast(bf8, b10[0]), __builtin_bit_cast(bf8, b10[1])};
+  const bf8 c01[2] = {__builtin_bit_cast(bf8, a01[RB0]), __builtin_bit_cast(bf8, a01[RB1])};   // [x0 | x1] of the row blocks
+  static_for<0, RB1 + 1>([&](auto cc) {
+    constexpr int CB = decltype(cc)::value;
+    const bf8 a = __builtin_bit_cast(bf8, a01[CB]);
+    if constexpr (CB <= RB0) acc[CB][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, c10[0], acc[CB][0], 0, 0, 0);
+    acc[CB][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, c10[1], acc[CB][1], 0, 0, 0);
+  });
+  static_for<0, RB1 + 1>([&](auto cc) {
+    constexpr int CB = decltype(cc)::value;
+    const bf8 a = __builtin_bit_cast(bf8, a01[CB]);
+    if constexpr (CB <= RB0) acc[CB][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, c01[0], acc[CB][0], 0, 0, 0);
+    acc[CB][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, c01[1], acc[CB][1], 0, 0, 0);
+  });
+}
+template <int D, int W, int S>   // S = c % D
+__device__ __forceinline__ void bx6_tri_iter(Prec<float>::acc_t (&acc)[NCB][2], BxTriStage<D> &st, int c, int nchunk, float *smem, const unsigned (&e)[2], bool hi) {
+  st.template load<S>(c + D);            // unconditional (bx6_iter)
+  lds_barrier();                         // chunk c is in its planes, chunk c - 1 is done with
+  bx6_tri_compute<W, (S & 1) * 6 * BX_PLANE>(acc, e, hi);
+  if (c + 1 < nchunk) st.template store<(S + 1) % D>(smem + ((S + 1) & 1) * BXT_FLOATS);
+}
+template <int D, int W>
+__device__ __forceinline__ void bx6_tri_wave(Prec<float>::acc_t (&acc)[NCB][2], BxTriStage<D> &st, int nchunk, float *smem, int tid) {
+  const int lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+  const unsigned base = (unsigned)(size_t)smem;
+  const unsigned e[2] = {base + 2 * bx_pos(l15, lq & 1), base + 2 * (bx_pos(DB + l15, lq & 1) - DB * BXS)};
+  st.template store<0>(smem);            // chunk 0
+  for (int c0 = 0; c0 < nchunk; c0 += D) {   // nchunk is a multiple of 8
+    bx6_tri_iter<D, W, 0>(acc, st, c0, nchunk, smem, e, lq >> 1);
+    bx6_tri_iter<D, W, 1>(acc, st, c0 + 1, nchunk, smem, e, lq >> 1);
+    if (D > 2) bx6_tri_iter<D, W, 2 % D>(acc, st, c0 + 2, nchunk, smem, e, lq >> 1);
+    if (D > 2) bx6_tri_iter<D, W, 3 % D>(acc, st, c0 + 3, nchunk, smem, e, lq >> 1);
+  }
+}
+template <int D>
+__device__ __forceinline__ void bx6_syrk_tri_loop(Prec<float>::acc_t (&acc)[NCB][2], BxTriStage<D> &st, int nchunk, float *smem, int tid) {
+  if (nchunk <= 0) return;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  switch (wave) {
+    case 0: bx6_tri_wave<D, 0>(acc, st, nchunk, smem, tid); break;
+    case 1: bx6_tri_wave<D, 1>(acc, st, nchunk, smem, tid); break;
+    case 2: bx6_tri_wave<D, 2>(acc, st, nchunk, smem, tid); break;
+    default: bx6_tri_wave<D, 3>(acc, st, nchunk, smem, tid); break;
+  }
 }
 
 // General exp (|x| small enough not to overflow): the covariance exponent with log(amplitude)
@@ -1163,16 +1274,24 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
   const int nchunk = c_last - c_first;
   const T *gR = Lw + (size_t)kn * TS + (size_t)c_first * KT * ld;
   T *img = reinterpret_cast<T *>(p.dpart) + ((size_t)b * img_slots(p) + kn % img_slots(p)) * DPART;
+  // fp32 builds with the deep loops (mid-size; the fat k_diag_lean): the update on the bf16 matrix cores (bx6_syrk_tri_loop)
+  // (the full-batch build keeps the fp32-input MFMA here: with this loop inlined its 168-VGPR kernel spilled 220 registers)
+  constexpr bool BXT = kF32Bf16x6 && kBxTri && sizeof(T) == 4 && TRI && DEEP;
+  BxTriStage<kBxMidSets> bxt;   // (only BXT uses it)
   {
     GramPre<T> gp;
     if (!from_image) gram_prefetch<T>(p, b, kn, kn, tid, gp);
-    if constexpr (TRI) tri_prologue<T, DEEP>(gR, (size_t)ld, nchunk, smem, tid);  // DEEP: DMA ring, 2 chunks ahead
+    if constexpr (BXT) {
+      bxt.init(gR, (size_t)ld, nchunk, tid);
+      bx6_tri_prologue(bxt);   // (nchunk = 0: the descriptor is empty, zeros without a memory access)
+    } else if constexpr (TRI) tri_prologue<T, DEEP>(gR, (size_t)ld, nchunk, smem, tid);  // DEEP: DMA ring, 2 chunks ahead
     else if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gR, (size_t)ld, smem, tid);
     if (from_image) acc_image<T, TRI, false>(acc, img, tid);
-    else gram_apply<T, TRI>(p, acc, smem + CH2, b, kn, kn, tid, gp);
+    else gram_apply<T, TRI>(p, acc, smem + (BXT ? BXT_FLOATS : CH2), b, kn, kn, tid, gp);   // BXT: behind plane buffer 0, over buffer 1
   }
   if (pc) pc->lap(p, 344);  // finisher: fence + image / Gram tile (measurement build; slots 344.. = all steps summed)
-  if constexpr (TRI) mfma_syrk_tri_loop<T, DEEP>(acc, gR, (size_t)ld, nchunk, smem, tid);
+  if constexpr (BXT) bx6_syrk_tri_loop(acc, bxt, nchunk, smem, tid);
+  else if constexpr (TRI) mfma_syrk_tri_loop<T, DEEP>(acc, gR, (size_t)ld, nchunk, smem, tid);
   else mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gR, (size_t)ld, nchunk, smem, tid);
   if (pc) pc->lap(p, 345);  // the two newest block columns
   if constexpr (MODE == DIAG_PARTIAL) {
