@@ -1634,7 +1634,9 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
 // mid-size build also takes the fat form of the diagonal tile (79 KB of LDS: two workgroups per CU, which these calls do
 // not fill anyway); fp64 would need 147 KB, one workgroup per CU, and keeps the packed form.
 #ifndef CGP_F32_FULL_OCC
-#define CGP_F32_FULL_OCC (CGP_F32_BF16X6 ? 3 : 4)   // workgroups per CU the register-staged fp32 build is compiled for (the bf16 planes: 51 KB of LDS, three fit)
+#define CGP_F32_FULL_OCC 4   // workgroups per CU the register-staged fp32 build is compiled for: 128 VGPRs -- the tile loop has none spilled (the
+                             // Gram / diagonal-tile code around it has: 85 in the fused kernel) -- and 38 KB of LDS; at three per CU (153 VGPRs, no
+                             // spill) the bf16-plane build measured 5 % slower (121.8 k against 127.9 k fits/s)
 #endif
 constexpr int F32_FULL_OCC = CGP_F32_FULL_OCC;
 template <typename T, bool DIAGNEXT = false, bool DEEP = sizeof(T) == 8, bool MID = false>
