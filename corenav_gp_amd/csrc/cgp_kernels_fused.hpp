@@ -148,8 +148,9 @@ __device__ __forceinline__ void mfma_rowpanel_loop(typename Prec<T>::acc_t (&acc
 // EXACTLY into three bf16 values by truncation, x = x0 + x1 + x2 (8 + 8 + 8 mantissa bits, same exponent range), and
 //     a b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) + O(2^-24 |a b|)
 // so SIX bf16 products with fp32 accumulation reproduce the fp32 product to fp32's own rounding level (every partial product of two
-// 8-bit mantissas is exact in fp32; what is dropped -- a1 b2, a2 b1, a2 b2 -- is below 2^-24 relative).  Terms are added smallest
-// first.  The split happens once, when a chunk is staged: three bf16 planes per panel in LDS (bx_pos: unpadded 32-byte rows, halves
+// 8-bit mantissas is exact in fp32; what is dropped -- a1 b2, a2 b1, a2 b2 -- is at most 2^-21, typically 2^-23 of |a b|: a 16-term
+// inner product comes out within 1.0-1.5 x the error of sixteen chained fp32 roundings, tests/test_bf16x6_split_cpu.py).  Terms are
+// added smallest first.  The split happens once, when a chunk is staged: three bf16 planes per panel in LDS (bx_pos: unpadded 32-byte rows, halves
 // swizzled); bx6_compute pairs the terms into three K = 32 MFMAs per 16 x 16 block (48 cycles against the fp32 form's 128).
 // Measured (round 5, configs[3], 512 fits): 104 k -> 123 k fits/s; the 64-fit call 0.89 -> 0.73 ms.  What bounds the loops now is
 // HBM: a 128 x 128 tile reads two 128 x K panels for 2 x 128 x 128 x K flops -- 32 flop per byte, 64 with the column panel served by
