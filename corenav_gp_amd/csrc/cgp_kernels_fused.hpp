@@ -166,6 +166,10 @@ constexpr bool kF32Bf16x6 = CGP_F32_BF16X6 != 0;
 #define CGP_BX_MID_SETS 4
 #endif
 constexpr int kBxMidSets = CGP_BX_MID_SETS;   // chunks in flight (register sets) of the mid-size build's bf16-plane loop
+#ifndef CGP_BX_TRMM
+#define CGP_BX_TRMM 1
+#endif
+constexpr bool kBxTrmm = CGP_BX_TRMM != 0;    // the in-register triangular product L = S W^T of the fp32 panel tiles on the bf16 matrix cores too
 #ifndef CGP_BX_TRI
 #define CGP_BX_TRI 1
 #endif
@@ -187,8 +191,7 @@ __device__ __forceinline__ int bx_row_slot(int r) { return (r & ~31) | ((r & 1) 
 // eight floats (consecutive k of one row) -> three planes of eight bf16 each, written as 16-byte rows.  Split by truncation:
 // x0 = the top 16 bits of x, x1 = the top 16 bits of x - x0, x2 = those of x - x0 - x1 (both differences exact); v_perm_b32 packs
 // the high halves of two words.
-__device__ __forceinline__ void bx_split_store(const float (&x)[8], unsigned short *plane0, int off) {
-  unsigned w[3][4];
+__device__ __forceinline__ void bx_split8(const float (&x)[8], bxu4 (&w)[3]) {
 #pragma unroll
   for (int i = 0; i < 8; i += 2) {
     unsigned hi[2][3];
@@ -206,12 +209,12 @@ __device__ __forceinline__ void bx_split_store(const float (&x)[8], unsigned sho
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) w[pl][i >> 1] = __builtin_amdgcn_perm(hi[1][pl], hi[0][pl], 0x07060302u);   // {hi[1] >> 16, hi[0] >> 16}
   }
+}
+__device__ __forceinline__ void bx_split_store(const float (&x)[8], unsigned short *plane0, int off) {
+  bxu4 w[3];
+  bx_split8(x, w);
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
-    bxu4 v;
-    v[0] = w[pl][0]; v[1] = w[pl][1]; v[2] = w[pl][2]; v[3] = w[pl][3];
-    *reinterpret_cast<bxu4 *>(plane0 + pl * BX_PLANE + off) = v;
-  }
+  for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bxu4 *>(plane0 + pl * BX_PLANE + off) = w[pl];
 }
 template <int D> struct BxStage {   // what a thread stages per chunk: row (tid & 127) of both panels, columns 8 (tid >> 7) .. + 7; D chunks in flight
   // buffer loads: the row of the chunk goes into the scalar offset, the lane's place in it is a constant VGPR -- no per-load
@@ -1429,6 +1432,95 @@ __device__ __forceinline__ void trmm_in_registers(const FitArgs &p, typename Pre
   }
 }
 
+// The same triangular product on the bf16 matrix cores (fp32 bf16-plane builds; see bx6_loop for the arithmetic).  A K = 32 MFMA
+// takes 8 k-values per lane: lane (l15, g) of the B operand supplies its OWN accumulator registers of a PAIR of column blocks --
+// acc[2m][j][0..3] and acc[2m + 1][j][0..3], i.e. k = (block 2m, q = 4g + r), (block 2m + 1, q = 4g + r) -- split into three
+// planes in registers; the A operand of (column block cb, pair m) is -W's entries in that k order, split and laid out per lane by a
+// conversion pass that all four waves share (fp32 image in global memory -> registers -> three planes in LDS, one 16-byte read per
+// lane, plane and operand).  Six terms, each its own instruction here (the pairing of bx6_compute needs 16 k-values per term):
+// 20 (cb, m) operands x 6 x 2 row blocks = 240 MFMAs of 16 cycles against 288 of 32.  Pairs in DESCENDING order: an input block
+// belongs to one pair only, so once pair m's B planes are taken, acc[2m] and acc[2m + 1] are free to become the outputs L(:, 2m),
+// L(:, 2m + 1), which later (lower) pairs keep adding to -- in place, as trmm_in_registers.  Two rounds (pairs 3, 2, 1: 12 operands
+// = 36 KB of planes; pair 0: 8 = 24 KB) so that the planes fit the panel kernels' LDS.
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void trmm_bx6_operand(int round, int ci, int &m, int &cb) {   // the ci-th (pair, column block) of a round
+  if (round) { m = 0; cb = ci; }
+  else if (ci < 2) { m = 3; cb = 6 + ci; }
+  else if (ci < 6) { m = 2; cb = 2 + ci; }
+  else { m = 1; cb = ci - 4; }
+}
+template <int M, int CI0>   // pair M, whose operands start at index CI0 of the round's planes
+__device__ __forceinline__ void trmm_bx6_pair(Prec<float>::acc_t (&acc)[NCB][2], const unsigned short *planes, int lane) {
+  using acc_t = Prec<float>::acc_t;
+  bf8 bp[2][3];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float v[8] = {acc[2 * M][j][0], acc[2 * M][j][1], acc[2 * M][j][2], acc[2 * M][j][3],
+                        acc[2 * M + 1][j][0], acc[2 * M + 1][j][1], acc[2 * M + 1][j][2], acc[2 * M + 1][j][3]};
+    bxu4 w[3];
+    bx_split8(v, w);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) bp[j][pl] = __builtin_bit_cast(bf8, w[pl]);
+    acc[2 * M][j] = acc_t{0, 0, 0, 0};
+    acc[2 * M + 1][j] = acc_t{0, 0, 0, 0};
+  }
+  // two column blocks at a time: four accumulators between two MFMAs on the same one
+  static_for<0, (NCB - 2 * M) / 2>([&](auto hc) {
+    constexpr int H = decltype(hc)::value, CB = 2 * M + 2 * H, CI = CI0 + 2 * H;
+    bf8 ap[2][3];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) ap[u][pl] = bx_ld8(planes + (((CI + u) * 3 + pl) * 64 + lane) * 8);
+    constexpr int TA[6] = {0, 2, 0, 1, 1, 0}, TB[6] = {2, 0, 1, 0, 1, 0};   // a0 b2, a2 b0, a0 b1, a1 b0, a1 b1, a0 b0: smallest first
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[CB + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[u][TA[t]], bp[j][TB[t]], acc[CB + u][j], 0, 0, 0);
+  });
+}
+__device__ __forceinline__ void trmm_bx6(const FitArgs &p, Prec<float>::acc_t (&acc)[NCB][2], float *__restrict__ smem, int b, int k, int tid,
+                                         PhaseClock *pc, int wslot, bool live) {
+  const int lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const float *__restrict__ Wk = reinterpret_cast<const float *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * WIMG;
+  unsigned short *planes = reinterpret_cast<unsigned short *>(smem);
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    // conversion: operand ci of the round, lane (c, g): -W[cb*16 + c][(2m)*16 + 4g + r], -W[cb*16 + c][(2m+1)*16 + 4g + r], r = 0..3
+    // (image: Wl[blk(cb, qb)][q][c]); block (cb, 2m + 1) of an even cb = 2m lies above the diagonal: zeros
+    const int nop = round ? 8 : 12;
+    for (int it = tid >> 6; it < nop; it += 4) {
+      int m, cb;
+      trmm_bx6_operand(round, it, m, cb);
+      const float *w0 = Wk + (cb * (cb + 1) / 2 + 2 * m) * DB * DB + (4 * g) * DB + c;
+      const bool second = 2 * m + 1 <= cb;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = w0[r * DB];
+        v[4 + r] = second ? w0[DB * DB + r * DB] : 0.f;
+      }
+      bxu4 w[3];
+      bx_split8(v, w);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bxu4 *>(planes + ((it * 3 + pl) * 64 + lane) * 8) = w[pl];
+    }
+    __syncthreads();
+    if (pc && round == 0) pc->lap(p, wslot);  // W_k staged (first round)
+    if (live) {
+      if (round == 0) {
+        trmm_bx6_pair<3, 0>(acc, planes, lane);
+        trmm_bx6_pair<2, 2>(acc, planes, lane);
+        trmm_bx6_pair<1, 6>(acc, planes, lane);
+      } else trmm_bx6_pair<0, 0>(acc, planes, lane);
+    }
+    if (round == 0) __syncthreads();   // every wave is done with the first round's planes
+  }
+}
+
 // acc (rows 32 wave + 2 l15 + {0,1}, columns cb*16 + drow) <-> a column-major 128 x 128 tile, 16-byte accesses
 template <typename T>
 __device__ __forceinline__ void store_tile(const typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ tile, int ld, int tid) {
@@ -1608,7 +1700,10 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
   }
   __syncthreads();  // every wave is done with the staged inputs before W_k overwrites them
   pc.lap(p, ps + 2);
-  if (!CGP_DBG_ON(p, 64)) trmm_in_registers<T>(p, acc, smem, b, k, tid, &pc, ps + 3, live);
+  if (!CGP_DBG_ON(p, 64)) {
+    if constexpr (kF32Bf16x6 && kBxTrmm && sizeof(T) == 4) trmm_bx6(p, acc, smem, b, k, tid, &pc, ps + 3, live);
+    else trmm_in_registers<T>(p, acc, smem, b, k, tid, &pc, ps + 3, live);
+  }
   pc.lap(p, ps + 4);
   if (live && (!CGP_DBG_ON(p, 32768) || acc[0][0][0] == T(12345.678)))  // timing probe: no store
   store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
