@@ -1437,8 +1437,8 @@ __device__ __forceinline__ void trmm_in_registers(const FitArgs &p, typename Pre
 // acc[2m][j][0..3] and acc[2m + 1][j][0..3], i.e. k = (block 2m, q = 4g + r), (block 2m + 1, q = 4g + r) -- split into three
 // planes in registers; the A operand of (column block cb, pair m) is -W's entries in that k order, split and laid out per lane by a
 // conversion pass that all four waves share (fp32 image in global memory -> registers -> three planes in LDS, one 16-byte read per
-// lane, plane and operand).  Six terms, each its own instruction here (the pairing of bx6_compute needs 16 k-values per term):
-// 20 (cb, m) operands x 6 x 2 row blocks = 240 MFMAs of 16 cycles against 288 of 32.  Pairs in DESCENDING order: an input block
+// lane, plane and operand).  Eight terms (see trmm_bx6_pair), each its own instruction here (the pairing of bx6_compute needs 16
+// k-values per term): 20 (cb, m) operands x 8 x 2 row blocks = 320 MFMAs of 16 cycles against 288 of 32.  Pairs in DESCENDING order: an input block
 // belongs to one pair only, so once pair m's B planes are taken, acc[2m] and acc[2m + 1] are free to become the outputs L(:, 2m),
 // L(:, 2m + 1), which later (lower) pairs keep adding to -- in place, as trmm_in_registers.  Two rounds (pairs 3, 2, 1: 12 operands
 // = 36 KB of planes; pair 0: 8 = 24 KB) so that the planes fit the panel kernels' LDS.
@@ -1472,9 +1472,17 @@ __device__ __forceinline__ void trmm_bx6_pair(Prec<float>::acc_t (&acc)[NCB][2],
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) ap[u][pl] = bx_ld8(planes + (((CI + u) * 3 + pl) * 64 + lane) * 8);
-    constexpr int TA[6] = {0, 2, 0, 1, 1, 0}, TB[6] = {2, 0, 1, 0, 1, 0};   // a0 b2, a2 b0, a0 b1, a1 b0, a1 b1, a0 b0: smallest first
+    // EIGHT terms here, smallest first: a1 b2, a2 b1 (the two the tile loop drops), a0 b2, a2 b0, a1 b1, a0 b1, a1 b0, a0 b0 -- all but
+    // a2 b2 (2^-32).  W is an explicit inverse: on the reference's RBF x Brownian windows (cond ~ 1e6) the product S W^T cancels
+    // heavily, and with six terms the dropped 2^-22 |s| |w| per product put 3 of 2 600 fuzz cases past their fp32 bar (1.1-1.35 x).
+    // With eight every product is exact to 2^-32 and only the fp32 accumulation rounds.
+    // (Six terms for the SE kernels only, whose windows hold their bar with six, would be 2 % faster at 512 fits -- 134.9 k against
+    // 132.0 k fits/s -- but neither form of the choice was usable: a per-term branch halved the kernel's speed, two straight-line
+    // bodies behind one branch spilled 318 registers.)
+    constexpr int NT8 = 8;
+    constexpr int TA[NT8] = {1, 2, 0, 2, 1, 0, 1, 0}, TB[NT8] = {2, 1, 2, 0, 1, 1, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < NT8; ++t)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
