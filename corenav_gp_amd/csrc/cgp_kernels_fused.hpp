@@ -1499,22 +1499,30 @@ __device__ __forceinline__ void trmm_bx6(const FitArgs &p, Prec<float>::acc_t (&
   for (int round = 0; round < 2; ++round) {
     // conversion: operand ci of the round, lane (c, g): -W[cb*16 + c][(2m)*16 + 4g + r], -W[cb*16 + c][(2m+1)*16 + 4g + r], r = 0..3
     // (image: Wl[blk(cb, qb)][q][c]); block (cb, 2m + 1) of an even cb = 2m lies above the diagonal: zeros
-    const int nop = round ? 8 : 12;
-    for (int it = tid >> 6; it < nop; it += 4) {
+    // 12 / 8 operands over four waves: three / two per wave, all their loads (L2 hits, ~1 us each way) issued before the first split
+    constexpr int NOPW[2] = {3, 2};
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float v[3][8];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i >= NOPW[round]) continue;
       int m, cb;
-      trmm_bx6_operand(round, it, m, cb);
+      trmm_bx6_operand(round, wv + 4 * i, m, cb);
       const float *w0 = Wk + (cb * (cb + 1) / 2 + 2 * m) * DB * DB + (4 * g) * DB + c;
       const bool second = 2 * m + 1 <= cb;
-      float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = w0[r * DB];
-        v[4 + r] = second ? w0[DB * DB + r * DB] : 0.f;
+        v[i][r] = w0[r * DB];
+        v[i][4 + r] = second ? w0[DB * DB + r * DB] : 0.f;
       }
-      bxu4 w[3];
-      bx_split8(v, w);
+    }
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bxu4 *>(planes + ((it * 3 + pl) * 64 + lane) * 8) = w[pl];
+    for (int i = 0; i < 3; ++i) {
+      if (i >= NOPW[round]) continue;
+      bxu4 w[3];
+      bx_split8(v[i], w);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bxu4 *>(planes + (((wv + 4 * i) * 3 + pl) * 64 + lane) * 8) = w[pl];
     }
     __syncthreads();
     if (pc && round == 0) pc->lap(p, wslot);  // W_k staged (first round)
