@@ -173,7 +173,8 @@ constexpr bool kBxTrmm = CGP_BX_TRMM != 0;    // the in-register triangular prod
 #ifndef CGP_WINV_REFINE
 #define CGP_WINV_REFINE 1
 #endif
-constexpr bool kWinvRefine = CGP_WINV_REFINE != 0;   // fp32, d = 1: Newton step on the diagonal tile's inverse, residual in fp64 (winv_refine_f32)
+constexpr bool kWinvRefine = CGP_WINV_REFINE != 0;   // fp32, d <= 2: Newton step on the diagonal tile's inverse, residual in fp64 (winv_refine_f32)
+constexpr int kWinvRefineMaxD = 2;
 #ifndef CGP_BX_TRI
 #define CGP_BX_TRI 1
 #endif
@@ -1251,17 +1252,18 @@ __device__ __forceinline__ void acc_image(typename Prec<T>::acc_t (&acc)[NCB][2]
 }
 
 // --------------------------------------------------------------------------------------------------
-// fp32, one input dimension: one Newton step on the diagonal tile's inverse with the residual in DOUBLE precision.
+// fp32, one or two input dimensions: one Newton step on the diagonal tile's inverse with the residual in DOUBLE precision.
 // The panels are multiplied by W = L_kk^-1 (trmm), which is not backward stable the way a triangular solve is: what W's own fp32
-// rounding errors -- amplified by cond(L_kk) -- leave in L(:, k) is what dense one-dimensional windows (the only ones whose 128 x
-// 128 diagonal tiles are that ill-conditioned) showed as 1.2-1.5 x misses of the fp32 bar in the fuzz sweeps.  With V = -W (what
+// rounding errors -- amplified by cond(L_kk) -- leave in L(:, k) is what dense low-dimensional windows showed as 1.2-1.5 x misses of the fp32 bar in
+// the fuzz sweeps (three with d = 1 and, once that was refined, one with d = 2 in ~45 000 cases; none with d >= 3, whose scattered
+// inputs keep the tiles well conditioned -- and whose throughput, BASELINE configs[2], would pay 10 % for the step).  With V = -W (what
 // the image holds):  R = I + L V  (products of fp32 numbers are exact in fp64; accumulated on the fp64 MFMA),  V' = V + V R  (the
 // correction is O(|R|) small: fp32 MFMA, register r of R's accumulator is the B operand of k-step r).  A numpy model of the blocked
 // factorisation puts the exactly rounded inverse at a fifth of the fp32-computed one's error in the predictions (docs/negatives.md,
 // round 5).  Block column J of V' needs R(J.., J) only: the eight block columns are dealt to the four waves by their number of block
 // products (36 | 28 + 1 | 21 + 6 + 3 | 15 + 10); the corrections wait in LDS until every wave has read V (the step is in place and
 // must not depend on who writes first).  Operands straight from global memory (the tile and the image were stored by this
-// workgroup a moment ago: workgroup-scope fence, as DIAG_FINISH).  ~7 us per tile; only taken for d = 1.
+// workgroup a moment ago: workgroup-scope fence, as DIAG_FINISH).  ~12 us per tile (N = 1024 fp32: one fit 0.31 -> 0.41 ms, 64 fits 0.71 -> 0.77, 512 fits 3.56 -> 3.90); only taken for d <= 2.
 // --------------------------------------------------------------------------------------------------
 template <int J>
 __device__ __forceinline__ void winv_refine_column(const float *__restrict__ tile, int ld, const float *__restrict__ V, int lane,
@@ -1332,7 +1334,7 @@ __device__ __forceinline__ void winv_refine_f32(const float *__restrict__ tile, 
 }
 template <typename T> __device__ __forceinline__ void winv_refine(const FitArgs &p, T *tile, int ld, T *smem, int b, int k, int tid) {
   if constexpr (sizeof(T) == 4 && kWinvRefine) {
-    if (p.d == 1) winv_refine_f32(tile, ld, reinterpret_cast<float *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * WIMG, smem, tid);
+    if (p.d <= kWinvRefineMaxD) winv_refine_f32(tile, ld, reinterpret_cast<float *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * WIMG, smem, tid);
   }
 }
 
