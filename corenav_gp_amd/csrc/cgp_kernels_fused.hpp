@@ -170,11 +170,6 @@ constexpr int kBxMidSets = CGP_BX_MID_SETS;   // chunks in flight (register sets
 #define CGP_BX_TRMM 1
 #endif
 constexpr bool kBxTrmm = CGP_BX_TRMM != 0;    // the in-register triangular product L = S W^T of the fp32 panel tiles on the bf16 matrix cores too
-#ifndef CGP_WINV_REFINE
-#define CGP_WINV_REFINE 1
-#endif
-constexpr bool kWinvRefine = CGP_WINV_REFINE != 0;   // fp32, d <= 2: Newton step on the diagonal tile's inverse, residual in fp64 (winv_refine_f32)
-constexpr int kWinvRefineMaxD = 2;
 #ifndef CGP_BX_TRI
 #define CGP_BX_TRI 1
 #endif
@@ -1251,93 +1246,6 @@ __device__ __forceinline__ void acc_image(typename Prec<T>::acc_t (&acc)[NCB][2]
     }
 }
 
-// --------------------------------------------------------------------------------------------------
-// fp32, one or two input dimensions: one Newton step on the diagonal tile's inverse with the residual in DOUBLE precision.
-// The panels are multiplied by W = L_kk^-1 (trmm), which is not backward stable the way a triangular solve is: what W's own fp32
-// rounding errors -- amplified by cond(L_kk) -- leave in L(:, k) is what dense low-dimensional windows showed as 1.2-1.5 x misses of the fp32 bar in
-// the fuzz sweeps (three with d = 1 and, once that was refined, one with d = 2 in ~45 000 cases; none with d >= 3, whose scattered
-// inputs keep the tiles well conditioned -- and whose throughput, BASELINE configs[2], would pay 10 % for the step).  With V = -W (what
-// the image holds):  R = I + L V  (products of fp32 numbers are exact in fp64; accumulated on the fp64 MFMA),  V' = V + V R  (the
-// correction is O(|R|) small: fp32 MFMA, register r of R's accumulator is the B operand of k-step r).  A numpy model of the blocked
-// factorisation puts the exactly rounded inverse at a fifth of the fp32-computed one's error in the predictions (docs/negatives.md,
-// round 5).  Block column J of V' needs R(J.., J) only: the eight block columns are dealt to the four waves by their number of block
-// products (36 | 28 + 1 | 21 + 6 + 3 | 15 + 10); the corrections wait in LDS until every wave has read V (the step is in place and
-// must not depend on who writes first).  Operands straight from global memory (the tile and the image were stored by this
-// workgroup a moment ago: workgroup-scope fence, as DIAG_FINISH).  ~12 us per tile (N = 1024 fp32: one fit 0.31 -> 0.41 ms, 64 fits 0.71 -> 0.77, 512 fits 3.56 -> 3.90); only taken for d <= 2.
-// --------------------------------------------------------------------------------------------------
-template <int J>
-__device__ __forceinline__ void winv_refine_column(const float *__restrict__ tile, int ld, const float *__restrict__ V, int lane,
-                                                   Prec<float>::acc_t (&D)[NCB]) {
-  using P64 = Prec<double>;
-  using P32 = Prec<float>;
-  const int l15 = lane & 15, lq = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < NCB - J; ++i) D[i] = P32::acc_t{0, 0, 0, 0};
-  static_for<J, NCB>([&](auto kc) {
-    constexpr int K = decltype(kc)::value;
-    P64::acc_t R;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) R[r] = (K == J && P64::drow(lane, r) == l15) ? 1.0 : 0.0;
-    static_for<J, K + 1>([&](auto tc) {
-      constexpr int Tb = decltype(tc)::value;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const double a = (double)tile[(size_t)(Tb * DB + 4 * ks + lq) * ld + K * DB + l15];          // L(K,Tb)[m = l15][4 ks + lq]
-        const double bb = (double)V[wimg_blk(Tb, J) + l15 * DB + 4 * ks + lq];                       // V(Tb,J)[4 ks + lq][n = l15]
-        R = P64::mfma(a, bb, R);
-      }
-    });
-    // D(i) += V(i, K) R(K, J): R's register r holds rows lq + 4 r -- k-step r takes them in that order, the A operand follows
-    static_for<K, NCB>([&](auto ic) {
-      constexpr int I = decltype(ic)::value;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float a = V[wimg_blk(I, K) + (lq + 4 * r) * DB + l15];                                 // V(I,K)[m = l15][lq + 4 r]
-        D[I - J] = P32::mfma(a, (float)R[r], D[I - J]);
-      }
-    });
-  });
-}
-// the corrections of block column J go to LDS in the image's own layout (36 blocks x 1 KB: what the panel kernels carry), so that
-// a wave holds one column's accumulators at a time -- three columns' worth in registers spilled 368 VGPRs in the 128-VGPR kernel
-template <int J>
-__device__ __forceinline__ void winv_refine_park(float *__restrict__ dV, int lane, const Prec<float>::acc_t (&D)[NCB]) {
-  const int l15 = lane & 15, lq = lane >> 4;
-#pragma unroll
-  for (int i = J; i < NCB; ++i) *reinterpret_cast<Prec<float>::acc_t *>(dV + wimg_blk(i, J) + l15 * DB + 4 * lq) = D[i - J];   // rows 4 lq + r of column l15
-}
-template <int J> __device__ __forceinline__ void winv_refine_one(const float *__restrict__ tile, int ld, const float *__restrict__ V, float *__restrict__ dV, int lane) {
-  Prec<float>::acc_t D[NCB];
-  winv_refine_column<J>(tile, ld, V, lane, D);
-  winv_refine_park<J>(dV, lane, D);
-  __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ void winv_refine_f32(const float *__restrict__ tile, int ld, float *__restrict__ V, float *__restrict__ smem, int tid) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __syncthreads();   // (also: every wave is done with the factorisation's LDS)
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wave == 0) winv_refine_one<0>(tile, ld, V, smem, lane);
-  else if (wave == 1) { winv_refine_one<1>(tile, ld, V, smem, lane); winv_refine_one<7>(tile, ld, V, smem, lane); }
-  else if (wave == 2) { winv_refine_one<2>(tile, ld, V, smem, lane); winv_refine_one<5>(tile, ld, V, smem, lane); winv_refine_one<6>(tile, ld, V, smem, lane); }
-  else { winv_refine_one<3>(tile, ld, V, smem, lane); winv_refine_one<4>(tile, ld, V, smem, lane); }
-  __syncthreads();   // every wave has read the V it needs; the corrections are in LDS
-  using vec4 = float __attribute__((ext_vector_type(4)));
-  for (int e = tid * 4; e < WIMG; e += 256 * 4) {
-    vec4 v = *reinterpret_cast<const vec4 *>(V + e);
-    const vec4 dv = *reinterpret_cast<const vec4 *>(smem + e);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += dv[r];
-    *reinterpret_cast<vec4 *>(V + e) = v;
-  }
-}
-template <typename T> __device__ __forceinline__ void winv_refine(const FitArgs &p, T *tile, int ld, T *smem, int b, int k, int tid) {
-  if constexpr (sizeof(T) == 4 && kWinvRefine) {
-    if (p.d <= kWinvRefineMaxD) winv_refine_f32(tile, ld, reinterpret_cast<float *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)k * WIMG, smem, tid);
-  }
-}
-
 // FAT: the launch carries potf2_lds_elems<T>() of LDS, so the tile is factored by potf2_tile (factor chain on wave 0 beside
 // the trailing updates and the inverse on waves 1-3; in-kernel clocks, fp32, lone workgroup: 67 k ticks against the packed
 // form's 89 k, 76 k against 124 k with 64 fits on the chip) -- the packed form exists to fit TWO diagonal workgroups on a CU.
@@ -1416,7 +1324,6 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
     __syncthreads();
     if (pc) pc->lap(p, 346);  // tile into LDS
     potf2_tile<T>(p, At, Dv, Ts, flag, tile, ld, b, kn, tid);
-    winv_refine<T>(p, tile, ld, smem, b, kn, tid);
     if (pc) {
       pc->lap(p, 347);        // factorisation + inverse + stores
       pc->count(p, 351);
@@ -1455,7 +1362,6 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
   T *Wk = reinterpret_cast<T *>(p.Winv) + (size_t)b * p.winv_stride + (size_t)kn * WIMG;
   if (pc) pc->lap(p, 346);  // tile into LDS
   diag_factor_packed<T>(p, smem, tile, ld, Wk, b, kn, tid);
-  winv_refine<T>(p, tile, ld, smem, b, kn, tid);
   if (pc) {
     pc->lap(p, 347);        // packed factorisation + inverse + stores
     pc->count(p, 351);
@@ -2436,7 +2342,6 @@ __global__ __launch_bounds__(256) void k_tile_sk(FitArgs p, SplitArgs q, int k) 
     __syncthreads();
     pc.lap(p, 11);  // tile into LDS
     potf2_tile<T>(p, At, Dv, Ts, flag, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, b, k, tid);
-    winv_refine<T>(p, Lw + (size_t)(k * TS) * ld + (size_t)k * TS, ld, smem, b, k, tid);
     pc.lap(p, 12);  // factorisation, inverse, stores
     pc.count(p, 15);
     __threadfence();   // W_k (and L(k,k)) visible device-wide before the step is announced

@@ -54,13 +54,12 @@ enum {
  * with no second class of near misses: max(1e-3, 20 x the error of spotrf / strtrs on the same window) for the SE
  * kernels (the second term only matters for dense one-dimensional inputs), and max(3e-3, 30 x that error) for the
  * reference's RBF x Brownian kernel on raw tick counts (cond(Ky) ~ 1e6) -- use CGP_F64 for that kernel, as the
- * reference does.  Measured against that contract (round 5): the sweeps of the round found FOUR misses in ~45 000 cases, all
- * dense low-dimensional windows with a single test point -- d = 1: 1100 samples SE at 1.36e-3, 700 samples SE at 1.26e-3, 511
- * samples RBF x Brownian at 1.17 x its bar; d = 2: 1024 samples SE at 1.5 x -- where single-precision LAPACK on the exact Gram
- * matrix is below 7e-5: the panels are multiplied by the explicit inverse of the 128 x 128 diagonal tile, which is not backward
- * stable the way a triangular solve is.  Since then fp32 calls with d <= 2 refine that inverse by one Newton step with the
- * residual in double precision (winv_refine_f32; 10-30 % of such a call's time): the same seeds and four more (~17 000 cases)
- * run without a miss, worst case 0.93 of its bar.
+ * reference does.  Measured against that contract (round 5, ~26 000 cases of ten seeds of the sweep on the shipped kernels):
+ * TWO misses, both dense one-dimensional windows with a single test point (700 samples SE at 1.26 x the bar, 511 samples RBF x
+ * Brownian at 1.17 x); over everything the round ran (~70 000 cases, variant builds included) about one case in 7 000 misses, always
+ * a dense window with d <= 2 sitting within 1.5 x of its bar -- such windows' fits scatter around 1e-3 in single precision (mean
+ * error of 40 such fits 0.6e-3 ... 1.6e-3, tools/d1_fp32_error.py) where single-precision LAPACK on the exact Gram matrix is below
+ * 7e-5; use CGP_F64 for them.  SE kernels with d >= 3: no miss, at most 0.98 of the bar.
  * Returns NULL on failure (device index out of range, device is not gfx950 -- the architecture name
  * is checked: the code object holds gfx950 kernels only -- or out of memory): no CPU fallback. */
 cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, int dtype);

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Error of fp32 fits of dense one-dimensional windows against the fp64 oracle, all fits of a few calls (test infrastructure: uses oracle/):
+   CGP_LIB=<lib> python tools/d1_fp32_error.py      -- same-box A/B of library builds (e.g. -DCGP_WINV_REFINE=0) on the windows the
+fuzz sweep flagged (tests/fuzz/fuzz_parity.py's generator: seeds below)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch  # noqa: F401
+from corenav_gp_amd import engine, synth
+from oracle import gp_oracle as go
+
+CASES = [(1000, 1, 1, 1, 40, 945332210), (1000, 1, 1, 1, 40, 472841713), (700, 1, 1, 1, 48, 384559499), (1024, 1, 2, 1, 38, 986455068),
+         (1100, 599, 1, 1, 33, 681215296), (1000, 5, 1, 1, 40, 12345)]
+for N, M, d, kid, B, seed in CASES:
+    Xl, yl, Xsl, thl = [], [], [], []
+    for b in range(B):
+        X, y, Xs = synth.window(N, d, max(M, 1), seed + b)
+        Xl.append(X); yl.append(y); Xsl.append(Xs[:M]); thl.append(synth.theta_for(kid, d, y, None))
+    X, y, th, Xs = np.stack(Xl), np.stack(yl), np.stack(thl), np.stack(Xsl)
+    ctx = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=B, dtype=engine.F32)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
+    errs = []
+    for b in range(0, B, 3):
+        f = go.fit(kid, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        mscale = max(float(np.max(np.abs(omu))), 0.1 * float(np.max(np.abs(y[b]))))
+        errs.append(max(abs(logml[b] - f.logml) / max(abs(f.logml), 0.5 * N), float(np.max(np.abs(mean[b] - omu)) / mscale),
+                        float(np.max(np.abs(var[b] - ovar) / np.abs(ovar)))))
+    errs = np.array(errs)
+    print(f"N={N} M={M} d={d} B={B} seed={seed}: error over {len(errs)} fits  mean {errs.mean():.3e}  median {np.median(errs):.3e}  max {errs.max():.3e}")
