@@ -374,8 +374,8 @@ __device__ __forceinline__ void bx6_compute_pipe(Prec<float>::acc_t (&acc)[NCB][
   bx_mm4(acc, 6, r6, r7, b01a, b01b);
 }
 // `st` arrives with chunks 0 .. D - 1 in flight (bx6_prologue, before the Gram phase); set c % D holds chunk c.  D = 1, one plane
-// buffer, two barriers per chunk: the full-batch build (three workgroups per CU cover the rest of the latency; a second set would
-// spill -- 168 VGPRs -- and a spill's scratch traffic drains the load queue at every reload; a second plane buffer measured the
+// buffer, two barriers per chunk: the full-batch build (four workgroups per CU at 128 VGPRs cover the rest of the latency; a second
+// set spilled even at three per CU -- 168 VGPRs -- and a spill's scratch traffic drains the load queue at every reload; a second plane buffer measured the
 // same).  D = 4, two plane buffers, one barrier per chunk: the mid-size build, whose CUs hold one or two workgroups (chunk c + 1 is
 // split into the buffer chunk c - 1 was read from, which every wave left before the barrier of iteration c; the Gram inputs lie
 // over buffer 1, first overwritten after the barrier of iteration 0).
@@ -1279,7 +1279,7 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
   const T *gR = Lw + (size_t)kn * TS + (size_t)c_first * KT * ld;
   T *img = reinterpret_cast<T *>(p.dpart) + ((size_t)b * img_slots(p) + kn % img_slots(p)) * DPART;
   // fp32 builds with the deep loops (mid-size; the fat k_diag_lean): the update on the bf16 matrix cores (bx6_syrk_tri_loop)
-  // (the full-batch build keeps the fp32-input MFMA here: with this loop inlined its 168-VGPR kernel spilled 220 registers)
+  // (the full-batch build keeps the fp32-input MFMA here: with this loop inlined its kernel -- then at 168 VGPRs, 128 now -- spilled 220 registers)
   constexpr bool BXT = kF32Bf16x6 && kBxTri && sizeof(T) == 4 && TRI && DEEP;
   BxTriStage<kBxMidSets> bxt;   // (only BXT uses it)
   {
