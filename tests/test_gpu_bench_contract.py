@@ -127,3 +127,7 @@ def test_bench_rccl_collectives_with_one_rank():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["config"]["collective_backend"] == "rccl" and j["config"]["collective_world"] == 1
     assert j["n_gpus"] == 1 and j["config"]["ensemble"]["n"] == 64 and j["config"]["ensemble"]["n_failed"] == 0
+    # an fp32 line of the shipped library says on which matrix cores its products run, and prices the kernel against both ceilings
+    rf = j["roofline"]
+    assert j["dtype"] == "f32" and rf["peak"] == pytest.approx(157.3) and "bf16x6" in rf["mfma_path"]
+    assert rf["bf16x6_bound_tflops"] == pytest.approx(2500.0 / 6.0) and rf["frac_of_bf16x6_bound"] == pytest.approx(rf["achieved"] / (2500.0 / 6.0))
