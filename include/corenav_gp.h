@@ -58,8 +58,8 @@ enum {
  * TWO misses, both dense one-dimensional windows with a single test point (700 samples SE at 1.26 x the bar, 511 samples RBF x
  * Brownian at 1.17 x); over everything the round ran (~70 000 cases, variant builds included) about one case in 7 000 misses, always
  * a dense window with d <= 2 sitting within 1.5 x of its bar -- on such windows logML and the variance are at single-precision
- * LAPACK's level (5e-5) but the predictive mean, an inner product of two solves by the diagonal tiles' explicit inverses, scatters
- * around 1e-3 (tools/d1_fp32_error.py); use CGP_F64 for them.  SE kernels with d >= 3: no miss, at most 0.98 of the bar.
+ * LAPACK's level (5e-5) but the predictive mean scatters around 1e-3 (tools/d1_fp32_error.py; what has been ruled out as its
+ * cause: DESIGN.md section 10); use CGP_F64 for them.  SE kernels with d >= 3: no miss, at most 0.98 of the bar.
  * Returns NULL on failure (device index out of range, device is not gfx950 -- the architecture name
  * is checked: the code object holds gfx950 kernels only -- or out of memory): no CPU fallback. */
 cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, int dtype);
