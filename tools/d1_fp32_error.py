@@ -9,15 +9,22 @@ import torch  # noqa: F401
 from corenav_gp_amd import engine, synth
 from oracle import gp_oracle as go
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", default=None, help='"N,M,d,kid,B,seed;..." instead of the flagged windows')
+ap.add_argument("--f64", action="store_true", help="an fp64 context (sanity: 1e-9)")
+a = ap.parse_args()
 CASES = [(1000, 1, 1, 1, 40, 945332210), (1000, 1, 1, 1, 40, 472841713), (700, 1, 1, 1, 48, 384559499), (1024, 1, 2, 1, 38, 986455068),
          (1100, 599, 1, 1, 33, 681215296), (1000, 5, 1, 1, 40, 12345)]
+if a.cases:
+    CASES = [tuple(int(v) for v in c.split(",")) for c in a.cases.split(";")]
 for N, M, d, kid, B, seed in CASES:
     Xl, yl, Xsl, thl = [], [], [], []
     for b in range(B):
         X, y, Xs = synth.window(N, d, max(M, 1), seed + b)
         Xl.append(X); yl.append(y); Xsl.append(Xs[:M]); thl.append(synth.theta_for(kid, d, y, None))
     X, y, th, Xs = np.stack(Xl), np.stack(yl), np.stack(thl), np.stack(Xsl)
-    ctx = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=B, dtype=engine.F32)
+    ctx = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=B, dtype=engine.F64 if a.f64 else engine.F32)
     rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
     errs = []
     for b in range(0, B, 3):
