@@ -13,6 +13,7 @@ import argparse
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", default=None, help='"N,M,d,kid,B,seed;..." instead of the flagged windows')
 ap.add_argument("--f64", action="store_true", help="an fp64 context (sanity: 1e-9)")
+ap.add_argument("--noise", type=float, default=None, help="override the noise variance of every window (the generator's is 3e-4 at an amplitude of 1e-2)")
 a = ap.parse_args()
 CASES = [(1000, 1, 1, 1, 40, 945332210), (1000, 1, 1, 1, 40, 472841713), (700, 1, 1, 1, 48, 384559499), (1024, 1, 2, 1, 38, 986455068),
          (1100, 599, 1, 1, 33, 681215296), (1000, 5, 1, 1, 40, 12345)]
@@ -23,6 +24,8 @@ for N, M, d, kid, B, seed in CASES:
     for b in range(B):
         X, y, Xs = synth.window(N, d, max(M, 1), seed + b)
         Xl.append(X); yl.append(y); Xsl.append(Xs[:M]); thl.append(synth.theta_for(kid, d, y, None))
+        if a.noise is not None:
+            thl[-1][-1] = a.noise
     X, y, th, Xs = np.stack(Xl), np.stack(yl), np.stack(thl), np.stack(Xsl)
     ctx = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=B, dtype=engine.F64 if a.f64 else engine.F32)
     rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, kid)
