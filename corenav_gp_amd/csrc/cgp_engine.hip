@@ -7,6 +7,7 @@
 #include "cgp_window.hpp"
 #include "cgp_lookahead.hpp"
 #include "cgp_small.hpp"
+#include "cgp_refine.hpp"
 #include "gp_predictor_core.hpp"
 #include "gp_predictor.h"
 #include "lbfgs.hpp"
@@ -61,6 +62,7 @@ struct cgp_ctx {
   // Two stream groups or one for an fp32 call of 56 ... 96 fits?  Decided per caller stream by timing one call each way (run_schedule).
   struct GroupTune {
     hipStream_t stream = nullptr;
+    int batch = 0, NT = 0;     // the entry is for calls of this many fits and block steps on `stream`
     int state = -1;            // -1 free, else eligible calls seen on this stream so far (kTuneDecide and beyond: decided)
     int groups = 2;
     float ms[2] = {0.f, 0.f};
@@ -73,6 +75,11 @@ struct cgp_ctx {
   // device buffers
   void *Lw = nullptr, *Winv = nullptr, *dX = nullptr, *dXs = nullptr, *dy = nullptr;
   void *dmean = nullptr, *dvar = nullptr, *dalpha = nullptr;
+  // fp32 contexts: mixed-precision refinement of alpha and the predictive mean (cgp_refine.hpp, cgp_set_refine)
+  double *dref_r = nullptr, *dref_a = nullptr;   // [max_batch][alpha_stride] residual, alpha in double precision
+  int *dref_flag = nullptr;                      // [max_batch] fits k_finalize marked as dense (d > 3 under the default setting)
+  int refine = -1;        // -1: the engine decides (one step: every fit at d <= 3, the dense ones beyond), 0: never, 1..3: that many steps for every call
+  bool refined = false;   // dref_a holds the refined alpha of the fits of the last fit call (cgp_predict / cgp_get_alpha use it)
   double *dtheta = nullptr, *djitter = nullptr, *dlogml = nullptr, *dprep = nullptr;
   long long *ddbg = nullptr;
   double *dgpart = nullptr;
@@ -312,6 +319,7 @@ template <typename T> int set_lds_attrs(int device) {
 #ifdef CGP_AB
   ok = ok && set(reinterpret_cast<const void *>(&k_sched<T>), paneldiag_mid_lds_bytes<T>());
 #endif
+  if constexpr (sizeof(T) == 4) ok = ok && set(reinterpret_cast<const void *>(&k_refine_solve<float>), 160 * 1024);
   if constexpr (mid_fat<T, true>()) ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T, true>), paneldiag_mid_lds_bytes<T>());
   if constexpr (CGP_F32_FULL_DEEP && sizeof(T) == 4) ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, false>), paneldiag_lds_bytes<T>());
 #ifdef CGP_AB
@@ -390,6 +398,7 @@ template <typename T> FitArgs group_view(const FitArgs &a, int g0) {
   v.prep = a.prep ? a.prep + (size_t)g0 * PREP_N : nullptr;
   v.logml = a.logml ? a.logml + g0 : nullptr;
   v.info = a.info ? a.info + g0 : nullptr;
+  v.rflag = a.rflag ? a.rflag + g0 : nullptr;
   return v;
 }
 
@@ -538,6 +547,49 @@ int run_sched(cgp_ctx *c, FitArgs a, int batch, hipStream_t s) {
 template <typename T> int run_sched(cgp_ctx *, FitArgs, int, hipStream_t) { return CGP_EINVAL; }
 #endif
 
+// Refinement of an fp32 fit (cgp_refine.hpp): how many steps this call takes, and whether every fit takes them or only the
+// ones k_finalize marks as dense (FitArgs::rflag, RF_RHO).  -1 (the default) = one step; every fit of a window of at most three
+// input dimensions (measured, 40 fits of N = 1000, mean error against the oracle without / with: d = 1 1.0e-3 / 6e-7, d = 2
+// 7e-4 / 1.5e-7, d = 3 3.1e-4 with a worst fit at 1.1e-3 / 1e-7), the marked fits beyond (d = 4: two windows of 43 000 fuzz cases
+// at 1.1 and 1.3e-3, rho = 21; d = 6: 7e-5, worst 1.8e-4, rho 3 ... 8): BASELINE configs[2] (d = 6, rho 3 ... 6) pays four
+// launches whose workgroups return at once.
+constexpr int kRefineAutoMaxD = 3;
+inline int refine_steps(const cgp_ctx *c, const FitArgs &a) {
+  if (c->dtype != CGP_F32 || !c->dref_a || a.xid || a.NT > kRefineMaxNT) return 0;
+  if (c->refine < 0) return 1;
+  return std::min(c->refine, 3);
+}
+inline bool refine_gated(const cgp_ctx *c, const FitArgs &a) { return c->refine < 0 && a.d > kRefineAutoMaxD; }
+template <bool MEAN> void launch_refine_gemv(int rows, int nfits, hipStream_t s, const FitArgs &a, const RefineArgs &q) {
+  const dim3 grid(cdiv(rows, RF_ROWS), nfits);
+  if (a.kernel_id == K_RBF_BROWNIAN) hipLaunchKernelGGL((k_refine_gemv<float, 1, true, MEAN>), grid, dim3(256), 0, s, a, q);
+  else if (a.d == 1) hipLaunchKernelGGL((k_refine_gemv<float, 1, false, MEAN>), grid, dim3(256), 0, s, a, q);
+  else if (a.d == 2) hipLaunchKernelGGL((k_refine_gemv<float, 2, false, MEAN>), grid, dim3(256), 0, s, a, q);
+  else if (a.d == 3) hipLaunchKernelGGL((k_refine_gemv<float, 3, false, MEAN>), grid, dim3(256), 0, s, a, q);
+  else hipLaunchKernelGGL((k_refine_gemv<float, 0, false, MEAN>), grid, dim3(256), 0, s, a, q);
+}
+// The launches that follow k_finalize of `nfits` fits starting at fit g0 of the call: alpha_0 = L^-T z in double (in place of
+// k_alpha), `steps` correction steps (solve = false: alpha of the last fit call is already in dref_a -- predict after fit),
+// then the mean of the M test points.
+inline void launch_refine(cgp_ctx *c, const FitArgs &a, int nfits, int g0, hipStream_t s, int steps, bool solve, bool alpha_for_all) {
+  const RefineArgs q{c->dref_r + (size_t)g0 * c->alpha_stride, c->dref_a + (size_t)g0 * c->alpha_stride, c->alpha_stride, a.rflag};
+  if (solve) {
+    const size_t lds = refine_solve_lds_bytes(a.NT);
+    RefineArgs q0 = q;
+    if (alpha_for_all) q0.flag = nullptr;   // the caller asked for alpha (cgp_get_alpha): alpha_0 of every fit, marked or not
+    hipLaunchKernelGGL(k_refine_solve<float>, dim3(nfits), dim3(RS_THREADS), lds, s, a, q0, 0);
+    for (int st = 0; st < steps; ++st) {
+      launch_refine_gemv<false>(a.N, nfits, s, a, q);
+      hipLaunchKernelGGL(k_refine_solve<float>, dim3(nfits), dim3(RS_THREADS), lds, s, a, q, 1);
+    }
+  }
+  if (a.M > 0) launch_refine_gemv<true>(a.M, nfits, s, a, q);
+}
+inline double refine_flops(const FitArgs &a, int nfits, int steps, bool solve) {   // covariance entries at (3 d + 20) flops + the two passes over the factor
+  const double ent = (solve ? (double)steps * a.N * a.N : 0.0) + (double)a.M * a.N;
+  return nfits * (ent * (3.0 * a.d + 20.0) + (solve ? (steps + 0.5) * 2.0 * a.N * a.N : 0.0));
+}
+
 // Enqueue the whole schedule for `batch` fits.  The batch is cut into up to c->nstreams contiguous
 // groups, one worker stream each, forked from / joined to the caller's stream `s` with events; the
 // launches are issued step-interleaved so every stream always has work queued.
@@ -546,6 +598,16 @@ template <typename T>
 int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha, hipStream_t s) {
   const SchedSwitches &sw = sched_switches();
   a.rows_from_extra = in_rows ? 0 : 1;
+  // fp32: alpha and the mean refined against a double-precision residual (cgp_refine.hpp).  A fit call computes alpha for it;
+  // a predict-after-fit call (in_rows = false) reuses the alpha the fit call left in dref_a.
+  int rsteps = 0;
+  if constexpr (sizeof(T) == 4) rsteps = refine_steps(c, a);
+  const bool rsolve = rsteps > 0 && (in_rows || want_alpha);
+  if (rsteps > 0 && !rsolve && !c->refined) rsteps = 0;
+  if (in_rows || want_alpha) c->refined = rsolve;
+  const bool ralpha_all = rsolve && want_alpha;
+  if (rsolve) want_alpha = false;   // alpha_0 comes from k_refine_solve (double precision, dref_a): no k_alpha launch
+  if constexpr (sizeof(T) == 4) a.rflag = rsteps > 0 && refine_gated(c, a) ? c->dref_flag : nullptr;
   const int upd_lds = upd_lds_bytes<T>();
   const int tile_lds = potf2_lds_bytes<T>();
   const bool auto_groups = c->nstreams == 0;
@@ -580,43 +642,70 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     // stream, and from then on the faster form is used.  Results are bitwise the same either way.
     // Every kRetune calls the two runs are repeated (a caller that first synchronises after every call and later issues calls
     // back to back sees the other behaviour: sweep_probe.py's 1.24 ms): 8 calls in 264, half of them at the slower setting.
+    // The measurement never blocks the caller and never touches a stream that is being captured: the decision is read with
+    // hipEventQuery (until the last timed call has finished the call keeps two groups and asks again next time), an entry is
+    // keyed by (stream, fits, block steps) -- a caller that mixes shapes on one stream gets one decision per shape --, a pair
+    // of spans that differ by more than 4 x is the caller's own host gaps, not the schedules (discarded, measured again), and
+    // while the stream is capturing (cgp_set_streams documents fixing the form for graphs; this keeps the default safe) the
+    // call takes the form already decided, or two groups, without recording or reading any timing event.
     constexpr int kWarm = 2, kRun = 4, kTuneDecide = kWarm + 2 * kRun, kRetune = 256;
     if (G == 2 && auto_groups && in_rows && !c->prof) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+      if (capturing) (void)hipGetLastError();
       cgp_ctx::GroupTune *t = nullptr, *lru = &c->tune[0];
       for (auto &e : c->tune) {
-        if (e.state >= 0 && e.stream == s) t = &e;
+        if (e.state >= 0 && e.stream == s && e.batch == batch && e.NT == a.NT) t = &e;
         if (e.used < lru->used) lru = &e;
       }
-      if (!t) {
+      if (!t && !capturing) {
         t = lru;
         t->stream = s;
+        t->batch = batch;
+        t->NT = a.NT;
         t->state = 0;
         t->groups = 2;
         for (auto &e : t->e)
-          if (!e && hipEventCreate(&e) != hipSuccess) t->state = kTuneDecide + 1;   // no events: keep the two groups
+          if (!e && hipEventCreate(&e) != hipSuccess) {   // no events: keep the two groups, never measure
+            (void)hipGetLastError();
+            t->state = kTuneDecide + 1;
+          }
       }
-      t->used = ++c->tune_clock;
-      if (t->state > kTuneDecide + kRetune) t->state = kWarm;
-      if (t->state == kTuneDecide) {
-        float m2 = 0.f, m1 = 0.f;
-        if (hipEventSynchronize(t->e[3]) == hipSuccess && hipEventElapsedTime(&m2, t->e[0], t->e[1]) == hipSuccess &&
-            hipEventElapsedTime(&m1, t->e[2], t->e[3]) == hipSuccess) {
-          t->ms[0] = m2;
-          t->ms[1] = m1;
-          t->groups = m2 <= m1 ? 2 : 1;
+      if (capturing) {
+        G = t && t->state > kTuneDecide ? t->groups : 2;
+        t = nullptr;
+      }
+      if (t) {
+        t->used = ++c->tune_clock;
+        if (t->state > kTuneDecide + kRetune) t->state = kWarm;
+        if (t->state == kTuneDecide) {
+          float m2 = 0.f, m1 = 0.f;
+          const hipError_t qe = hipEventQuery(t->e[3]);
+          if (qe == hipSuccess && hipEventElapsedTime(&m2, t->e[0], t->e[1]) == hipSuccess &&
+              hipEventElapsedTime(&m1, t->e[2], t->e[3]) == hipSuccess) {
+            t->ms[0] = m2;
+            t->ms[1] = m1;
+            if (m2 > 4.f * m1 || m1 > 4.f * m2) t->state = kWarm - 1;   // host gaps, not schedules: measure again
+            else t->groups = m2 <= m1 ? 2 : 1;
+            ++t->state;
+          } else {
+            (void)hipGetLastError();   // not ready (or a failed query): nothing sticks, two groups for this call, ask again
+            if (qe != hipErrorNotReady) t->state = kTuneDecide + 1;
+          }
         }
-        ++t->state;
-      }
-      if (t->state > kTuneDecide) {
-        G = t->groups;
-        ++t->state;
-      } else {
-        G = t->state < kWarm + kRun ? 2 : 1;
-        tune = t;
-        if (t->state == kWarm) tune_ev0 = t->e[0];
-        if (t->state == kWarm + kRun - 1) tune_ev1 = t->e[1];
-        if (t->state == kWarm + kRun) tune_ev0 = t->e[2];
-        if (t->state == kTuneDecide - 1) tune_ev1 = t->e[3];
+        if (t->state == kTuneDecide) {
+          G = 2;
+        } else if (t->state > kTuneDecide) {
+          G = t->groups;
+          ++t->state;
+        } else {
+          G = t->state < kWarm + kRun ? 2 : 1;
+          tune = t;
+          if (t->state == kWarm) tune_ev0 = t->e[0];
+          if (t->state == kWarm + kRun - 1) tune_ev1 = t->e[1];
+          if (t->state == kWarm + kRun) tune_ev0 = t->e[2];
+          if (t->state == kTuneDecide - 1) tune_ev1 = t->e[3];
+        }
       }
     }
   }
@@ -690,6 +779,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     if (rc != CGP_OK) return rc;
     hipLaunchKernelGGL((k_finalize<T, 64>), dim3(cdiv(a.M, 64) + 1, batch), dim3(256), 0, s, ga[0], 1);
     if (want_alpha) hipLaunchKernelGGL(k_alpha<T>, dim3(batch), dim3(256), alpha_lds_bytes(a.NT), s, ga[0]);
+    if (rsteps > 0) launch_refine(c, ga[0], batch, 0, s, rsteps, rsolve, ralpha_all);
     HIP_TRY(c, hipGetLastError());
     return CGP_OK;
   }
@@ -734,6 +824,7 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     HIP_TRY(c, hipStreamWaitEvent(sA, ev(3 * (NT - 1) + 2), 0));
     hipLaunchKernelGGL((k_finalize<T, 64>), dim3(cdiv(a.M, 64) + 1, B), dim3(256), 0, sA, ga[0], 1);
     if (want_alpha) hipLaunchKernelGGL(k_alpha<T>, dim3(B), dim3(256), (a.NT * TS + TS) * sizeof(double), sA, ga[0]);
+    if (rsteps > 0) launch_refine(c, ga[0], B, 0, sA, rsteps, rsolve, ralpha_all);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_join[0], sA));
     HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[0], 0));
@@ -772,6 +863,11 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     if (want_alpha) {
       L[0].begin(4, batch * (double)a.N * a.N);
       hipLaunchKernelGGL(k_alpha<T>, dim3(batch), dim3(256), alpha_lds_bytes(a.NT), s, ga[0]);
+      L[0].end();
+    }
+    if (rsteps > 0) {
+      L[0].begin(4, refine_flops(a, batch, rsteps, rsolve));
+      launch_refine(c, ga[0], batch, 0, s, rsteps, rsolve, ralpha_all);
       L[0].end();
     }
     HIP_TRY(c, hipGetLastError());
@@ -841,13 +937,18 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
     HIP_TRY(c, hipEventRecord(c->ev_join[0], sE));
     HIP_TRY(c, hipStreamWaitEvent(gs[0], c->ev_join[0], 0));
   }
-  for (int g = 0; g < G; ++g) {
+  for (int g = 0, g0 = 0; g < G; g0 += gb[g], ++g) {
     L[g].begin(3, gb[g] * (4.0 * a.M * a.N + 2.0 * a.N));
     hipLaunchKernelGGL((k_finalize<T, 64>), dim3(cdiv(a.M, 64) + 1, gb[g]), dim3(256), 0, gs[g], ga[g], in_rows ? 1 : 0);
     L[g].end();
     if (want_alpha) {
       L[g].begin(4, gb[g] * (double)a.N * a.N);
       hipLaunchKernelGGL(k_alpha<T>, dim3(gb[g]), dim3(256), alpha_lds_bytes(a.NT), gs[g], ga[g]);
+      L[g].end();
+    }
+    if (rsteps > 0) {
+      L[g].begin(4, refine_flops(a, gb[g], rsteps, rsolve));
+      launch_refine(c, ga[g], gb[g], g0, gs[g], rsteps, rsolve, ralpha_all);
       L[g].end();
     }
   }
@@ -1065,6 +1166,12 @@ cgp_ctx *cgp_create_ex(int device, int max_n, int max_m, int max_d, int max_batc
   ok = ok && hipMalloc(&c->dmean, B * (size_t)std::max(max_m, 1) * c->esz) == hipSuccess;
   ok = ok && hipMalloc(&c->dvar, B * (size_t)std::max(max_m, 1) * c->esz) == hipSuccess;
   ok = ok && hipMalloc(&c->dalpha, B * c->alpha_stride * c->esz) == hipSuccess;
+  if (dtype == CGP_F32) {
+    ok = ok && hipMalloc((void **)&c->dref_r, B * c->alpha_stride * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->dref_a, B * c->alpha_stride * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->dref_flag, B * sizeof(int)) == hipSuccess;
+    ok = ok && hipMemset(c->dref_flag, 0, B * sizeof(int)) == hipSuccess;
+  }
   ok = ok && hipMalloc((void **)&c->dtheta, B * CGP_MAX_THETA * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->djitter, B * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dgpart, (B * c->NTmax * (c->NTmax + 1) / 2 * GRAD_N + 2) * sizeof(double)) == hipSuccess;  // + logML, info of a single evaluation
@@ -1131,7 +1238,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg, c->dpanimg, c->dsmall, c->dsmdeal};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg, c->dpanimg, c->dsmall, c->dsmdeal, c->dref_r, c->dref_a, c->dref_flag};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {
@@ -1226,6 +1333,12 @@ int cgp_synchronize(cgp_ctx *c) {
 int cgp_set_streams(cgp_ctx *c, int n) {
   if (!c || n < 0 || n > cgp_ctx::kMaxStreams) return CGP_EINVAL;
   c->nstreams = n;
+  return CGP_OK;
+}
+
+int cgp_set_refine(cgp_ctx *c, int steps) {
+  if (!c || steps < -1 || steps > 3) return CGP_EINVAL;
+  c->refine = steps;
   return CGP_OK;
 }
 
@@ -1531,6 +1644,11 @@ int cgp_get_alpha(cgp_ctx *c, double *alpha) {
   a.info = c->dinfo;
   int rc = run(c, a, 1, false, true, s);
   if (rc != CGP_OK) return rc;
+  if (c->dtype == CGP_F32 && c->refined) {   // the refined alpha is kept in double precision (cgp_refine.hpp)
+    HIP_TRY(c, hipMemcpyAsync(alpha, c->dref_a, (size_t)c->fN * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return CGP_OK;
+  }
   std::vector<char> h((size_t)c->fN * c->esz);
   HIP_TRY(c, hipMemcpyAsync(h.data(), c->dalpha, h.size(), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));

@@ -41,6 +41,13 @@ constexpr int NCB = TS / DB;  // 8 column blocks of 16
 //   Wimg[blk(cb, qb)][q][c] = -W[cb*16 + c][qb*16 + q],   blk(cb, qb) = cb (cb + 1) / 2 + qb,  qb <= cb,
 // so staging it is a straight 16-byte-per-lane LDS-DMA copy of 36 (fp32) / 72 (fp64) KiB.
 constexpr int WIMG = NCB * (NCB + 1) / 2 * DB * DB;
+// fp32 fits of more than three input dimensions are refined (cgp_refine.hpp) per fit, when the factor itself says the window is
+// dense: rho = (sigma_f^2 + sigma_n^2) / geometric mean of L_ii^2 >= RF_RHO -- how much of every Schur complement is cancellation.
+// The unrefined mean's error against the oracle follows it (tools/rho_vs_error.py, 192 fits of N = 1100, d = 3 ... 6, mean / worst
+// error by rho: [0, 4) 2.8e-5 / 8.6e-5, [4, 8) 5.7e-5 / 1.7e-4, [8, 12) 9.8e-5 / 2.3e-4, [12, 16) 2.1e-4 / 7.6e-4, [16, 24) 3.0e-4 /
+// 9.4e-4, >= 24 5.4e-4 / 1.6e-3): 12 keeps the worst unrefined fit a factor of four inside 1e-3.  BASELINE configs[2]'s 512
+// windows sit at rho 2.9 ... 11.5: none is marked.
+constexpr double RF_RHO = 12.0;
 __host__ __device__ __forceinline__ constexpr int wimg_blk(int cb, int qb) { return (cb * (cb + 1) / 2 + qb) * DB * DB; }
 
 enum { K_SE_ISO = 0, K_SE_ARD = 1, K_RBF_BROWNIAN = 2 };
@@ -76,6 +83,7 @@ struct FitArgs {
   int img_slots;         // register-image slots per fit in dpart / pimg: 0 = 2 (by parity of the tile index), else one per tile index (k_sched)
   int xid;               // 1: the M (= N) "test rows" are the identity, so the extra block becomes (L^-1)^T (gradient mode)
   double *gpart;         // [batch][pairs][GRAD_N] per-tile-pair partial sums of k_grad
+  int *rflag;            // [batch] or null: k_finalize marks the fits whose fp32 mean wants the refinement (cgp_refine.hpp, RF_RHO)
   long long *dbgbuf;     // 64 slots of s_memtime stamps / per-phase cycle sums (-DCGP_ABLATION builds)
   int dbg;               // timing ablations (env CGP_DBG); only a -DCGP_ABLATION build reads it
 };
@@ -772,7 +780,12 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs p, int do_logml) {
       }
       __syncthreads();
     }
-    if (tid == 0) p.logml[b] = -0.5 * red[1][0] - red[0][0] - 0.5 * (double)N * 1.8378770664093453;
+    if (tid == 0) {
+      p.logml[b] = -0.5 * red[1][0] - red[0][0] - 0.5 * (double)N * 1.8378770664093453;
+      // rho = prior variance / geometric mean of the pivots L_ii^2 (the conditional variances): how much of every Schur
+      // complement is cancellation -- the quantity the fp32 mean's error follows
+      if (p.rflag) p.rflag[b] = (th[0] + th[nth - 1]) * exp(-2.0 * red[0][0] / (double)N) >= RF_RHO ? 1 : 0;
+    }
   }
 }
 

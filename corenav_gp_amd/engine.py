@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # `make ab` writes next to the shipped one); there is still no CPU fallback.
 LIB_PATH = os.environ.get("CGP_LIB") or os.path.join(_HERE, "libcorenav_gp.so")
 DEBUG_SLOTS = 512
-ABI_VERSION = 2   # include/corenav_gp.h CGP_ABI_VERSION: load() refuses a library of another revision
+ABI_VERSION = 3   # include/corenav_gp.h CGP_ABI_VERSION: load() refuses a library of another revision
 BUILD_ABLATION, BUILD_AB, BUILD_F32_NATIVE = 1, 2, 4
 STREAM_CTX = ctypes.c_void_p(-1).value   # CGP_STREAM_CTX: the context's private stream
 
@@ -67,6 +67,7 @@ _SIGS = {
     "cgp_window_push_device": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "cgp_window_state": (ctypes.c_int, [_vp, ctypes.c_int, _ip, _ip]),
     "cgp_set_streams": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "cgp_set_refine": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cgp_debug_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong)]),
     "cgp_debug_buffers": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_ulonglong)]),
     "cgp_debug_small": (ctypes.c_int, [_vp, _dp]),
@@ -366,6 +367,11 @@ class Context:
 
     def set_streams(self, n):
         self._chk(self.lib.cgp_set_streams(self.h, int(n)))
+
+    def set_refine(self, steps=-1):
+        """fp32 contexts: correction steps of alpha / the mean against a double-precision residual (cgp_set_refine): -1 the
+        engine decides (one step at d <= 2), 0 never, 1..3 always."""
+        self._chk(self.lib.cgp_set_refine(self.h, int(steps)))
 
     def profile_enable(self, on=True):
         self._chk(self.lib.cgp_profile_enable(self.h, int(on)))

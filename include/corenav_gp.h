@@ -48,18 +48,17 @@ enum {
 /* Allocates every device buffer for up to `max_batch` simultaneous fits of at most max_n training
  * points, max_m test points, max_d input dimensions.  dtype = CGP_F64 | CGP_F32 is the arithmetic
  * type of the device path; host buffers are always fp64 (the messages are float64[]).
- * CGP_F64 is the reference's arithmetic and meets 1e-6 against it on every kernel.  CGP_F32 is for the SE
- * kernels on standardised inputs (BASELINE configs[2], 1e-3); a window that is ill-conditioned in single
- * precision is as accurate as single-precision LAPACK is on it.  The contract, checked by tests/fuzz/fuzz_parity.py
- * with no second class of near misses: max(1e-3, 20 x the error of spotrf / strtrs on the same window) for the SE
- * kernels (the second term only matters for dense one-dimensional inputs), and max(3e-3, 30 x that error) for the
- * reference's RBF x Brownian kernel on raw tick counts (cond(Ky) ~ 1e6) -- use CGP_F64 for that kernel, as the
- * reference does.  Measured against that contract (round 5, ~26 000 cases of ten seeds of the sweep on the shipped kernels):
- * TWO misses, both dense one-dimensional windows with a single test point (700 samples SE at 1.26 x the bar, 511 samples RBF x
- * Brownian at 1.17 x); over everything the round ran (~70 000 cases, variant builds included) about one case in 7 000 misses, always
- * a dense window with d <= 2 sitting within 1.5 x of its bar -- on such windows logML and the variance are at single-precision
- * LAPACK's level (5e-5) but the predictive mean scatters around 1e-3 (tools/d1_fp32_error.py; what has been ruled out as its
- * cause: DESIGN.md section 10); use CGP_F64 for them.  SE kernels with d >= 3: no miss, at most 0.98 of the bar.
+ * CGP_F64 is the reference's arithmetic and meets 1e-6 against it on every kernel.  CGP_F32 is for the SE kernels on
+ * standardised inputs (BASELINE configs[2], 1e-3).  Its contract, checked by tests/fuzz/fuzz_parity.py (one bar, no second class):
+ *   - predictive mean: refined against a double-precision residual (cgp_set_refine below; by default every window of d <= 3
+ *     input dimensions and, beyond, every fit whose factor shows a dense window) -- 1e-5 of the oracle or better where it is
+ *     refined, 1e-3 where it is not;
+ *   - variance and logML come from the single-precision factor: max(1e-3, 10 x the error of spotrf / strtrs on the same
+ *     window) -- the second term only matters for windows that are ill-conditioned in single precision (dense
+ *     one-dimensional inputs), where no single-precision factorisation holds 1e-3;
+ *   - the reference's RBF x Brownian kernel on raw tick counts (cond(Ky) ~ 1e6, prior variance 1000 x the posterior one) is an
+ *     fp64 path, as in the reference: in CGP_F32 its mean is refined like any d = 1 window, its variance is held to
+ *     max(3e-3, 30 x that LAPACK error) only.  Use CGP_F64 for that kernel.
  * Returns NULL on failure (device index out of range, device is not gfx950 -- the architecture name
  * is checked: the code object holds gfx950 kernels only -- or out of memory): no CPU fallback. */
 cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, int dtype);
@@ -72,9 +71,11 @@ const char *cgp_strerror(int code);
 /* Text of the last HIP error seen by this context ("" if none). */
 const char *cgp_last_error(const cgp_ctx *ctx);
 /* ABI revision of the library that is loaded; compare with CGP_ABI_VERSION of the header a client was built
- * against.  2 (this header): cgp_debug_read writes CGP_DEBUG_SLOTS = 512 slots (version 1: 64), and a NULL
- * `hip_stream` is the legacy default stream (version 1: the context's private stream, now CGP_STREAM_CTX). */
-#define CGP_ABI_VERSION 2
+ * against.  2: cgp_debug_read writes CGP_DEBUG_SLOTS = 512 slots (version 1: 64), and a NULL `hip_stream` is the legacy
+ * default stream (version 1: the context's private stream, now CGP_STREAM_CTX).  3 (this header): cgp_set_streams accepts 0
+ * (the engine decides; the default, was one group) and cgp_create_ex, cgp_lbfgs_minimize, cgp_sweep_fit_predict_device,
+ * cgp_sweep_synchronize, cgp_sweep_context, cgp_set_refine exist; fp32 windows of d <= 3 get a refined mean by default. */
+#define CGP_ABI_VERSION 3
 int cgp_abi_version(void);
 /* How the library was built: 0 for the shipped library.  CGP_BUILD_ABLATION (-DCGP_ABLATION): env
  * CGP_DBG is read and can skip parts of the arithmetic for timing ablations -- outputs are WRONG by
@@ -226,7 +227,10 @@ int cgp_sweep_fit_predict(cgp_sweep *sweep, int batch, int N, int d, int M, int 
  * no PCIe copy and no host round trip inside the call (a 64-fit shard is 0.8 ms of device time).  Wait with the streams
  * you passed, or cgp_sweep_synchronize for the contexts' own streams.  No jitter retry, as cgp_fit_predict_batch_device.
  * Threads: shard 0 is issued by the calling thread, the others by persistent worker threads created with the sweep (no
- * thread is created per call); a sweep over ONE device is exactly that context's call. */
+ * thread is created per call); a sweep over ONE device is exactly that context's call.  Current device: every entry point
+ * that takes a context makes that context's device current on the thread it runs on (hipSetDevice) and leaves it so; after a
+ * cgp_sweep_* call the CALLING thread's current device is therefore devices[0] -- a caller with its own work on another device
+ * sets it again. */
 int cgp_sweep_fit_predict_device(cgp_sweep *sweep, int batch, int N, int d, int M, int kernel_id, const void *const *dX,
                                  const void *const *dy, const void *const *dXs, const double *const *dtheta,
                                  const double *const *djitter, int include_noise, void *const *dmean, void *const *dvar,
@@ -283,6 +287,22 @@ int cgp_window_push_device(cgp_ctx *ctx, int T, const double *dxs, const double 
                            double *dpred_mean, double *dpred_var, double *dlogml, void *hip_stream);
 /* Current size of window `w` and the first failing tick (0 = none). */
 int cgp_window_state(cgp_ctx *ctx, int w, int *n, int *info);
+
+/* ---- fp32 contexts: mixed-precision refinement of alpha and the predictive mean -----------------
+ * After the single-precision factorisation: alpha_0 = L^-T L^-1 y from the factor, then `steps` times
+ *   r = y - Ky alpha   in DOUBLE precision, Ky entries re-evaluated from X on the fly (never stored),
+ *   alpha += L^-T L^-1 r   through the fp32 factor, alpha kept in double,
+ * and mean = K*^T alpha with K* evaluated in double -- GPy's own form of the mean (gp_slip_node.py:48 m.predict: mu = k*^T
+ * woodbury_vector).  One step takes the mean of a dense one- or two-dimensional window from ~1e-3 of the oracle to ~1e-6
+ * (tools/d1_fp32_error.py); variance and logML come from the factor as before.  steps = -1 (the default): the engine decides --
+ * one step; for every fit of a window of d <= 3 input dimensions (the RBF x Brownian kernel included: +40 % per call at
+ * N = 1024, M = 599), and for d > 3 only for the fits whose factor shows a dense window (prior variance / geometric mean of
+ * the pivots L_ii^2 >= 12: the unrefined mean's error follows that ratio, tools/rho_vs_error.py) -- BASELINE configs[2] (d = 6,
+ * ratio 3 ... 11.5) has no such fit and pays four launches whose workgroups return at once (+0.5 ... 0.9 % per call); a call
+ * with such a fit pays the latency of one refinement (~0.25 ms at N = 1024) whatever their number.  0: never; 1..3: that many
+ * steps for every fit of every fp32 call.  cgp_get_alpha then returns the refined alpha (double precision).  No effect on
+ * CGP_F64 contexts, nor on windows of more than 9 900 samples (the solve keeps the window's alpha in LDS). */
+int cgp_set_refine(cgp_ctx *ctx, int steps);
 
 /* ---- per-kernel timing for the roofline line (bench.py) --------------------------------------
  * on = 1: every launch is bracketed by hipEvents on its stream; on = 2 + k: only the update launch of block

@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in corenav_gp.h but not exported"
     assert declared == set(engine.EXPORTS), declared ^ set(engine.EXPORTS)
-    assert lib.cgp_abi_version() == 2
+    assert lib.cgp_abi_version() == engine.ABI_VERSION == 3
 
 
 def test_no_device_fails_loudly():

@@ -10,6 +10,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--streams", type=int, default=0, help="cgp_set_streams (0 = leave the default)")
 ap.add_argument("--reps", type=int, default=200)
 ap.add_argument("--n", type=int, default=None)
+ap.add_argument("--refine", type=int, default=None, help="cgp_set_refine (fp32: correction steps of alpha / the mean)")
 ap.add_argument("--sweep", action="store_true", help="the same call through cgp_sweep_fit_predict_device over [0] (a second context), its own streams")
 ap.add_argument("--torch-stream", action="store_true", help="enqueue on a fresh torch stream instead of the legacy default stream")
 a = ap.parse_args()
@@ -21,6 +22,8 @@ kid, X, y, Xs, th, dts = synth.config(a.config, batch=a.batch, **kw)
 W = bench.Workload(engine, torch, torch.device("cuda", 0), 0, kid, X, y, Xs, th, dts, a.streams)
 if a.streams:
     W.ctx.set_streams(a.streams)
+if a.refine is not None:
+    W.ctx.set_refine(a.refine)
 if a.torch_stream:
     ts = torch.cuda.Stream(torch.device("cuda", 0))
     W.stream = ts.cuda_stream
