@@ -286,6 +286,7 @@ def run_rank(args):
                        "fits_per_gpu_per_step": B if not strong else B_total / world, "fits_per_step_all_ranks": B_total,
                        "streams": args.streams, "pipeline_depth": depth, "N": N, "d": d, "M": M_TEST,
                        "single_fit_latency_ms": single_ms,
+                       "single_fit_cholesky_roofline_frac": (f_chol / 1e12 / (single_ms * 1e-3) / peak) if single_ms else None,
                        "fit_tflops": value * f_fit / 1e12, "cholesky_roofline_frac": value * f_chol / 1e12 / world / peak,
                        "inputs": "resident in HBM", "ensemble": ens,
                        "ranks": world, "collective_backend": ("rccl" if backend == "nccl" else backend) if use_dist else None,
@@ -304,6 +305,10 @@ def run_rank(args):
                 out["config"]["extra"] = extras(engine, torch, dev, local, W)
             if not args.no_cpu and world == 1:   # rank 0 at N = 1 only: other ranks would wait on the host work
                 out["cpu_baseline"] = cpu_baseline(kid, X, y, Xs, th, args.cpu_sample, W.dmean, W.dvar, W.dlogml, f_fit)
+                if single_ms and out["cpu_baseline"].get("value"):
+                    # BASELINE configs[1] read literally is ONE fit: its latency against the one-thread CPU rate (north_star's >= 100 x
+                    # is met by the batched rate, `value`; a lone fit is a chain of 16 block steps on a handful of CUs)
+                    out["config"]["single_fit_vs_cpu_1thread"] = (1e3 / single_ms) / out["cpu_baseline"]["value"]
                 if not args.no_extra and not strong:
                     try:
                         out["config"]["extra"]["node_cpu_baseline"] = node_cpu_leg(engine, local)
@@ -612,20 +617,32 @@ def extras_cfg3(engine, torch, dev, local, W):
             while time.perf_counter() - tw < 0.15:   # the part idled through the host leg: back to its working clock first
                 W3.step()
                 torch.cuda.synchronize()
+            n3 = 20   # (5 until round 6: the projection below moved +- 6 % between runs of one tree)
             t0 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(n3):
                 W3.step()
             torch.cuda.synchronize()
-            el = (time.perf_counter() - t0) / 5
+            el = (time.perf_counter() - t0) / n3
             assert int(W3.dinfo.abs().sum().item()) == 0
             rf, kms = W3.roofline(FP32_MFMA_PEAK_TFLOPS)
             ex["cfg3_fits_per_s"] = 512 / el
             ex["cfg3_ms_per_step"] = el * 1e3
+            ex["cfg3_steps"] = n3
             ex["cfg3_roofline_frac"] = rf["frac"]
+            # `cfg3_roofline_frac` prices the launch against the FP32-input MFMA peak (the instruction a plain fp32 kernel has).  The loop
+            # itself runs on the bf16 matrix cores, eight bf16 terms per fp32 product in the triangular product and six in the tile loop:
+            # against THAT pipe's ceiling (dense bf16 peak / 6, the generous bound) and against HBM the same launch reads as follows
+            if "frac_of_bf16x6_bound" in rf:
+                ex["cfg3_frac_of_bf16x6_bound"] = rf["frac_of_bf16x6_bound"]
+                ex["cfg3_bf16x6_bound_tflops"] = rf["bf16x6_bound_tflops"]
+            if rf.get("traffic") and rf.get("avg_launch_ms"):
+                ex["cfg3_hbm_frac"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                ex["cfg3_hbm_note"] = ("PMC bytes per k_panel launch (" + str(rf.get("traffic_source")) + ") / the launch's duration in this run / 8 TB/s: "
+                                       "neither the matrix cores nor HBM is saturated")
             ex["cfg3_kernel_ms_per_step"] = kms
             ex["cfg3_workload"] = "BASELINE configs[2]: 512 x N=1024 d=6 SE-ARD fp32, M=599, one GPU's view of the sweep"
             ex["cfg3_strong"] = {"fits_per_s": 512 / el, "ms_per_step": el * 1e3, "fits_per_step_all_ranks": 512, "fits_per_gpu_per_call": 512,
-                                 "n_gpus": 1, "scaling": "strong", "pipeline_depth": 1, "steps": 5,
+                                 "n_gpus": 1, "scaling": "strong", "pipeline_depth": 1, "steps": n3,
                                  "workload": "BASELINE configs[2] as written on ONE rank (the denominator of the strong-scaling curve; "
                                              "`bench.py --gpus N` reports the same key over N ranks)"}
             # configs[2] AS WRITTEN shards the 512 fits over 8 GPUs: 64 fits per GPU and call.  The same engine on the
@@ -826,10 +843,13 @@ def window_line(engine, torch, dev, local, W=1024, N=512, d=3, T=200):
     # 430 GB algorithmic -- the HBM pipe itself is at 0.64 of the algorithmic fraction
     kCounterOverAlgorithmic = 275.9 / 429.5
     return {"window_ticks_per_s": W * T / el, "window_hbm_frac": gbps / HBM_PEAK_GBPS,
-            "window_hbm_frac_counter_traffic": gbps / HBM_PEAK_GBPS * kCounterOverAlgorithmic, "window_host_tick_us": host_tick_us,
-            "window_traffic_note": "window_hbm_frac = ALGORITHMIC bytes per tick (factor read + written once) x ticks/s / 8 TB/s; the kernel takes "
-                                   "steady-state ticks two per pass, so the traffic the PMC counters see is 0.64 of that "
-                                   "(profiles/r05_window_pmc_summary.json): window_hbm_frac_counter_traffic is what the HBM pipe carries",
+            "window_hbm_frac_counter_traffic_projected": gbps / HBM_PEAK_GBPS * kCounterOverAlgorithmic, "window_host_tick_us": host_tick_us,
+            "window_counter_over_algorithmic": {"ratio": kCounterOverAlgorithmic, "from": "profiles/r05_window_pmc_summary.json (commit 1910133's kernels: "
+                                                "unchanged since), NOT measured in this run"},
+            "window_traffic_note": "window_hbm_frac = ALGORITHMIC bytes per tick (factor read + written once) x ticks/s / 8 TB/s, measured in this run; the "
+                                   "kernel takes steady-state ticks two per pass, so the traffic the PMC counters saw is 0.64 of that: "
+                                   "window_hbm_frac_counter_traffic_projected = this run's rate x that committed ratio, a projection (tools/pmc_window.sh "
+                                   "re-measures the ratio)",
             "window_workload": f"BASELINE configs[3]: {W} windows x N={N} d={d} fp64, {T} ticks, algorithmic {gbps:.0f} GB/s of {HBM_PEAK_GBPS:.0f}"}
 
 

@@ -1,7 +1,7 @@
 """ROS-free closed-loop replay of the corenav-GP slip loop (the stand-in for
 BASELINE configs[4]: the Pathfinder bag is not obtainable, so the sensor stream is synthetic).
 
-    RoverSim (wheel + INS speeds, 10 Hz) --> SlipRecorder [CoreNav::Update, C++]
+    RoverSim (wheel + INS speeds, 10 Hz; IMU specific force + rate, 50 Hz --> FilterCovariance) --> SlipRecorder [CoreNav::Update, C++]
         --/core_nav/core_nav/gp_input-->   GP engine [gp_slip_node.py arithmetic, HIP]
         --/core_nav/core_nav/gp_result-->  GpPredictor [gp_predictor.cpp, C++]  <-- stopping_service
         --/core_nav/core_nav/stop_cmd-->   SlipRecorder.stopCallback + DriveStraightWithStop FSM
@@ -28,7 +28,9 @@ class RoverSim:
 
     def __init__(self, seed):
         self.rng = np.random.default_rng(seed)
+        self.imu_rng = np.random.default_rng(seed + 7919)   # its own generator: the slip sequence does not depend on the IMU stream
         self.tick = 0
+        self.v_prev = 0.0
 
     def step(self, driving):
         self.tick += 1
@@ -39,6 +41,19 @@ class RoverSim:
         wheels = tuple(DRIVE_SPEED * (1.0 + 0.002 * self.rng.normal()) for _ in range(4))
         vlin = float(np.mean(wheels)) * (1.0 - float(np.clip(slip, -0.9, 0.9)))
         return wheels, vlin
+
+    def imu(self, vlin):
+        """The IMU_PER_ODO body-frame samples (specific force f_b [m/s^2], angular rate w_b [rad/s]) of one odometry period, 50 Hz
+        (parameters.yaml:46: the reference's ADIS IMU rate): forward acceleration between two odometry speeds, gravity on z, a
+        slowly wandering yaw rate, sensor noise at the levels of CoreNav's Q (sig_gyro_inRun / sig_accel_inRun)."""
+        a_x = (vlin - self.v_prev) / DT_ODO
+        self.v_prev = vlin
+        out = []
+        for _ in range(IMU_PER_ODO):
+            f_b = np.array([a_x, 0.0, -9.80665]) + self.imu_rng.normal(0.0, 0.02, 3)
+            w_b = np.array([0.0, 0.0, 0.01 * np.sin(self.tick / 50.0)]) + self.imu_rng.normal(0.0, 1e-3, 3)
+            out.append((f_b, w_b))
+        return out
 
 
 class DriveStraightWithStop:
@@ -89,7 +104,8 @@ class FilterCovariance:
     def __init__(self, P, Q, STM, H, zero_updates_enabled=True):
         self.P = np.array(P, dtype=np.float64).reshape(15, 15)
         self.Q = np.asarray(Q, dtype=np.float64).reshape(15, 15)
-        self.STM = np.asarray(STM, dtype=np.float64).reshape(15, 15)
+        self.STM0 = np.asarray(STM, dtype=np.float64).reshape(15, 15)   # the trajectory's synthetic transition matrix at rest
+        self.STM = self.STM0.copy()                                     # ... and of the latest IMU step (what setStopping_ serves)
         self.H = np.asarray(H, dtype=np.float64).reshape(4, 15)
         self.P_pred = self.P.copy()
         self.zero_updates = 0
@@ -101,8 +117,27 @@ class FilterCovariance:
         IKH = np.eye(15) - K @ H
         return IKH @ P @ IKH.T + K @ R @ K.T
 
-    def odometry_tick(self, stopped):
-        for _ in range(IMU_PER_ODO):
+    @staticmethod
+    def _skew(v):
+        return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+
+    def imu_transition(self, f_b, w_b):
+        """The IMU-dependent blocks of the error-state transition over one 20 ms IMU step (the first-order terms every INS
+        error model has -- CoreNav builds its STM_ from the same measurements in insErrorStateModel_LNF, CoreNav.cpp:104 is where
+        it is applied): attitude error rotates with the measured rate, velocity error picks up -[f x] times the attitude
+        error; everything else stays the trajectory's synthetic matrix.  States: 0-2 attitude, 3-5 velocity (CoreNav's order)."""
+        dt = DT_ODO / IMU_PER_ODO
+        STM = self.STM0.copy()
+        STM[0:3, 0:3] -= self._skew(w_b) * dt
+        STM[3:6, 0:3] -= self._skew(f_b) * dt
+        return STM
+
+    def odometry_tick(self, stopped, imu=None):
+        """One odometry period: IMU_PER_ODO propagations, each with the transition matrix of ITS IMU sample when a stream is
+        given (imu = [(f_b, w_b)] * IMU_PER_ODO, RoverSim.imu), else with the fixed matrix (round 5's form)."""
+        for j in range(IMU_PER_ODO):
+            if imu is not None:
+                self.STM = self.imu_transition(*imu[j])
             self.P = self.STM @ self.P @ self.STM.T + self.Q
             if stopped and self.zero_updates_enabled:   # |rearVel_| < 0.005 (CoreNav.cpp:139): the commanded stop holds the wheels
                 self.P = self._joseph(self.P, _H_ZERO, _R_ZERO)
@@ -115,8 +150,9 @@ class FilterCovariance:
 
 
 class Trajectory:
-    def __init__(self, seed, evolve_filter=True, zero_updates=True):
+    def __init__(self, seed, evolve_filter=True, zero_updates=True, imu_stream=True):
         self.sim = RoverSim(seed)
+        self.imu_stream = imu_stream   # False: every propagation with the trajectory's fixed matrix (round 5)
         self.rec = engine.SlipRecorder()
         self.drv = DriveStraightWithStop()
         self.P, self.Q, self.STM, self.Hvec, self.pos, H = synth.filter_state(seed, with_H=True)
@@ -134,20 +170,23 @@ class Trajectory:
         self.rec.cmd_callback(cmd)
         wheels, vlin = self.sim.step(cmd != 0.0)
         if self.cov is not None:
-            self.cov.odometry_tick(cmd == 0.0)
+            # the filter runs at the IMU rate: five 50 Hz samples per 10 Hz odometry tick, each with its own transition matrix
+            self.cov.odometry_tick(cmd == 0.0, self.sim.imu(vlin) if self.imu_stream else None)
         win = self.rec.update(*wheels, vlin, cmd)
         if win is not None and self.cov is not None:
-            # CoreNav.cpp:289-305: the snapshot is taken at the tick that publishes the window
+            # CoreNav.cpp:289-305: the snapshot is taken at the tick that publishes the window; setStopping_ (:652-676) serves
+            # P_pred together with the filter's CURRENT Q_, STM_, H_
             self.cov.snapshot()
             self.P = self.cov.P_pred.reshape(225).copy()
-            self.served.append((self.P.copy(), self.cov.zero_updates))
+            self.STM = self.cov.STM.reshape(225).copy()
+            self.served.append((self.P.copy(), self.cov.zero_updates, self.STM.copy()))
         return win
 
 
 class ClosedLoopEnsemble:
     def __init__(self, n_traj, theta=(0.5, 30.0, 0.01, 0.002), optimize=False, device=0, seed=synth.SEED_BASE + 5,
-                 evolve_filter=True, zero_updates=True):
-        self.traj = [Trajectory(seed + 31 * i, evolve_filter, zero_updates) for i in range(n_traj)]
+                 evolve_filter=True, zero_updates=True, imu_stream=True):
+        self.traj = [Trajectory(seed + 31 * i, evolve_filter, zero_updates, imu_stream) for i in range(n_traj)]
         self.theta = np.asarray(theta, dtype=np.float64)
         self.optimize = optimize
         self.ctx = engine.Context(device=device, max_n=256, max_m=1024, max_d=1, max_batch=max(n_traj, 1))   # max_m >= N: optimiser needs it

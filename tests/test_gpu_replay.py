@@ -98,8 +98,33 @@ def test_stop_feedback_closes_the_loop():
         # the second look-ahead, restated by the oracle on what each run served
         (mean, sigma, th) = tr.results[1]
         H = go.unpack_H(tr.Hvec, True)
-        f1, c1, i1, xy1, trace1 = go.predict_stop(mean, sigma, tr.served[1][0], tr.Q, tr.STM, H, tr.pos, return_trace=True)
-        f0, c0, i0, xy0, trace0 = go.predict_stop(mean, sigma, tc.served[1][0], tc.Q, tc.STM, H, tc.pos, return_trace=True)
+        f1, c1, i1, xy1, trace1 = go.predict_stop(mean, sigma, tr.served[1][0], tr.Q, tr.served[1][2], H, tr.pos, return_trace=True)
+        f0, c0, i0, xy0, trace0 = go.predict_stop(mean, sigma, tc.served[1][0], tc.Q, tc.served[1][2], H, tc.pos, return_trace=True)
         n = min(len(trace0), len(trace1))
         assert np.all(trace1[:n] < trace0[:n]) and i1 >= i0                      # the stop lowered the trace
         assert f1 and tr.stop_cmds[1] == pytest.approx(c1, rel=1e-9)             # and the engine published the oracle's answer
+
+
+def test_filter_runs_at_the_imu_rate():
+    """the covariance bookkeeping behind SetStopping is driven at the 50 Hz IMU rate from a generated IMU stream
+    (five samples per 10 Hz odometry tick, each with its own transition matrix: the attitude error rotates with the measured
+    rate, the velocity error picks up -[f x] attitude error) -- not the EKF (no state, no mechanisation).  What is served
+    differs from the fixed-matrix form and from trajectory to trajectory; the closed loop still publishes the oracle's answer
+    on what it served."""
+    from corenav_gp_amd import replay
+    ens = replay.ClosedLoopEnsemble(n_traj=3)
+    fix = replay.ClosedLoopEnsemble(n_traj=3, imu_stream=False)
+    ens.run(700)
+    fix.run(700)
+    for tr, tf in zip(ens.traj, fix.traj):
+        assert len(tr.windows) >= 1 and len(tr.served) == len(tr.windows)
+        np.testing.assert_array_equal(tr.windows[0][1], tf.windows[0][1])          # the slip stream does not depend on the IMU stream
+        P, nz, STM = tr.served[0]
+        assert not np.allclose(STM, tf.served[0][2]) and not np.allclose(P, tf.served[0][0], rtol=1e-6, atol=0)
+        Pm = P.reshape(15, 15)
+        assert np.allclose(Pm, Pm.T, rtol=1e-9, atol=1e-18) and np.all(np.linalg.eigvalsh(0.5 * (Pm + Pm.T)) > -1e-12)
+        (mean, sigma, th) = tr.results[0]
+        f, c, i, xy = go.predict_stop(mean, sigma, P, tr.Q, STM, go.unpack_H(tr.Hvec, True), tr.pos)
+        if f:
+            assert tr.stop_cmds[0] == pytest.approx(c, rel=1e-9)
+    assert not np.allclose(ens.traj[0].served[0][2], ens.traj[1].served[0][2])

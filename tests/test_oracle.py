@@ -6,7 +6,9 @@ import math
 import numpy as np
 import pytest
 
-from conftest import load_golden
+import os
+
+from conftest import GOLDEN, load_golden
 from oracle import gp_oracle as go
 
 SK = ["sk_se_iso_n256_d3", "sk_se_ard_n2_d1", "sk_se_ard_n15_d3", "sk_se_ard_n134_d6", "sk_se_ard_n256_d6",
@@ -234,3 +236,22 @@ def test_optimize_improves_likelihood():
     # stationarity in the transformed space
     nll, gr = go.nll_and_grad(2, th, xtr, ytr[:, 0])
     assert np.max(np.abs(gr * -np.expm1(-th))) < 1e-2
+
+
+def test_fixture_classes():
+    """tests/golden/README.md: every fixture says where its expected values come from; the ones the oracle itself produced
+    (`restated`) are regression vectors, not pins, and each has a pin of the same quantity next to it."""
+    import glob
+    pins = {"closed", "kalman", "sklearn", "mpmath", "restated+scipy"}
+    readme = open(os.path.join(GOLDEN, "README.md")).read()
+    regression = []
+    for f in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
+        name = os.path.splitext(os.path.basename(f))[0]
+        src = str(load_golden(name)["source"])
+        assert src in pins | {"restated"}, (name, src)
+        if src == "restated":
+            regression.append(name)
+            assert name in readme.split("**regression**")[1], name
+    assert sorted(regression) == ["llh_to_enu_restated", "lookahead_restated", "slipval_window_rbfbrownian", "synth_window_rbfbrownian"]
+    for pin in ("mp_rbfbrownian_n134", "mp_lookahead"):
+        assert str(load_golden(pin)["source"]) == "mpmath"
