@@ -1745,6 +1745,9 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
 // MID: kinds C / image-A compiled in (their branches cost registers the full-batch build cannot spare).  In fp32 the
 // mid-size build also takes the fat form of the diagonal tile (79 KB of LDS: two workgroups per CU, which these calls do
 // not fill anyway); fp64 would need 147 KB, one workgroup per CU, and keeps the packed form.
+#ifndef CGP_KINDA_PRIO
+#define CGP_KINDA_PRIO 0   // s_setprio of the kind-A workgroup's waves in the mid-size build (0: none; `make variant` A/B)
+#endif
 #ifndef CGP_F32_FULL_OCC
 #define CGP_F32_FULL_OCC 4   // workgroups per CU the register-staged fp32 build is compiled for: 128 VGPRs -- the tile loop has none spilled (the
                              // Gram / diagonal-tile code around it has: 85 in the fused kernel) -- and 38 KB of LDS; at three per CU (153 VGPRs, no
@@ -1788,6 +1791,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (DEEP ? ((MID && (CGP_MID_RIN
       b = ia;
       rt = k + 1;
       finish_next = !CGP_DBG_ON(p, 65536);
+      // The kind-A workgroup IS the block step's critical path in a call that does not fill the chip (tile (k + 1, k), then the
+      // diagonal tile: 77 us alone, 86 ... 95 us beside the bulk tile its CU also hosts); its waves take the issue slots first.
+      if constexpr (MID && CGP_KINDA_PRIO > 0) __builtin_amdgcn_s_setprio(CGP_KINDA_PRIO);
       if (MID && (p.diag_slots & 8)) {  // tile (k + 1, k) minus block column k - 1 is waiting in the image
         from_image = true;
         c_first = (k - 1) * (TS / KT);
