@@ -74,6 +74,7 @@ struct cgp_ctx {
   int nstreams = 0;   // cgp_set_streams: 0 = the engine decides (two groups for fp32 calls of 56 ... 96 fits, else one); n >= 1 = as told
   // device buffers
   void *Lw = nullptr, *Winv = nullptr, *dX = nullptr, *dXs = nullptr, *dy = nullptr;
+  void *Lp = nullptr;   // fp32: the panel tiles of a mid-size call as bf16 planes [mid_cap][3][lw_stride] (cgp_kernels_fused.hpp, bx6p_loop)
   void *dmean = nullptr, *dvar = nullptr, *dalpha = nullptr;
   // fp32 contexts: mixed-precision refinement of alpha and the predictive mean (cgp_refine.hpp, cgp_set_refine)
   double *dref_r = nullptr, *dref_a = nullptr;   // [max_batch][alpha_stride] residual, alpha in double precision
@@ -385,6 +386,7 @@ template <typename T> FitArgs group_view(const FitArgs &a, int g0) {
   };
   v.Lw = const_cast<void *>(adv(a.Lw, (size_t)g0 * a.lw_stride));
   v.Winv = const_cast<void *>(adv(a.Winv, (size_t)g0 * a.winv_stride));
+  v.Lp = a.Lp ? static_cast<void *>(static_cast<unsigned short *>(a.Lp) + (size_t)g0 * a.lp_stride) : nullptr;
   v.dpart = const_cast<void *>(adv(a.dpart, (size_t)g0 * 2 * DPART));
   v.pimg = const_cast<void *>(adv(a.pimg, (size_t)g0 * 2 * DPART));
   v.X = adv(a.X, (size_t)g0 * a.d * a.N);
@@ -976,6 +978,8 @@ FitArgs base_args(cgp_ctx *c, int N, int d, int M, int kid, int include_noise) {
   a.ld = c->ld;
   a.Winv = c->Winv;
   a.winv_stride = c->winv_stride;
+  a.Lp = c->Lp;
+  a.lp_stride = 3 * c->lw_stride;
   a.alpha = c->dalpha;
   a.alpha_stride = c->alpha_stride;
   a.prep = c->dprep;
@@ -1201,6 +1205,7 @@ cgp_ctx *cgp_create_ex(int device, int max_n, int max_m, int max_d, int max_batc
   ok = ok && hipMalloc(&c->ddiagimg, B * 2 * DPART * c->esz) == hipSuccess;
   c->mid_cap = std::min(MID_FITS_ALLOC, max_batch);
   ok = ok && hipMalloc(&c->dpanimg, (size_t)c->mid_cap * 2 * DPART * c->esz) == hipSuccess;
+  if (dtype == CGP_F32 && kMidPlanes) ok = ok && hipMalloc(&c->Lp, (size_t)c->mid_cap * 3 * c->lw_stride * sizeof(unsigned short)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->ddbg, DBG_SLOTS * sizeof(long long)) == hipSuccess;
   ok = ok && hipMemset(c->ddbg, 0, DBG_SLOTS * sizeof(long long)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->dprep, B * PREP_N * sizeof(double)) == hipSuccess;
@@ -1238,7 +1243,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg, c->dpanimg, c->dsmall, c->dsmdeal, c->dref_r, c->dref_a, c->dref_flag};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg, c->dpanimg, c->dsmall, c->dsmdeal, c->dref_r, c->dref_a, c->dref_flag, c->Lp};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {

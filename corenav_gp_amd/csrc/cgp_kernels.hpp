@@ -84,6 +84,8 @@ struct FitArgs {
   int xid;               // 1: the M (= N) "test rows" are the identity, so the extra block becomes (L^-1)^T (gradient mode)
   double *gpart;         // [batch][pairs][GRAD_N] per-tile-pair partial sums of k_grad
   int *rflag;            // [batch] or null: k_finalize marks the fits whose fp32 mean wants the refinement (cgp_refine.hpp, RF_RHO)
+  void *Lp;              // fp32 mid-size calls: the panel tiles a second time, split into three bf16 planes (bx6p_loop); null otherwise
+  size_t lp_stride;      // bf16 elements per fit (3 planes of lw_stride elements)
   long long *dbgbuf;     // 64 slots of s_memtime stamps / per-phase cycle sums (-DCGP_ABLATION builds)
   int dbg;               // timing ablations (env CGP_DBG); only a -DCGP_ABLATION build reads it
 };

@@ -440,6 +440,138 @@ __device__ __forceinline__ void bx6_loop(Prec<float>::acc_t (&acc)[NCB][2], BxSt
 }
 
 // --------------------------------------------------------------------------------------------------
+// The mid-size build's tile loop on panels that arrive ALREADY SPLIT (round 6).  Inside a call that leaves a CU one or two
+// workgroups a tile's duration is its loop's latency, and the register-staged split above costs a wave as many issue cycles as the
+// products themselves (16 loads, ~90 VALU, 6 ds_write per chunk against 48 MFMAs: 3 000 ticks per chunk measured, 768 of them MFMA).
+// So the workgroup that PRODUCES a tile of L writes it twice: as fp32 (everything else reads that) and as three bf16 planes,
+//     Lp[plane][16-column chunk][row][16]        (one chunk of one tile = 4 KB contiguous per plane)
+// and a consumer's staging is six LDS-DMA instructions per wave and chunk -- no VGPR, no VALU, no ds_write: lane i of wave w
+// fetches the 16 bytes that belong at LDS unit 64 w + i of the plane (the swizzle of bx_pos and the row order of bx_row_slot are a
+// permutation INSIDE a wave's 1 KB, applied on the global side).  Three chunk buffers of 24 KB, chunks c + 1 and c + 2 in flight
+// while chunk c is multiplied (hand-counted `s_waitcnt vmcnt(6)`), one barrier per chunk.  The products, their order and the planes'
+// values are those of bx6_loop: results are bitwise the register-staged form's.  1.5 x the panel bytes from HBM -- which is why the
+// full-batch build (HBM at 3.5 TB/s) would keep the register-staged split and only calls of at most 96 fits take this form.
+// --------------------------------------------------------------------------------------------------
+// MEASURED, NOT SHIPPED (round 6, docs/negatives.md): the loop itself is 22-27 % faster per tile (k = 5: 119 k -> 93 k ticks, k = 7:
+// 142 k -> 104 k; 1 850 ticks per chunk) and every result is bitwise the register-staged build's, but a tile's store phase grows
+// from 3 k to 10 k ticks (48 eight-byte plane stores per lane) -- on the kind-A chain too -- and the late launches of a 64-fit call
+// are bound by 576-704 workgroups meeting 512 slots, not by the tile's length: 0.704 ms per call against 0.697 (two stream groups),
+// 0.770 against 0.718 (one).  `make variant EXTRA=-DCGP_MID_PLANES=1` builds it (the context then allocates the planes).
+#ifndef CGP_MID_PLANES
+#define CGP_MID_PLANES 0
+#endif
+constexpr bool kMidPlanes = CGP_MID_PLANES != 0 && kF32Bf16x6;
+constexpr int BXP_BUF = 6 * BX_PLANE * 2;   // bytes of one chunk buffer: six planes of 4 KB
+constexpr int BXP_NBUF = 3;
+struct BxPlaneSrc {
+  const unsigned short *gR, *gC;   // this lane's 16 bytes of plane 0, chunk 0 of the row / column panel
+  size_t chunk_stride, plane_stride;   // bf16 elements
+  __device__ __forceinline__ void init(const unsigned short *planes, size_t plane_elems, int ld, int chunk0, int row_tile, int col_tile, int tid) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = 32 * wave + (lane >> 1);
+    const int h = ((lane & 1) ^ (slot >> 2) ^ (slot >> 4)) & 1;                       // bx_pos: which half of the row sits at this unit
+    const int rowR = (slot & ~31) | ((slot & 15) << 1) | ((slot >> 4) & 1);          // inverse of bx_row_slot
+    chunk_stride = (size_t)ld * BXS;
+    plane_stride = plane_elems;
+    const unsigned short *base = planes + (size_t)chunk0 * chunk_stride;
+    gR = base + ((size_t)row_tile * TS + rowR) * BXS + 8 * h;
+    gC = base + ((size_t)col_tile * TS + slot) * BXS + 8 * h;
+  }
+  // chunk c of both panels -> buffer `buf` (byte offset): 6 wave-instructions of 1 KB each
+  __device__ __forceinline__ void issue(int c, unsigned char *smem_bytes, int buf, int wave) const {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    const unsigned short *r = gR + (size_t)c * chunk_stride, *q = gC + (size_t)c * chunk_stride;
+    unsigned char *dst = smem_bytes + buf + wave * 1024;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      __builtin_amdgcn_global_load_lds((gbl_void *)(r + pl * plane_stride), (lds_void *)(dst + pl * 2 * BX_PLANE), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void *)(q + pl * plane_stride), (lds_void *)(dst + (3 + pl) * 2 * BX_PLANE), 16, 0, 0);
+    }
+  }
+};
+// the tile's own planes, written next to store_tile's fp32 copy: lane (l15, lq) holds k = 4 lq + r of rows 2 l15 + {0, 1} of its wave's slab
+__device__ __forceinline__ void store_tile_planes(const Prec<float>::acc_t (&acc)[NCB][2], unsigned short *planes, size_t plane_elems, int ld, int rt, int k,
+                                                  int tid) {
+  const int lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  typedef unsigned bxu2 __attribute__((ext_vector_type(2)));
+  unsigned short *out = planes + ((size_t)(k * (TS / KT)) * ld + (size_t)rt * TS + wave * 32 + 2 * l15) * BXS + 4 * lq;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const float v[8] = {acc[cb][0][0], acc[cb][0][1], acc[cb][0][2], acc[cb][0][3], acc[cb][1][0], acc[cb][1][1], acc[cb][1][2], acc[cb][1][3]};
+    bxu4 w[3];
+    bx_split8(v, w);
+    unsigned short *o = out + (size_t)cb * ld * BXS;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      *reinterpret_cast<bxu2 *>(o + pl * plane_elems) = bxu2{w[pl][0], w[pl][1]};           // row 2 l15
+      *reinterpret_cast<bxu2 *>(o + pl * plane_elems + BXS) = bxu2{w[pl][2], w[pl][3]};     // row 2 l15 + 1
+    }
+  }
+}
+// zs != null (extra rows, running predictive sums): V z and V^2 over the newest block column (the last 8 chunks), from the fp32
+// copy -- the planes never pass through registers.  ms as bx6_loop leaves it.
+__device__ __forceinline__ void bx6p_loop(Prec<float>::acc_t (&acc)[NCB][2], const BxPlaneSrc &src, int nchunk, float *smem, int tid, const float *zs, float *ms,
+                                          bool live, const float *gR32, size_t ldR32) {
+  if (nchunk <= 0) return;
+  unsigned char *sb = reinterpret_cast<unsigned char *>(smem);
+  const int lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lq >> 1;
+  const unsigned base = (unsigned)(size_t)smem;
+  // this lane's fragments of plane 0 of buffer 0 (bx6_loop's pa / pb as LDS byte addresses)
+  const unsigned lb0[2] = {base + 2 * bx_pos(wave * 32 + l15, lq & 1), base + 2 * bx_pos(wave * 32 + DB + l15, lq & 1)};
+  const unsigned la0[2] = {base + 2 * (3 * BX_PLANE + bx_pos(l15, lq & 1)), base + 2 * (3 * BX_PLANE + bx_pos(DB + l15, lq & 1) - DB * BXS)};
+  // (chunks 0 and 1 were issued by the caller before the Gram phase: bx6p_prologue)
+  int buf = 0;
+  for (int c = 0; c < nchunk; ++c) {
+    // everything but the six DMAs of chunk c + 1 has landed, i.e. chunk c is in its buffer -- for this wave's share; the barrier
+    // makes it everybody's, and says every wave is done with chunk c - 1, whose buffer chunk c + 2 takes
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    lds_barrier();
+    const int nb = buf == 0 ? 2 * BXP_BUF : buf - BXP_BUF;   // buffer of chunk c + 2 = (c - 1) mod 3
+    src.issue(c + 2 < nchunk ? c + 2 : nchunk - 1, sb, nb, wave);   // past the end: the last chunk again (never read), so the count holds
+    if (live) {
+      const unsigned la[2] = {la0[0] + buf, la0[1] + buf}, lb[2] = {lb0[0] + buf, lb0[1] + buf};
+      bx6_compute_pipe<0>(acc, la, lb, hi);
+    }
+    buf = buf == 2 * BXP_BUF ? 0 : buf + BXP_BUF;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (zs) {
+    // row r = tid & 127, columns 8 h .. 8 h + 7 of each of the newest block column's eight chunks
+    const int r = tid & (TS - 1), h8 = 8 * (tid >> 7), zfirst = nchunk - TS / KT;
+    float pz = 0.f, pv = 0.f;
+    const float *g = gR32 + (size_t)(zfirst * KT + h8) * ldR32 + r;
+#pragma unroll
+    for (int c = 0; c < TS / KT; ++c) {
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = g[(size_t)(c * KT + i) * ldR32];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        pz = __builtin_fmaf(x[i], zs[c * KT + h8 + i], pz);
+        pv = __builtin_fmaf(x[i], x[i], pv);
+      }
+    }
+    smem[tid] = pz;
+    smem[2 * TS + tid] = pv;
+    __syncthreads();
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rr = wave * 32 + 2 * lane + j;
+        ms[j] = smem[rr] + smem[TS + rr];
+        ms[2 + j] = smem[2 * TS + rr] + smem[3 * TS + rr];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
 // fp64 panel loop with the row panel kept out of LDS.  A wave's B operand is its own 32 rows of the
 // row panel and nobody else reads them, so they are loaded straight into registers (one 16-byte
 // load per lane and k-step: rows 2 l15 + {0,1}, column 4 ks + lq -- 256-byte runs per 16 lanes);
@@ -1646,8 +1778,9 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
   constexpr bool BX6 = kF32Bf16x6 && sizeof(T) == 4 && (!DEEP || MID);
   constexpr bool BXDBL = DEEP;
   constexpr int BXD = DEEP ? kBxMidSets : 1;
-  constexpr int GRAM_OFF = BX6 ? BX_FLOATS : CH2;               // where the Gram inputs are staged (BXDBL: over the second plane buffer)
-  T *zs = smem + (BX6 ? bx_z_offset<BXDBL>() : R * KT * LDST);
+  constexpr bool PL = kMidPlanes && BX6 && MID;                 // panels arrive as bf16 planes by LDS-DMA (bx6p_loop): three chunk buffers
+  constexpr int GRAM_OFF = PL ? 2 * BXP_BUF / 4 : (BX6 ? BX_FLOATS : CH2);   // where the Gram inputs are staged (BXDBL: over the second plane buffer; PL: the third)
+  T *zs = smem + (PL ? BXP_NBUF * BXP_BUF / 4 : (BX6 ? bx_z_offset<BXDBL>() : R * KT * LDST));
   if (tid < TS) zs[tid] = accm ? Lw[(size_t)((k - 1) * TS + tid) * ld + (size_t)p.NT * TS + p.M] : T(0);
   T ms[4] = {T(0), T(0), T(0), T(0)};
   if constexpr (DEEP && !BX6) {
@@ -1662,12 +1795,18 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
     pc.lap(p, ps + 0);
     mfma_rowpanel_loop_rdirect<T, R>(acc, rf, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, zs, ms);
   } else {
-    BxStage<BXD> bxs;   // (only the bf16-plane build uses it)
+    BxStage<PL ? 1 : BXD> bxs;   // (only the register-staged bf16-plane build uses it)
+    BxPlaneSrc bps;              // (only the DMA build)
     {
       GramPre<T> gp;
       if (!(MID && from_image)) gram_prefetch<T>(p, b, k, rt, tid, gp);
       if (nchunk > 0) {
-        if constexpr (BX6) {
+        if constexpr (PL) {
+          bps.init(reinterpret_cast<const unsigned short *>(p.Lp) + (size_t)b * p.lp_stride, p.lp_stride / 3, ld, c_first, rt, k, tid);
+          const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+          bps.issue(0, reinterpret_cast<unsigned char *>(smem), 0, wv);        // chunks 0 and 1: in flight through the Gram phase
+          bps.issue(1, reinterpret_cast<unsigned char *>(smem), BXP_BUF, wv);
+        } else if constexpr (BX6) {
           bxs.init(gR, (size_t)ld, gC, (size_t)ld, nchunk, tid);
           bx6_prologue(bxs, nchunk);   // in flight through the Gram phase
         } else stage_first_chunk<T>(gR, (size_t)ld, gC, (size_t)ld, smem, tid);
@@ -1683,7 +1822,8 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
       else gram_apply<T>(p, acc, smem + GRAM_OFF, b, k, rt, tid, gp, &pc, ps + 6, -1, live);
     }
     pc.lap(p, ps + 0);
-    if constexpr (BX6) bx6_loop<BXD, BXDBL>(acc, bxs, nchunk, smem, tid, accm ? zs : nullptr, ms, live);
+    if constexpr (PL) bx6p_loop(acc, bps, nchunk, smem, tid, accm ? zs : nullptr, ms, live, gR, (size_t)ld);
+    else if constexpr (BX6) bx6_loop<BXD, BXDBL>(acc, bxs, nchunk, smem, tid, accm ? zs : nullptr, ms, live);
     else mfma_rowpanel_loop<T, true>(acc, gR, (size_t)ld, gC, (size_t)ld, nchunk, smem, tid, accm ? zs : nullptr, ms, live);
   }
   pc.lap(p, ps + 1);
@@ -1723,6 +1863,9 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
   pc.lap(p, ps + 4);
   if (live && (!CGP_DBG_ON(p, 32768) || acc[0][0][0] == T(12345.678)))  // timing probe: no store
   store_tile<T>(acc, Lw + (size_t)(k * TS) * ld + (size_t)rt * TS, ld, tid);
+  if constexpr (PL) {   // ... and as bf16 planes, for the tiles that take this one as a panel (rows beyond the window's y row are never read)
+    if (live) store_tile_planes(acc, reinterpret_cast<unsigned short *>(p.Lp) + (size_t)b * p.lp_stride, p.lp_stride / 3, ld, rt, k, tid);
+  }
   pc.lap(p, ps + 5);
   pc.count(p, ps + 7);
   if constexpr (DIAGNEXT) {
