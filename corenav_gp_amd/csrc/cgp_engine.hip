@@ -321,6 +321,7 @@ template <typename T> int set_lds_attrs(int device) {
   ok = ok && set(reinterpret_cast<const void *>(&k_sched<T>), paneldiag_mid_lds_bytes<T>());
 #endif
   if constexpr (sizeof(T) == 4) ok = ok && set(reinterpret_cast<const void *>(&k_refine_solve<float>), 160 * 1024);
+  if constexpr (sizeof(T) == 4) ok = ok && set(reinterpret_cast<const void *>(&k_refine_gated<float>), 160 * 1024);
   if constexpr (mid_fat<T, true>()) ok = ok && set(reinterpret_cast<const void *>(&k_diag_lean<T, true>), paneldiag_mid_lds_bytes<T>());
   if constexpr (CGP_F32_FULL_DEEP && sizeof(T) == 4) ok = ok && set(reinterpret_cast<const void *>(&k_panel<T, true, true, false>), paneldiag_lds_bytes<T>());
 #ifdef CGP_AB
@@ -553,8 +554,8 @@ template <typename T> int run_sched(cgp_ctx *, FitArgs, int, hipStream_t) { retu
 // ones k_finalize marks as dense (FitArgs::rflag, RF_RHO).  -1 (the default) = one step; every fit of a window of at most three
 // input dimensions (measured, 40 fits of N = 1000, mean error against the oracle without / with: d = 1 1.0e-3 / 6e-7, d = 2
 // 7e-4 / 1.5e-7, d = 3 3.1e-4 with a worst fit at 1.1e-3 / 1e-7), the marked fits beyond (d = 4: two windows of 43 000 fuzz cases
-// at 1.1 and 1.3e-3, rho = 21; d = 6: 7e-5, worst 1.8e-4, rho 3 ... 8): BASELINE configs[2] (d = 6, rho 3 ... 6) pays four
-// launches whose workgroups return at once.
+// at 1.1 and 1.3e-3, rho = 21; d = 6: 7e-5, worst 1.8e-4, rho 3 ... 8): BASELINE configs[2] (d = 6, rho 3 ... 11.5) pays one
+// launch whose workgroups return at once (k_refine_gated).
 constexpr int kRefineAutoMaxD = 3;
 inline int refine_steps(const cgp_ctx *c, const FitArgs &a) {
   if (c->dtype != CGP_F32 || !c->dref_a || a.xid || a.NT > kRefineMaxNT) return 0;
@@ -575,6 +576,11 @@ template <bool MEAN> void launch_refine_gemv(int rows, int nfits, hipStream_t s,
 // then the mean of the M test points.
 inline void launch_refine(cgp_ctx *c, const FitArgs &a, int nfits, int g0, hipStream_t s, int steps, bool solve, bool alpha_for_all) {
   const RefineArgs q{c->dref_r + (size_t)g0 * c->alpha_stride, c->dref_a + (size_t)g0 * c->alpha_stride, c->alpha_stride, a.rflag};
+  if (solve && q.flag && !alpha_for_all && a.NT <= kRefineGatedMaxNT) {
+    // d > 3 under the default setting: k_finalize marked the dense fits, almost always none -- one launch, not four
+    hipLaunchKernelGGL(k_refine_gated<float>, dim3(nfits), dim3(RS_THREADS), refine_gated_lds_bytes(a.NT), s, a, q, steps, a.M > 0 ? 1 : 0);
+    return;
+  }
   if (solve) {
     const size_t lds = refine_solve_lds_bytes(a.NT);
     RefineArgs q0 = q;

@@ -139,7 +139,7 @@ constexpr int RS_THREADS = 1024;
 // (lanes = 16 rows c of four consecutive row blocks cb: blk mod 4 distinct) and the backward one (lanes = 16 columns q of four
 // consecutive column blocks qb) are both conflict-free.
 constexpr int RS_WB = DB * (DB + 1);   // floats per padded block
-inline size_t refine_solve_lds_bytes(int NT) {
+__host__ __device__ inline size_t refine_solve_lds_bytes(int NT) {
   return (size_t)(NT * TS + TS) * sizeof(double) + (size_t)16 * TS * sizeof(double) + (size_t)(WIMG / (DB * DB)) * RS_WB * sizeof(float);
 }
 constexpr int kRefineMaxNT = (160 * 1024 - (TS + 16 * TS) * 8 - (WIMG / (DB * DB)) * RS_WB * 4) / (TS * 8);   // block steps the LDS holds
@@ -157,20 +157,18 @@ __device__ __forceinline__ float rs_w(const float *__restrict__ WB, int row, int
   return WB[(wimg_blk(row >> 4, col >> 4) / (DB * DB)) * RS_WB + (col & 15) * (DB + 1) + (row & 15)];
 }
 
+// r: the right-hand side of mode 1; a64: alpha, read-modified-written (mode 0: written) -- global or LDS (the one-launch form)
 template <typename T>
-__global__ __launch_bounds__(RS_THREADS, CGP_RS_MINW) void k_refine_solve(FitArgs p, RefineArgs q, int mode) {
+__device__ __forceinline__ void rs_solve_body(const FitArgs &p, int mode, int b, char *smem_raw, const double *r, double *a64) {
   static_assert(sizeof(T) == 4, "the refinement is for the fp32 factor");
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int NP = p.NT * TS, N = p.N;
   double *w = reinterpret_cast<double *>(smem_raw);   // [NP]
   double *rhs = w + NP;                               // [128]
   double *red = rhs + TS;                             // [16][128]
   float *WT = reinterpret_cast<float *>(red + 16 * TS);   // W image of the tile step, padded blocks (rs_stage_w)
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (q.flag && !q.flag[b]) return;   // (workgroup-uniform)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T *__restrict__ Lw = reinterpret_cast<const T *>(p.Lw) + (size_t)b * p.lw_stride;
   const T *__restrict__ Winv = reinterpret_cast<const T *>(p.Winv) + (size_t)b * p.winv_stride;
-  const double *__restrict__ r = q.r + (size_t)b * q.stride;
   const int ld = p.ld;
   if (mode == 0) {
     // w = z: the y row of the panel, extra row index M
@@ -280,8 +278,99 @@ __global__ __launch_bounds__(RS_THREADS, CGP_RS_MINW) void k_refine_solve(FitArg
     }
     __syncthreads();
   }
-  double *__restrict__ a64 = q.alpha + (size_t)b * q.stride;
   for (int j = tid; j < NP; j += RS_THREADS) a64[j] = (j < N) ? (mode == 0 ? 0.0 : a64[j]) + w[j] : 0.0;
+}
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS, CGP_RS_MINW) void k_refine_solve(FitArgs p, RefineArgs q, int mode) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int b = blockIdx.x;
+  if (q.flag && !q.flag[b]) return;   // (workgroup-uniform)
+  rs_solve_body<T>(p, mode, b, smem_raw, q.r + (size_t)b * q.stride, q.alpha + (size_t)b * q.stride);
+}
+
+// --------------------------------------------------------------------------------------------------
+// The whole refinement of ONE fit in one workgroup: what a call of more than three input dimensions launches under the default
+// setting, where k_finalize marks the dense fits (FitArgs::rflag) and almost always marks none -- ONE launch whose workgroups
+// return at once instead of four (BASELINE configs[2]: +1.5 us per call instead of +6).  A marked fit runs the four stages back to
+// back on its CU: alpha and r live in LDS between them, the covariance sums take one row per thread (1024 rows per pass, every column
+// chunk staged once): ~270 us at N = 1024, M = 599 against ~250 us of the four-launch form -- the stages of the one fit are a chain
+// either way.  Runtime input dimension, SE kernels only (d <= 3 and the RBF x Brownian kernel take the four launches, every fit).
+// --------------------------------------------------------------------------------------------------
+inline size_t refine_gated_lds_bytes(int NT) { return refine_solve_lds_bytes(NT) + (size_t)2 * NT * TS * sizeof(double); }
+constexpr int kRefineGatedMaxNT = (160 * 1024 - (TS + 16 * TS) * 8 - (WIMG / (DB * DB)) * RS_WB * 4) / (3 * TS * 8);
+template <typename T, bool MEAN>
+__device__ __forceinline__ void rf_rowsum_wg(const FitArgs &p, int b, double *stage, const double *alpha, double *r_out) {
+  // stage: [MAXD][RF_CW] scaled column points + [RF_CW] alpha (the solve's reduction / W-image area, free between the solves)
+  const int tid = threadIdx.x, N = p.N, M = p.M, d = p.d;
+  const int rows = MEAN ? M : N;
+  const double *__restrict__ pr = p.prep + (size_t)b * PREP_N;
+  const T *__restrict__ Xb = reinterpret_cast<const T *>(p.X) + (size_t)b * d * N;
+  const T *__restrict__ Rb = MEAN ? reinterpret_cast<const T *>(p.Xs) + (size_t)b * d * M : Xb;
+  double *xc = stage, *ac = stage + MAXD * RF_CW;
+  ExpC ec;
+  ec.load();
+  const double amp = pr[9], diag_add = pr[11];
+  for (int row0 = 0; row0 < rows; row0 += RS_THREADS) {
+    const int row = row0 + tid;
+    const bool rok = row < rows;
+    double xr[MAXD];
+#pragma unroll
+    for (int j = 0; j < MAXD; ++j) xr[j] = (j < d && rok) ? (double)Rb[(size_t)j * rows + row] * pr[j] : 0.0;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < N; c0 += RF_CW) {
+      __syncthreads();
+      if (tid < RF_CW) {
+        const int c = c0 + tid;
+        const bool cok = c < N;
+#pragma unroll
+        for (int j = 0; j < MAXD; ++j) xc[j * RF_CW + tid] = (j < d && cok) ? (double)Xb[(size_t)j * N + c] * pr[j] : 0.0;
+        ac[tid] = cok ? alpha[c] : 0.0;
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int cc = 0; cc < RF_CW; cc += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          double sq = 0.0;
+#pragma unroll
+          for (int j = 0; j < MAXD; ++j) {
+            if (j < d) {
+              const double df = xr[j] - xc[j * RF_CW + cc + u];
+              sq = __builtin_fma(df, df, sq);
+            }
+          }
+          acc[u] = __builtin_fma(exp_nonpos(-0.5 * sq, ec), ac[cc + u], acc[u]);
+        }
+      }
+    }
+    if (rok) {
+      const double ka = amp * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+      if constexpr (MEAN) reinterpret_cast<T *>(p.mean)[(size_t)b * M + row] = (T)ka;
+      else r_out[row] = (double)reinterpret_cast<const T *>(p.y)[(size_t)b * N + row] - ka - diag_add * alpha[row];
+    }
+  }
+  __syncthreads();
+}
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS, CGP_RS_MINW) void k_refine_gated(FitArgs p, RefineArgs q, int steps, int want_mean) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int b = blockIdx.x;
+  if (q.flag && !q.flag[b]) return;   // (workgroup-uniform)
+  const int NP = p.NT * TS;
+  double *al = reinterpret_cast<double *>(smem_raw + refine_solve_lds_bytes(p.NT));   // [NP] alpha, then [NP] r, behind the solve's arrays
+  double *rr = al + NP;
+  double *stage = reinterpret_cast<double *>(smem_raw) + NP + TS;                     // the solve's red / W-image area
+  static_assert((MAXD + 1) * RF_CW * 8 <= 16 * TS * 8 + (WIMG / (DB * DB)) * RS_WB * 4, "the column stage fits the solve's scratch");
+  rs_solve_body<T>(p, 0, b, smem_raw, rr, al);
+  __syncthreads();
+  for (int st = 0; st < steps; ++st) {
+    rf_rowsum_wg<T, false>(p, b, stage, al, rr);
+    rs_solve_body<T>(p, 1, b, smem_raw, rr, al);
+    __syncthreads();
+  }
+  if (want_mean && p.M > 0) rf_rowsum_wg<T, true>(p, b, stage, al, nullptr);
+  double *a64 = q.alpha + (size_t)b * q.stride;
+  for (int j = threadIdx.x; j < NP; j += RS_THREADS) a64[j] = al[j];
 }
 
 }  // namespace cgp

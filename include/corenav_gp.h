@@ -298,8 +298,8 @@ int cgp_window_state(cgp_ctx *ctx, int w, int *n, int *info);
  * one step; for every fit of a window of d <= 3 input dimensions (the RBF x Brownian kernel included: +40 % per call at
  * N = 1024, M = 599), and for d > 3 only for the fits whose factor shows a dense window (prior variance / geometric mean of
  * the pivots L_ii^2 >= 12: the unrefined mean's error follows that ratio, tools/rho_vs_error.py) -- BASELINE configs[2] (d = 6,
- * ratio 3 ... 11.5) has no such fit and pays four launches whose workgroups return at once (+0.5 ... 0.9 % per call); a call
- * with such a fit pays the latency of one refinement (~0.25 ms at N = 1024) whatever their number.  0: never; 1..3: that many
+ * ratio 3 ... 11.5) has no such fit and pays one launch whose workgroups return at once (not measurable: 0.696 ms per 64-fit
+ * call either way); a call with such a fit pays the latency of one refinement (~0.27 ms at N = 1024) whatever their number.  0: never; 1..3: that many
  * steps for every fit of every fp32 call.  cgp_get_alpha then returns the refined alpha (double precision).  No effect on
  * CGP_F64 contexts, nor on windows of more than 9 900 samples (the solve keeps the window's alpha in LDS). */
 int cgp_set_refine(cgp_ctx *ctx, int steps);

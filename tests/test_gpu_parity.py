@@ -820,3 +820,37 @@ def test_fp32_refinement_single_window_entry_points(engine):
     omu, ovar = go.predict(f, ts)
     assert relmax(mean, omu) < 2e-5, relmax(mean, omu)
     assert releach(var, ovar) < 3e-3
+
+
+def test_fp32_refinement_is_gated_by_the_windows_density_beyond_three_dimensions(engine):
+    """d = 4 (the dimension in which round 6's sweep found two unrefined means at 1.1 and 1.3e-3): under the default setting
+    k_finalize marks the fits whose factor shows a dense window -- rho = (sigma_f^2 + sigma_n^2) / geometric mean of L_ii^2 >= 12
+    (csrc/cgp_kernels.hpp: RF_RHO) -- and ONE launch (k_refine_gated) refines exactly those: a marked fit's mean sits at 2e-5 or
+    better, an unmarked fit's outputs are bitwise what cgp_set_refine(0) gives, every mean stays inside north_star's 1e-3."""
+    N, M, d, B, seed = 1100, 5, 4, 12, 642426859
+    Xl, yl, Xsl, thl = [], [], [], []
+    for b in range(B):
+        X, y, Xs = synth.window(N, d, M, seed + b)
+        Xl.append(X); yl.append(y); Xsl.append(Xs); thl.append(synth.theta_for(1, d, y, np.random.default_rng(seed + 7 + b)))
+    X, y, Xs, th = np.stack(Xl), np.stack(yl), np.stack(Xsl), np.stack(thl)
+    ctx = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=B, dtype=engine.F32)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, 1)
+    assert rc == 0 and not info.any()
+    ctx.set_refine(0)
+    rc, mean0, var0, logml0, _ = ctx.fit_predict_batch(X, y, Xs, th, 1)
+    assert rc == 0 and np.array_equal(var0, var) and np.array_equal(logml0, logml)
+    marked = unmarked = 0
+    for b in range(B):
+        f = go.fit(1, th[b], X[b], y[b])
+        omu, _ = go.predict(f, Xs[b])
+        ms = max(float(np.max(np.abs(omu))), 0.1 * float(np.max(np.abs(y[b]))))
+        rho = (th[b][0] + th[b][-1]) * np.exp(-2.0 * np.sum(np.log(np.diag(f.L))) / N)
+        e1, e0 = float(np.max(np.abs(mean[b] - omu))) / ms, float(np.max(np.abs(mean0[b] - omu))) / ms
+        assert e1 < TOL32
+        if rho >= 12.5:
+            marked += 1
+            assert e1 < 2e-5 and not np.array_equal(mean[b], mean0[b]), (b, rho, e1, e0)
+        elif rho < 11.5:
+            unmarked += 1
+            assert np.array_equal(mean[b], mean0[b]), (b, rho)
+    assert marked >= 3 and unmarked >= 2, (marked, unmarked)
