@@ -997,6 +997,9 @@ FitArgs base_args(cgp_ctx *c, int N, int d, int M, int kid, int include_noise) {
   a.M = M;
   a.NT = cdiv(N, TS);
   a.ET = cdiv(M + 1, TS);
+  // the tile loops read up to four chunks (64 columns) past block column k - 1 of a panel without a branch (bx6_iter): every block
+  // step k < NT of a call stays inside the NTmax x 128 columns of the fit's slab
+  static_assert(4 * KT <= TS, "the unconditional look-ahead of the tile loops stays inside the next block column");
   a.kernel_id = kid;
   a.include_noise = include_noise;
 #ifdef CGP_ABLATION

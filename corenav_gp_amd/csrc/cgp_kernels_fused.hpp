@@ -389,7 +389,11 @@ template <int D> __device__ __forceinline__ void bx6_prologue(BxStage<D> &st, in
 template <int D, bool DBL, int S>   // S = c % D: the set the split of chunk c emptied takes chunk c + D
 __device__ __forceinline__ void bx6_iter(Prec<float>::acc_t (&acc)[NCB][2], BxStage<D> &st, int c, int nchunk, float *smem, const unsigned short *const (&pa)[2],
                                          const unsigned short *const (&pb)[2], int hi, const float *zs, int zfirst, int h8, bool live) {
-  // UNCONDITIONAL: past the last chunk the buffer descriptor's bound answers with zeros and no memory access.  A load behind a branch
+  // UNCONDITIONAL.  Past the last chunk the loads are harmless either way: the chunk's row goes into the SCALAR offset, which the
+  // descriptor's bounds check may or may not cover (the range check is defined on the vector offset), so what makes the look-ahead
+  // safe is the LAYOUT, not the descriptor: a look-ahead reaches at most D chunks = 64 columns past column 128 k of a panel that has
+  // NT x 128 >= 128 (k + 1) columns inside the same fit's slab (run_schedule asserts k < NT; cgp_create sizes the slab by NTmax), the
+  // values are never stored, and where the check does fire they are zeros without a memory access.  A load behind a branch
   // is one the compiler cannot count on when it computes the vmcnt of an OLDER load's wait -- every wait then drained the queue
   // (vmcnt(0) at each split: one chunk in flight however many sets there were).
   st.template load<S>(c + D);
