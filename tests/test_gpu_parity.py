@@ -854,3 +854,51 @@ def test_fp32_refinement_is_gated_by_the_windows_density_beyond_three_dimensions
             unmarked += 1
             assert np.array_equal(mean[b], mean0[b]), (b, rho)
     assert marked >= 3 and unmarked >= 2, (marked, unmarked)
+
+
+def test_device_entry_is_capturable_into_a_graph_with_default_settings(engine):
+    """A 64-fit fp32 call (the shape whose stream groups the engine tunes by measurement) captured into a hipGraph with
+    DEFAULT settings -- the case ADVICE (round 5) flagged: the tuner used to hipEventSynchronize / hipEventElapsedTime on the
+    capturing stream, which fails under capture and left a sticky error.  Since round 6 a capturing stream is never touched
+    with a timing event (the call takes the form already decided, or two groups forked / joined with plain events, which
+    capture records as graph edges) and the decision itself is read with hipEventQuery.  The replayed graph gives the eager
+    call's results bitwise, and eager calls on the same stream -- before, between and after, enough of them to walk the tuner
+    through its measuring and deciding states -- keep returning 0."""
+    import torch
+    B = 64
+    kid, X, y, Xs, th, _ = synth.config(3, batch=B, N=384, M=130)
+    N, d, M = X.shape[1], X.shape[2], Xs.shape[1]
+    dev = torch.device("cuda", 0)
+    ctx = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=B, dtype=engine.F32)
+    thp = np.zeros((B, engine.MAX_THETA))
+    thp[:, :th.shape[1]] = th
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=torch.float32)
+    dX, dXs, dy = f32(X.transpose(0, 2, 1)), f32(Xs.transpose(0, 2, 1)), f32(y)
+    dth = torch.from_numpy(thp).to(dev)
+    outs = lambda: (torch.zeros((B, M), device=dev, dtype=torch.float32), torch.zeros((B, M), device=dev, dtype=torch.float32),
+                    torch.zeros(B, device=dev, dtype=torch.float64), torch.zeros(B, device=dev, dtype=torch.int32))
+    em, ev, el, ei = outs()
+    gm, gv, gl, gi = outs()
+    side = torch.cuda.Stream(dev)
+
+    def call(o, stream):
+        return ctx.fit_predict_batch_device(B, N, d, M, kid, dX.data_ptr(), dy.data_ptr(), dXs.data_ptr(), dth.data_ptr(), 0, True,
+                                            o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), stream.cuda_stream)
+    with torch.cuda.stream(side):
+        for _ in range(3):                     # eager warm-up calls on the stream that will capture: the tuner is mid-measurement
+            assert call((em, ev, el, ei), side) == 0
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            assert call((gm, gv, gl, gi), side) == 0
+        for _ in range(12):                    # eager calls after the capture walk the tuner through its decision
+            assert call((em, ev, el, ei), side) == 0
+        side.synchronize()
+        gm.zero_(); gl.zero_()
+        g.replay()
+        side.synchronize()
+    torch.cuda.synchronize()
+    assert int(ei.abs().sum().item()) == 0 and int(gi.abs().sum().item()) == 0
+    assert torch.equal(gm, em) and torch.equal(gv, ev) and torch.equal(gl, el)
+    f = go.fit(kid, th[5], X[5], y[5])
+    assert abs(el[5].item() - f.logml) <= TOL32 * abs(f.logml)
