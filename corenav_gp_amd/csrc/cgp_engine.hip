@@ -1025,8 +1025,13 @@ inline hipStream_t pick_stream(cgp_ctx *c, void *hip_stream) {
   return hip_stream == CGP_STREAM_CTX ? c->stream : (hipStream_t)hip_stream;
 }
 
+// Pinned staging blocks that kernels also access IN PLACE (the one-launch short-window paths, the per-tick window push) must not be
+// freed and allocated again between two such launches (see cgp_window_push: stores lost under load): a block starts at 64 KB -- more
+// than any in-place use needs -- and grows geometrically, so the in-place paths never see a second allocation and the DMA-staged
+// ones (cgp_fit_predict_batch's megabytes) see few.
 bool grow_pinned(void *&p, size_t &cap, size_t bytes) {
   if (bytes <= cap) return true;
+  bytes = std::max({bytes, (size_t)64 * 1024, 2 * cap});
   if (p) (void)hipHostFree(p);
   p = nullptr;
   cap = 0;
@@ -1235,6 +1240,9 @@ cgp_ctx *cgp_create_ex(int device, int max_n, int max_m, int max_d, int max_batc
     }
     ok = ok && set_small_attr(device) == 0;
   }
+  // the fills above (tickets, debug slots, refinement flags) are asynchronous to the host and ordered on the legacy default stream;
+  // the context's work runs on non-blocking streams that do not wait for it (see cgp_window_init)
+  ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok) {
     const hipError_t e = hipGetLastError();
     cgp_destroy(c);
@@ -1292,6 +1300,7 @@ int cgp_debug_read(cgp_ctx *c, long long out[CGP_DEBUG_SLOTS]) {
   HIP_TRY(c, hipDeviceSynchronize());
   HIP_TRY(c, hipMemcpy(out, c->ddbg, DBG_SLOTS * sizeof(long long), hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemset(c->ddbg, 0, DBG_SLOTS * sizeof(long long)));  // the sums restart
+  HIP_TRY(c, hipDeviceSynchronize());                                 // (the fill is asynchronous to the host: see cgp_window_init)
   return CGP_OK;
 }
 
@@ -2348,8 +2357,14 @@ extern "C" int cgp_window_init(cgp_ctx *c, int nwin, int N, int d, int kid, cons
     o[10] = (kid == CGP_KERNEL_RBF_BROWNIAN) ? th[2] : 0.0;
     for (int q = 0; q < nth; ++q) h[W * PREP_N + w * MAX_THETA + q] = th[q];
   }
+  // hipMemset of device memory is ASYNCHRONOUS to the host and ordered on the legacy default stream only -- the pushes run on the
+  // context's non-blocking stream (or the caller's), which does not wait for it: without the synchronisation below the first
+  // push could read the windows' state words before they were zeroed (found by round 6's sweep under load: fourteen processes
+  // sharing the GPU -- a memory access fault, or garbage for one window; never seen on an idle GPU, where the fill is over
+  // before the first launch is issued).
   if (!hip_ok(c, hipMemcpy(pt, h.data(), h.size() * 8, hipMemcpyHostToDevice), "window theta H2D") ||
-      !hip_ok(c, hipMemset(wa.state, 0, W * 4 * sizeof(int)), "window state memset")) {
+      !hip_ok(c, hipMemset(wa.state, 0, W * 4 * sizeof(int)), "window state memset") ||
+      !hip_ok(c, hipDeviceSynchronize(), "window init synchronise")) {
     drop();
     return CGP_EHIP;
   }
@@ -2457,7 +2472,11 @@ extern "C" int cgp_window_push(cgp_ctx *c, int T, const double *xs, const double
   // context; per call: stage in, ONE H2D, the launch, TWO D2H (outputs, window states), one synchronisation.
   const size_t W = c->nwin, nx = W * T * c->win.d, ny = W * T;
   const size_t ndbl = nx + 4 * ny, bytes = ndbl * 8 + W * 4 * sizeof(int);
-  if (!grow_pinned(c->win_pin, c->win_pin_cap, bytes) || !grow_device(c->win_dev, c->win_dev_cap, ndbl * 8)) return CGP_ENOMEM;
+  // (the pinned block is never smaller than the largest push the kernels access in place: a block that was freed and allocated again
+  // between two small pushes -- the first pushes of a stream grow -- is what round 6's sweep caught under load, fourteen processes on
+  // the GPU: about one push in a hundred came back with its outputs untouched, the kernel's stores having gone to the pages of the
+  // block just freed.  One allocation for the context's lifetime takes the window out of that path.)
+  if (!grow_pinned(c->win_pin, c->win_pin_cap, std::max(bytes, kWinZeroCopyBytes)) || !grow_device(c->win_dev, c->win_dev_cap, ndbl * 8)) return CGP_ENOMEM;
   double *h = static_cast<double *>(c->win_pin), *d = static_cast<double *>(c->win_dev);
   int *hst = reinterpret_cast<int *>(h + ndbl);
   memcpy(h, xs, nx * 8);
