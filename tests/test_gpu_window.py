@@ -123,3 +123,43 @@ def test_many_windows_take_the_packed_paired_kernel(engine):
         assert np.max(np.abs(pv[w] - opv) / opv) < TOL
         assert np.max(np.abs(lm[w] - olm) / np.maximum(np.abs(olm), 1.0)) < TOL
     assert all(ctx.window_state(w) == (N, 0) for w in (0, 1, 777, 1023))
+
+
+def test_growing_pushes_of_a_fresh_context_under_load(engine):
+    """Regression of the two races round 6's sweeps found with fourteen processes on the GPU (never on an idle one): a fresh
+    context's first pushes -- one tick, then seven, then seventeen: each longer than the pinned block the previous one left --
+    used to come back, about once in a hundred under load, with the outputs of a push untouched (the kernels access that block in
+    place; it was freed and allocated again between pushes), and cgp_window_init's asynchronous fill of the windows' state words
+    was not ordered before the first push on the context's non-blocking stream (a memory access fault).  Here: the failing case
+    of the sweep, 300 fresh contexts, while six other processes keep the GPU busy with fits."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N, d, kid, T, nwin, cuts, seed = 3, 1, 2, 25, 2, [0, 1, 8, 25], 581800996
+    X, y = [], []
+    for w in range(nwin):
+        t = np.arange(11 + w, 11 + w + T, dtype=np.float64)
+        X.append(t[:, None]); y.append(synth._slip_series(np.random.default_rng(seed + w), t))
+    X, y = np.stack(X), np.stack(y)
+    theta = np.array([0.5, 30.0, 0.01, 0.002])
+    ref = [go.sliding_window_stream(kid, theta, N, X[w], y[w], include_noise=False) for w in range(nwin)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    load = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_parity.py"), "25", str(40 + i)], env=env, cwd=root,
+                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(6)]
+    try:
+        bad = 0
+        for rep in range(300):
+            ctx = engine.Context(max_n=8, max_m=8, max_d=d)
+            ctx.window_init(nwin, N, d, kid, theta)
+            outs = [ctx.window_push(X[:, a:b], y[:, a:b], include_noise=False) for a, b in zip(cuts[:-1], cuts[1:])]
+            pm, pv, lm = [np.concatenate([o[i] for o in outs], axis=1) for i in range(3)]
+            for w in range(nwin):
+                opm, opv, olm = ref[w]
+                if not (np.max(np.abs(pm[w] - opm)) < 1e-9 and np.max(np.abs(lm[w] - olm)) < 1e-6 * np.max(np.abs(olm))
+                        and np.max(np.abs(pv[w] - opv)) < 1e-9 and ctx.window_state(w) == (N, 0)):
+                    bad += 1
+        assert bad == 0, bad
+    finally:
+        for p in load:
+            p.wait(timeout=120)
