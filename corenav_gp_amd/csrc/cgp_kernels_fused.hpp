@@ -254,7 +254,15 @@ template <int D> struct BxStage {   // what a thread stages per chunk: row (tid 
       }
     }
     bx_split_store(xr[S], sp, offR);
+#if defined(CGP_PROBE_COLSPLIT) && CGP_PROBE_COLSPLIT == 0
+    // timing probe (WRONG results; `make variant`): the column panel's split and plane stores are skipped -- the bound of what sharing
+    // the column-panel stage between row tiles (a 256 x 128 row-pair tile, or more) could save
+    if (xc[S][0] == 12345.678f) bx_split_store(xc[S], sp + 3 * BX_PLANE, offC);
+#elif defined(CGP_PROBE_COLSPLIT) && CGP_PROBE_COLSPLIT == 2
+    if ((threadIdx.x & 64) == 0) bx_split_store(xc[S], sp + 3 * BX_PLANE, offC);   // probe: half of it (what a row PAIR saves per tile)
+#else
     bx_split_store(xc[S], sp + 3 * BX_PLANE, offC);
+#endif
   }
 };
 // One chunk of products out of the planes.  The full-rate bf16 MFMA of gfx950 is the K = 32 form (v_mfma_f32_16x16x32_bf16: 16
