@@ -314,6 +314,10 @@ def run_rank(args):
                         out["config"]["extra"]["node_cpu_baseline"] = node_cpu_leg(engine, local)
                     except Exception as e:
                         out["config"]["extra"]["node_cpu_error"] = repr(e)
+                    try:
+                        out["config"]["extra"]["fp32_refinement"] = refine_leg(engine, torch, dev, local)
+                    except Exception as e:
+                        out["config"]["extra"]["fp32_refinement_error"] = repr(e)
             if world == 1 and not args.no_extra and not strong:
                 ex3 = extras_cfg3(engine, torch, dev, local, W)
                 leg = ex3.pop("_cpu_leg", None)
@@ -953,6 +957,47 @@ def node_cpu_leg(engine, local):
             "sample": "one GP_Input window of the reference's slip series (149 ticks, 599 predictions, RBF x Brownian), oracle/gp_oracle.py on one host thread",
             "gpu_vs_oracle_max_rel_err_fixed_theta": max(rel(mean, omean), rel(sigma, osigma)),
             "nll_at_gpu_optimum_minus_nll_at_oracle_optimum": float(f_gpu - (-ologml))}
+
+
+def refine_leg(engine, torch, dev, local):
+    """fp32 accuracy on the windows round 5's sweep flagged (dense, one input dimension, N = 1000): the predictive mean of eight
+    fits of a 40-fit call against the oracle (test infrastructure, this CPU leg only) without and with the engine's default
+    refinement of alpha against a double-precision residual (cgp_set_refine, csrc/cgp_refine.hpp), and what the call costs either way."""
+    import numpy as np
+    import corenav_gp_amd.synth as synth
+    from oracle import gp_oracle as go
+    N, M, d, B, seed = 1000, 5, 1, 40, 12345
+    Xl, yl, Xsl, thl = [], [], [], []
+    for b in range(B):
+        X, y, Xs = synth.window(N, d, M, seed + b)
+        Xl.append(X); yl.append(y); Xsl.append(Xs); thl.append(synth.theta_for(1, d, y, None))
+    X, y, Xs, th = np.stack(Xl), np.stack(yl), np.stack(Xsl), np.stack(thl)
+    ctx = engine.Context(device=local, max_n=N, max_m=M, max_d=d, max_batch=B, dtype=engine.F32)
+    out, ms = {}, {}
+    for mode in (0, -1):
+        ctx.set_refine(mode)
+        ctx.fit_predict_batch(X, y, Xs, th, 1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, 1)
+        ms[mode] = (time.perf_counter() - t0) / 3 * 1e3
+        assert rc == 0
+        out[mode] = (mean, var, logml)
+    err = {0: [], -1: [], "var": [], "logml": []}
+    for b in range(0, B, 5):
+        f = go.fit(1, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        sc = max(float(np.max(np.abs(omu))), 0.1 * float(np.max(np.abs(y[b]))))
+        for mode in (0, -1):
+            err[mode].append(float(np.max(np.abs(out[mode][0][b] - omu))) / sc)
+        err["var"].append(float(np.max(np.abs(out[-1][1][b] - ovar) / np.abs(ovar))))
+        err["logml"].append(abs(out[-1][2][b] - f.logml) / abs(f.logml))
+    return {"workload": f"{B} x N={N} d={d} SE-ARD fp32, M={M}: dense one-dimensional windows (round 5's open accuracy item)",
+            "mean_err_vs_oracle_unrefined_max": max(err[0]), "mean_err_vs_oracle_default_max": max(err[-1]),
+            "variance_err_vs_oracle_max": max(err["var"]), "logml_err_vs_oracle_max": max(err["logml"]), "fits_compared": len(err[0]),
+            "host_call_ms_unrefined": ms[0], "host_call_ms_default": ms[-1],
+            "note": "default = cgp_set_refine(-1): one correction step for every fit of a window with d <= 3 (and for the dense fits beyond); "
+                    "variance and logML come from the single-precision factor either way"}
 
 
 def host_description():

@@ -58,6 +58,14 @@ def test_bench_extra_lines():
     assert 0.9 < sw["devices_1_over_context"] < 1.15 and sw["devices_same_gpu_twice_ms_per_call"] > 0
     assert ex["replay"]["windows_fitted"] >= 64 and ex["replay"]["stops"] >= 1
     assert ex["cfg3_strong"]["n_gpus"] == 1 and ex["cfg3_strong"]["fits_per_s"] == ex["cfg3_fits_per_s"]
+    # round 6: what cfg3_roofline_frac is (a label against the FP32-input MFMA peak) next to the pipe the loop runs on and HBM, over 20 steps
+    assert ex["cfg3_steps"] == 20 and 0 < ex["cfg3_frac_of_bf16x6_bound"] < ex["cfg3_roofline_frac"] and 0 < ex["cfg3_hbm_frac"] < 1
+    assert "window_hbm_frac_counter_traffic_projected" in ex and "window_hbm_frac_counter_traffic" not in ex
+    # BASELINE configs[1] read literally -- ONE fit -- priced on the line
+    assert 0 < j["config"]["single_fit_cholesky_roofline_frac"] < 0.2 and j["config"]["single_fit_vs_cpu_1thread"] > 10
+    # fp32: the mean refined against a double-precision residual (the CPU leg's oracle check)
+    fr = ex["fp32_refinement"]
+    assert fr["mean_err_vs_oracle_default_max"] < 2e-5 < fr["mean_err_vs_oracle_unrefined_max"] and fr["variance_err_vs_oracle_max"] < 1e-3
 
 
 def test_bench_live_pmc_traffic():
