@@ -496,6 +496,13 @@ class SlipRecorder:
     STATE_FIELDS = ("odomUptCount", "startRecording", "stopRecording", "gp_flag", "first_driving_flag",
                     "new_stop_data_arrived_", "skipped_windows", "cmd_stop_")
 
+    def set_refine(self, steps=-1):
+        """cgp_set_refine on every shard's context."""
+        for i in range(self.ndev):
+            rc = self.lib.cgp_set_refine(self.lib.cgp_sweep_context(self.h, i), int(steps))
+            if rc != 0:
+                raise CgpError(rc)
+
     def __init__(self):
         self.lib = load()
         self.h = self.lib.cgp_recorder_create()

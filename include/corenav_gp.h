@@ -236,7 +236,7 @@ int cgp_sweep_fit_predict_device(cgp_sweep *sweep, int batch, int N, int d, int 
                                  const double *const *djitter, int include_noise, void *const *dmean, void *const *dvar,
                                  double *const *dlogml, int *const *dinfo, void *const *hip_streams);
 int cgp_sweep_synchronize(cgp_sweep *sweep);
-/* The engine context of shard i (owned by the sweep): for cgp_set_streams, cgp_last_error, cgp_profile_* on a shard. */
+/* The engine context of shard i (owned by the sweep): for cgp_set_streams, cgp_set_refine, cgp_last_error, cgp_profile_* on a shard. */
 cgp_ctx *cgp_sweep_context(const cgp_sweep *sweep, int i);
 
 /* Stream groups of a batch.  n = 0 (the default): the engine decides -- an fp32 call of 56 ... 96 fits (BASELINE configs[2] as

@@ -902,3 +902,26 @@ def test_device_entry_is_capturable_into_a_graph_with_default_settings(engine):
     assert torch.equal(gm, em) and torch.equal(gv, ev) and torch.equal(gl, el)
     f = go.fit(kid, th[5], X[5], y[5])
     assert abs(el[5].item() - f.logml) <= TOL32 * abs(f.logml)
+
+
+def test_fp32_refinement_with_stream_groups(engine):
+    """A 64-fit fp32 call of dense one-dimensional windows: the engine cuts it into two stream groups (caller's stream + a worker
+    stream) AND refines every fit -- the refinement launches of a group work on that group's slice of the residual / alpha
+    buffers.  One group, two groups and the engine's own choice give bitwise the same outputs, every checked mean is refined."""
+    N, M, d, B = 520, 33, 1, 64
+    X, y, Xs, th = _dense_windows(B, N, d, M, 777)
+    ctx = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=B, dtype=engine.F32)
+    res = {}
+    for ns in (1, 2, 0):
+        ctx.set_streams(ns)
+        rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, 1)
+        assert rc == 0 and not info.any()
+        res[ns] = (mean, var, logml)
+    for ns in (2, 0):
+        assert all(np.array_equal(a, b) for a, b in zip(res[ns], res[1])), ns
+    for b in (0, 31, 32, 63):     # either side of the cut between the groups
+        f = go.fit(1, th[b], X[b], y[b])
+        omu, ovar = go.predict(f, Xs[b])
+        ms = max(float(np.max(np.abs(omu))), 0.1 * float(np.max(np.abs(y[b]))))
+        assert float(np.max(np.abs(res[1][0][b] - omu))) / ms < 2e-5
+        assert releach(res[1][1][b], ovar) < TOL32
