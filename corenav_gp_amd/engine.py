@@ -370,7 +370,7 @@ class Context:
 
     def set_refine(self, steps=-1):
         """fp32 contexts: correction steps of alpha / the mean against a double-precision residual (cgp_set_refine): -1 the
-        engine decides (one step at d <= 2), 0 never, 1..3 always."""
+        engine decides (one step: every fit at d <= 3, the dense fits beyond), 0 never, 1..3 always."""
         self._chk(self.lib.cgp_set_refine(self.h, int(steps)))
 
     def profile_enable(self, on=True):
@@ -451,6 +451,13 @@ class Sweep:
             if rc:
                 raise CgpError(rc)
 
+    def set_refine(self, steps=-1):
+        """cgp_set_refine on every shard's context."""
+        for i in range(self.ndev):
+            rc = self.lib.cgp_set_refine(self.lib.cgp_sweep_context(self.h, i), int(steps))
+            if rc:
+                raise CgpError(rc)
+
 
 INIT_LLH = (0.693457963620326, -1.39498384275845, 334.993517334743)   # init_params.yaml:13-16
 INIT_ECEF = (859153.0153, -4836303.7266, 4055378.501)                  # init_params.yaml:9-12
@@ -495,13 +502,6 @@ class SlipRecorder:
     """CoreNav's slip computation + recording-window state machine (C++ class behind the C ABI)."""
     STATE_FIELDS = ("odomUptCount", "startRecording", "stopRecording", "gp_flag", "first_driving_flag",
                     "new_stop_data_arrived_", "skipped_windows", "cmd_stop_")
-
-    def set_refine(self, steps=-1):
-        """cgp_set_refine on every shard's context."""
-        for i in range(self.ndev):
-            rc = self.lib.cgp_set_refine(self.lib.cgp_sweep_context(self.h, i), int(steps))
-            if rc != 0:
-                raise CgpError(rc)
 
     def __init__(self):
         self.lib = load()
