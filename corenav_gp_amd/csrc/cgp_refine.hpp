@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_refine_gemv(FitArgs p, RefineArgs q) {
 // fp64.  One workgroup of 1024 threads per fit -- these solves are chains of NT tile steps, each step a matrix-vector product
 // with a slab of the factor, and a lone 256-thread workgroup with a handful of loads in flight per thread ran them at the
 // latency of one HBM round trip per 16 columns (k_alpha: 218 us for N = 1024; first version of this kernel: 424 us).  Here a
-// tile step has its whole slab in flight at once (16-byte loads, up to 32 per thread) and the W image of the step is staged
+// tile step has a thousand 16-byte loads of its slab in flight at once (1024 threads x four) and the W image of the step is staged
 // into LDS, transposed and padded, while the slab streams.
 //   mode 0:  alpha = L^-T z            z = the y row of the factor panel (what k_alpha computes, kept in double)
 //   mode 1:  alpha += L^-T L^-1 r      the correction solve of a refinement step
