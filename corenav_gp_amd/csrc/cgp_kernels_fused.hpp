@@ -1396,7 +1396,7 @@ __device__ __forceinline__ void acc_image(typename Prec<T>::acc_t (&acc)[NCB][2]
 template <typename T> constexpr int potf2_lds_elems() { return TS * LDP + 8 * DB * DB + 4 * DB * DB + 8; }
 template <typename T, int MODE, bool TRI, bool DEEP = sizeof(T) == 8, bool FAT = false>
 __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::acc_t (&acc)[NCB][2], T *__restrict__ smem,
-                                          T *__restrict__ Lw, int b, int kn, int tid, PhaseClock *pc = nullptr) {
+                                          T *__restrict__ Lw, int b, int kn, int tid, PhaseClock *pc = nullptr, bool img_ready = false) {
   using P = Prec<T>;
   using vec2 = T __attribute__((ext_vector_type(2)));
   const int ld = p.ld;
@@ -1434,8 +1434,9 @@ __device__ __forceinline__ void diag_next(const FitArgs &p, typename Prec<T>::ac
       bx6_tri_prologue(bxt);   // (nchunk = 0: the descriptor is empty, zeros without a memory access)
     } else if constexpr (TRI) tri_prologue<T, DEEP>(gR, (size_t)ld, nchunk, smem, tid);  // DEEP: DMA ring, 2 chunks ahead
     else if (nchunk > 0) stage_first_chunk<T>(gR, (size_t)ld, gR, (size_t)ld, smem, tid);
-    if (from_image) acc_image<T, TRI, false>(acc, img, tid);
-    else gram_apply<T, TRI>(p, acc, smem + (BXT ? BXT_FLOATS : CH2), b, kn, kn, tid, gp);   // BXT: behind plane buffer 0, over buffer 1
+    if (from_image) {
+      if (!img_ready) acc_image<T, TRI, false>(acc, img, tid);   // (img_ready: the caller requested it before the fence, see panel_tile_body)
+    } else gram_apply<T, TRI>(p, acc, smem + (BXT ? BXT_FLOATS : CH2), b, kn, kn, tid, gp);   // BXT: behind plane buffer 0, over buffer 1
   }
   if (pc) pc->lap(p, 344);  // finisher: fence + image / Gram tile (measurement build; slots 344.. = all steps summed)
   if constexpr (BXT) bx6_syrk_tri_loop(acc, bxt, nchunk, smem, tid);
@@ -1751,6 +1752,9 @@ __device__ __forceinline__ void panel_partial(const FitArgs &p, typename Prec<T>
   acc_image<T, false, true>(acc, reinterpret_cast<T *>(p.pimg) + ((size_t)b * img_slots(p) + kc % img_slots(p)) * DPART, tid);
 }
 
+#ifndef CGP_IMG_EARLY
+#define CGP_IMG_EARLY 1   // mid-size build: the finisher's image is requested in front of its fence (`make variant` A/B: 0)
+#endif
 template <typename T, bool MID> constexpr bool mid_fat() { return MID && sizeof(T) == 4; }
 // One tile of block step k: L(rt, k) = (G(rt,k) - sum_{c_first*16 <= col < 128 k} L(rt,:) L(k,:)^T [+ image]) W_k^T, stored; then, kind A
 // (finish_next), the next diagonal tile.  The body of k_panel after its role decode -- also what a tile task of the
@@ -1881,7 +1885,20 @@ __device__ __forceinline__ void panel_tile_body(const FitArgs &p, int k, int b, 
   pc.lap(p, ps + 5);
   pc.count(p, ps + 7);
   if constexpr (DIAGNEXT) {
-    if (finish_next) diag_next<T, DIAG_FINISH, kTriDiag, DEEP, mid_fat<T, MID>()>(p, acc, smem, Lw, b, k + 1, tid, &pc);
+    if (finish_next) {
+      // The pre-updated image of the diagonal tile (kind B, two launches ago) does not depend on the tile this workgroup has just
+      // stored: mid-size build, it is requested HERE, in front of the finish's workgroup fence, whose wait for the tile's stores then
+      // covers its latency too (the accumulators are free once the stores are issued).
+      bool img_ready = false;
+      if constexpr (MID && CGP_IMG_EARLY) {
+        if (k + 1 >= 3) {
+          const T *img = reinterpret_cast<const T *>(p.dpart) + ((size_t)b * img_slots(p) + (k + 1) % img_slots(p)) * DPART;
+          acc_image<T, kTriDiag, false>(acc, const_cast<T *>(img), tid);
+          img_ready = true;
+        }
+      }
+      diag_next<T, DIAG_FINISH, kTriDiag, DEEP, mid_fat<T, MID>()>(p, acc, smem, Lw, b, k + 1, tid, &pc, img_ready);
+    }
   }
 }
 
