@@ -301,7 +301,7 @@ int cgp_window_state(cgp_ctx *ctx, int w, int *n, int *info);
  * ratio 3 ... 11.5) has no such fit and pays one launch whose workgroups return at once (not measurable: 0.696 ms per 64-fit
  * call either way); a call with such a fit pays the latency of one refinement (~0.27 ms at N = 1024) whatever their number.  0: never; 1..3: that many
  * steps for every fit of every fp32 call.  cgp_get_alpha then returns the refined alpha (double precision).  No effect on
- * CGP_F64 contexts, nor on windows of more than 9 900 samples (the solve keeps the window's alpha in LDS). */
+ * CGP_F64 contexts, nor on windows of more than 13 000 samples (the solve keeps the window's alpha in LDS). */
 int cgp_set_refine(cgp_ctx *ctx, int steps);
 
 /* ---- per-kernel timing for the roofline line (bench.py) --------------------------------------
