@@ -786,7 +786,10 @@ __global__ __launch_bounds__(256) void k_finalize(FitArgs p, int do_logml) {
       p.logml[b] = -0.5 * red[1][0] - red[0][0] - 0.5 * (double)N * 1.8378770664093453;
       // rho = prior variance / geometric mean of the pivots L_ii^2 (the conditional variances): how much of every Schur
       // complement is cancellation -- the quantity the fp32 mean's error follows
-      if (p.rflag) p.rflag[b] = (th[0] + th[nth - 1]) * exp(-2.0 * red[0][0] / (double)N) >= RF_RHO ? 1 : 0;
+      // (the unrefined error at a given rho grows with the window's length: N = 1100 / 2200 / 4400, worst fit with rho in [8, 12):
+      // 2.3e-4 / 2.0e-4 / 3.1e-4, in [12, 16): 7.6e-4 / 7.2e-4 / 1.3e-3 -- longer windows are marked earlier)
+      const double rho_min = p.NT > 48 ? 5.0 : (p.NT > 24 ? 8.0 : RF_RHO);
+      if (p.rflag) p.rflag[b] = (th[0] + th[nth - 1]) * exp(-2.0 * red[0][0] / (double)N) >= rho_min ? 1 : 0;
     }
   }
 }
