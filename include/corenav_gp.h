@@ -51,8 +51,8 @@ enum {
  * CGP_F64 is the reference's arithmetic and meets 1e-6 against it on every kernel.  CGP_F32 is for the SE kernels on
  * standardised inputs (BASELINE configs[2], 1e-3).  Its contract, checked by tests/fuzz/fuzz_parity.py (one bar, no second class):
  *   - predictive mean: refined against a double-precision residual (cgp_set_refine below; by default every window of d <= 3
- *     input dimensions and, beyond, every fit whose factor shows a dense window) -- 1e-5 of the oracle or better where it is
- *     refined, 1e-3 where it is not;
+ *     input dimensions and, beyond, every fit whose factor shows a dense window) -- 2e-5 of the oracle or better where it is
+ *     refined (typically 1e-6), 1e-3 where it is not;
  *   - variance and logML come from the single-precision factor: max(1e-3, 10 x the error of spotrf / strtrs on the same
  *     window) -- the second term only matters for windows that are ill-conditioned in single precision (dense
  *     one-dimensional inputs), where no single-precision factorisation holds 1e-3;
