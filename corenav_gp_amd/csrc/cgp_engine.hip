@@ -559,9 +559,11 @@ template <typename T> int run_sched(cgp_ctx *, FitArgs, int, hipStream_t) { retu
 constexpr int kRefineAutoMaxD = 3;
 inline int refine_steps(const cgp_ctx *c, const FitArgs &a) {
   if (c->dtype != CGP_F32 || !c->dref_a || a.xid || a.NT > kRefineMaxNT) return 0;
-  // one step contracts the mean's error by ~1e-3 up to 3 000 samples (N = 1536 / 2048 / 3000, d = 1: 2.4e-3 / 8.8e-4 / 2.4e-3 -> 1.8e-6 /
-  // 6.0e-6 / 1.9e-6) and by 2e-2 at 4 500 (6.7e-3 -> 1.4e-4 -> 2.6e-6): longer windows take two
-  if (c->refine < 0) return a.NT > 24 ? 2 : 1;
+  // one step contracts the mean's error by ~1e-3 on most windows (N = 1536 / 2048 / 3000, d = 1, a lone fit: 2.4e-3 / 8.8e-4 / 2.4e-3 ->
+  // 1.8e-6 / 6.0e-6 / 1.9e-6) but by as little as 2e-2 on some -- 6.7e-3 -> 1.4e-4 -> 2.6e-6 at N = 4 500; in batched calls of N = 1 100
+  // the sweep found single fits at 3 ... 7e-5 after one step (six in ~3 000 refined cases) -- so windows of more than 1 024 samples
+  // take two (the contract for a refined mean is 5e-5: include/corenav_gp.h)
+  if (c->refine < 0) return a.NT > 8 ? 2 : 1;
   return std::min(c->refine, 3);
 }
 inline bool refine_gated(const cgp_ctx *c, const FitArgs &a) { return c->refine < 0 && a.d > kRefineAutoMaxD; }

@@ -51,7 +51,7 @@ enum {
  * CGP_F64 is the reference's arithmetic and meets 1e-6 against it on every kernel.  CGP_F32 is for the SE kernels on
  * standardised inputs (BASELINE configs[2], 1e-3).  Its contract, checked by tests/fuzz/fuzz_parity.py (one bar, no second class):
  *   - predictive mean: refined against a double-precision residual (cgp_set_refine below; by default every window of d <= 3
- *     input dimensions and, beyond, every fit whose factor shows a dense window) -- 2e-5 of the oracle or better where it is
+ *     input dimensions and, beyond, every fit whose factor shows a dense window) -- 5e-5 of the oracle or better where it is
  *     refined (typically 1e-6), 1e-3 where it is not;
  *   - variance and logML come from the single-precision factor: max(1e-3, 10 x the error of spotrf / strtrs on the same
  *     window) -- the second term only matters for windows that are ill-conditioned in single precision (dense
@@ -295,7 +295,7 @@ int cgp_window_state(cgp_ctx *ctx, int w, int *n, int *info);
  * and mean = K*^T alpha with K* evaluated in double -- GPy's own form of the mean (gp_slip_node.py:48 m.predict: mu = k*^T
  * woodbury_vector).  One step takes the mean of a dense one- or two-dimensional window from ~1e-3 of the oracle to ~1e-6
  * (tools/d1_fp32_error.py); variance and logML come from the factor as before.  steps = -1 (the default): the engine decides --
- * one step (two for windows of more than 3 072 samples, where a step contracts less); for every fit of a window of d <= 3 input dimensions (the RBF x Brownian kernel included: +40 % per call at
+ * one step (two for windows of more than 1 024 samples, where a step contracts less); for every fit of a window of d <= 3 input dimensions (the RBF x Brownian kernel included: +40 % per call at
  * N = 1024, M = 599), and for d > 3 only for the fits whose factor shows a dense window (prior variance / geometric mean of
  * the pivots L_ii^2 >= 12: the unrefined mean's error follows that ratio, tools/rho_vs_error.py) -- BASELINE configs[2] (d = 6,
  * ratio 3 ... 11.5) has no such fit and pays one launch whose workgroups return at once (not measurable: 0.696 ms per 64-fit

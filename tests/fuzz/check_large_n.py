@@ -21,7 +21,7 @@ for N in (2047, 2049, 2304, 2305, 2432, 2433, 2560, 2561, 2689, 3000):
             bad += not ok
             print("N", N, "B", B, "f64" if dt == engine.F64 else "f32", "fit", b, "err %.2e" % e, "ok" if ok else "FAIL", flush=True)
         del ctx
-# round 6: dense low-dimensional fp32 windows of the same lengths -- the refined mean (two correction steps beyond 3 072 samples) at
+# round 6: dense low-dimensional fp32 windows of the same lengths -- the refined mean (two correction steps beyond 1 024 samples) at
 # 2e-5, variance and logML at the fp32 bar
 for N in (2049, 2561, 3000, 3073, 3500, 4200):
     for d in (1, 2, 3):
