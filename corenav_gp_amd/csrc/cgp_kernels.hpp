@@ -43,7 +43,7 @@ constexpr int NCB = TS / DB;  // 8 column blocks of 16
 constexpr int WIMG = NCB * (NCB + 1) / 2 * DB * DB;
 // fp32 fits of more than three input dimensions are refined (cgp_refine.hpp) per fit, when the factor itself says the window is
 // dense: rho = (sigma_f^2 + sigma_n^2) / geometric mean of L_ii^2 >= RF_RHO -- how much of every Schur complement is cancellation.
-// The unrefined mean's error against the oracle follows it (tools/rho_vs_error.py, 192 fits of N = 1100, d = 3 ... 6, mean / worst
+// The unrefined mean's error against the oracle follows it (tests/fuzz/rho_vs_error.py, 192 fits of N = 1100, d = 3 ... 6, mean / worst
 // error by rho: [0, 4) 2.8e-5 / 8.6e-5, [4, 8) 5.7e-5 / 1.7e-4, [8, 12) 9.8e-5 / 2.3e-4, [12, 16) 2.1e-4 / 7.6e-4, [16, 24) 3.0e-4 /
 // 9.4e-4, >= 24 5.4e-4 / 1.6e-3): 12 keeps the worst unrefined fit a factor of four inside 1e-3.  BASELINE configs[2]'s 512
 // windows sit at rho 2.9 ... 11.5: none is marked.

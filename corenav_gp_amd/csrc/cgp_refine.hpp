@@ -3,7 +3,7 @@
 // What it is for: on dense low-dimensional windows the single-precision factorisation leaves logML and
 // the predictive variance at single-precision LAPACK's level, but the predictive MEAN -- mean = (L^-1 K*)^T (L^-1 y), both
 // factors carrying the forward error of the tile solves amplified by the cancellation of the Schur complements -- scatters
-// around 1e-3 (tools/d1_fp32_error.py).  The classical remedy: keep the fp32 factor as the SOLVER and take the residual in
+// around 1e-3 (tests/fuzz/d1_fp32_error.py).  The classical remedy: keep the fp32 factor as the SOLVER and take the residual in
 // double precision from a Gram matrix that is never stored,
 //     alpha_0 = L^-T z                      z = the y row of the factor panel                    k_refine_solve, mode 0
 //     r       = y - Ky alpha                Ky entries evaluated in fp64 from X on the fly       k_refine_gemv<.., false>
@@ -11,7 +11,7 @@
 //     alpha  += delta                       kept in fp64
 //     mean    = K*^T alpha                  K* entries in fp64 on the fly                         k_refine_gemv<.., true>
 // (reference behaviour being matched: gp_slip_node.py:48 `m.predict` -> mu = k*^T alpha, GPy's woodbury_vector.)
-// Measured (tools/d1_fp32_error.py, the windows round 5's sweep flagged): mean error 1.0e-3 -> 5e-7 (d = 1), 7e-4 -> 1.5e-7
+// Measured (tests/fuzz/d1_fp32_error.py, the windows round 5's sweep flagged): mean error 1.0e-3 -> 5e-7 (d = 1), 7e-4 -> 1.5e-7
 // (d = 2), 3e-4 -> 1e-7 (d = 3) in ONE step; variance and logML are the factor's (single-precision LAPACK's level).
 // Cost: N^2 + M N covariance entries in fp64 on the VALU (25 instructions each at d = 1) and three passes over the factor:
 // +40 % on an fp32 fit + predict of N = 1024, M = 599 (tools/refine_cost.py), which is why the engine only takes it where it is

@@ -294,10 +294,10 @@ int cgp_window_state(cgp_ctx *ctx, int w, int *n, int *info);
  *   alpha += L^-T L^-1 r   through the fp32 factor, alpha kept in double,
  * and mean = K*^T alpha with K* evaluated in double -- GPy's own form of the mean (gp_slip_node.py:48 m.predict: mu = k*^T
  * woodbury_vector).  One step takes the mean of a dense one- or two-dimensional window from ~1e-3 of the oracle to ~1e-6
- * (tools/d1_fp32_error.py); variance and logML come from the factor as before.  steps = -1 (the default): the engine decides --
+ * (tests/fuzz/d1_fp32_error.py); variance and logML come from the factor as before.  steps = -1 (the default): the engine decides --
  * one step (two for windows of more than 1 024 samples, where a step contracts less); for every fit of a window of d <= 3 input dimensions (the RBF x Brownian kernel included: +40 % per call at
  * N = 1024, M = 599), and for d > 3 only for the fits whose factor shows a dense window (prior variance / geometric mean of
- * the pivots L_ii^2 >= 12: the unrefined mean's error follows that ratio, tools/rho_vs_error.py) -- BASELINE configs[2] (d = 6,
+ * the pivots L_ii^2 >= 12: the unrefined mean's error follows that ratio, tests/fuzz/rho_vs_error.py) -- BASELINE configs[2] (d = 6,
  * ratio 3 ... 11.5) has no such fit and pays one launch whose workgroups return at once (not measurable: 0.696 ms per 64-fit
  * call either way); a call with such a fit pays the latency of one refinement (~0.27 ms at N = 1024) whatever their number.  0: never; 1..3: that many
  * steps for every fit of every fp32 call.  cgp_get_alpha then returns the refined alpha (double precision).  No effect on

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Error of fp32 fits of dense one-dimensional windows against the fp64 oracle, all fits of a few calls (test infrastructure: uses oracle/):
-   CGP_LIB=<lib> python tools/d1_fp32_error.py      -- same-box A/B of library builds (e.g. `make variant` builds) on the windows the
+   CGP_LIB=<lib> python tests/fuzz/d1_fp32_error.py      -- same-box A/B of library builds (e.g. `make variant` builds) on the windows the
 fuzz sweep flagged (tests/fuzz/fuzz_parity.py's generator: seeds below)."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch  # noqa: F401
 from corenav_gp_amd import engine, synth

@@ -1,4 +1,8 @@
-import sys; sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""The per-fit density gate of the fp32 refinement at d = 4 (test infrastructure: uses oracle/): the windows round 6's sweep flagged
+(rho = 21) inside a batch with sparser ones -- marked fits are refined (1e-7), unmarked fits are bitwise what cgp_set_refine(0) gives.
+   python tests/fuzz/gated_refine_check.py"""
+import sys; import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np, torch
 from corenav_gp_amd import engine, synth
 from oracle import gp_oracle as go

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """fp32 mean error (no refinement) against the window's density indicator rho = prior variance / geometric mean of the
 pivots L_ii^2 (test infrastructure: uses oracle/): the data behind RF_RHO (csrc/cgp_kernels.hpp).
-   python tools/rho_vs_error.py [N=1100] [fits per dimension=24]"""
+   python tests/fuzz/rho_vs_error.py [N=1100] [fits per dimension=24]"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch  # noqa: F401
 from corenav_gp_amd import engine, synth
