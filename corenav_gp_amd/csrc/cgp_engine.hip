@@ -67,6 +67,10 @@ struct cgp_ctx {
     int groups = 2;
     float ms[2] = {0.f, 0.f};
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t mon[2] = {nullptr, nullptr};   // after the decision: one call in a while bracketed, read later with hipEventQuery
+    bool mon_pending = false;
+    int slow = 0;                              // consecutive monitored calls well above what the chosen form measured
+    int retune = 24;                           // decided calls until the two forms are measured again: 24, 48, ... kRetune
     unsigned long long used = 0;
   } tune[4];
   unsigned long long tune_clock = 0;
@@ -682,6 +686,11 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
             (void)hipGetLastError();
             t->state = kTuneDecide + 1;
           }
+        for (auto &e : t->mon)
+          if (!e && hipEventCreate(&e) != hipSuccess) (void)hipGetLastError();   // (no monitor then)
+        t->mon_pending = false;
+        t->slow = 0;
+        t->retune = 24;
       }
       if (capturing) {
         G = t && t->state > kTuneDecide ? t->groups : 2;
@@ -689,7 +698,12 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
       }
       if (t) {
         t->used = ++c->tune_clock;
-        if (t->state > kTuneDecide + kRetune) t->state = kWarm;
+        // (the first decisions are re-checked early: a context's first calls run while the part is still coming out of idle -- both forms
+      // then measure alike, 4.70 / 4.72 ms per four calls where warm they are 4.5 / 2.9 -- and the decision is a coin toss)
+      if (t->state > kTuneDecide + t->retune) {
+        t->state = kWarm;
+        t->retune = std::min(2 * t->retune, kRetune);
+      }
         if (t->state == kTuneDecide) {
           float m2 = 0.f, m1 = 0.f;
           const hipError_t qe = hipEventQuery(t->e[3]);
@@ -700,6 +714,9 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
             if (m2 > 4.f * m1 || m1 > 4.f * m2) t->state = kWarm - 1;   // host gaps, not schedules: measure again
             else t->groups = m2 <= m1 ? 2 : 1;
             ++t->state;
+            static const bool trace = getenv("CGP_TUNE_TRACE") != nullptr;   // development aid: what was measured and decided
+            if (trace) fprintf(stderr, "cgp tune: ctx %p stream %p fits %d NT %d: two groups %.3f ms, one group %.3f ms per %d calls -> %s\n", (void *)c, (void *)s,
+                               batch, a.NT, m2, m1, kRun, t->state == kWarm ? "measure again" : (t->groups == 2 ? "two groups" : "one group"));
           } else {
             (void)hipGetLastError();   // not ready (or a failed query): nothing sticks, two groups for this call, ask again
             if (qe != hipErrorNotReady) t->state = kTuneDecide + 1;
@@ -710,6 +727,30 @@ int run_schedule(cgp_ctx *c, FitArgs a, int batch, bool in_rows, bool want_alpha
         } else if (t->state > kTuneDecide) {
           G = t->groups;
           ++t->state;
+          // The stream -> hardware-queue mapping the decision rests on can change under a long-lived caller (other contexts and
+          // streams come and go): one call in a while is bracketed by two events that a LATER call reads without blocking; three
+          // such calls in a row at more than 1.3 x what the chosen form measured send the entry back to measuring.
+          if (t->mon[0] && t->mon[1]) {
+            if (t->mon_pending) {
+              const hipError_t qm = hipEventQuery(t->mon[1]);
+              if (qm == hipSuccess) {
+                float ms1 = 0.f;
+                const float base = t->ms[t->groups == 2 ? 0 : 1] / (float)kRun;
+                if (hipEventElapsedTime(&ms1, t->mon[0], t->mon[1]) == hipSuccess && base > 0.f) t->slow = ms1 > 1.3f * base ? t->slow + 1 : 0;
+                t->mon_pending = false;
+                if (t->slow >= 3) {
+                  t->slow = 0;
+                  t->state = kWarm;
+                  static const bool trace2 = getenv("CGP_TUNE_TRACE") != nullptr;
+                  if (trace2) fprintf(stderr, "cgp tune: ctx %p stream %p: three monitored calls above 1.3 x %.3f ms (last %.3f): measuring again\n", (void *)c, (void *)s, base, ms1);
+                }
+              } else (void)hipGetLastError();
+            } else if ((t->state & 7) == 0) {
+              tune_ev0 = t->mon[0];
+              tune_ev1 = t->mon[1];
+              t->mon_pending = true;
+            }
+          }
         } else {
           G = t->state < kWarm + kRun ? 2 : 1;
           tune = t;
@@ -1279,9 +1320,12 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipStreamDestroy(c->hstream);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  for (auto &t : c->tune)
+  for (auto &t : c->tune) {
     for (auto e : t.e)
       if (e) (void)hipEventDestroy(e);
+    for (auto e : t.mon)
+      if (e) (void)hipEventDestroy(e);
+  }
   for (auto e : c->ev_look)
     if (e) (void)hipEventDestroy(e);
   for (void *wb : c->winbuf)
