@@ -244,12 +244,14 @@ cgp_ctx *cgp_sweep_context(const cgp_sweep *sweep, int i);
  * stream and group 1 on one of the context's worker streams, forked from / joined to the caller's stream with events, so
  * the chain-bound early launches of one group run beside the MFMA-bound ones of the other (0.99 -> 0.90 ms per 64-fit
  * call on one context); every other call is one group.  Whether two streams really overlap depends on how the runtime mapped
- * them onto its hardware queues (the process's history), so the engine MEASURES: per caller stream, after two warm-up calls,
- * four such calls run as two groups and four as one (events on the caller's stream; the call that reads them waits once
- * for the previous call), the faster form is kept and measured again after 24, 48, ... 256 calls (a context's first calls run on a part still
- * coming out of idle, where both forms measure alike) and whenever three monitored calls in a row come out 1.3 x slower than the form measured.  Since round 6 no call of this
- * measurement blocks: decisions are read with hipEventQuery.  (A caller that captures the calls into a
- * hipGraph, or must never block in an enqueue call, fixes the form instead: n = 1 or n = 2.)  n = 1: always one group.  n = 2..8: up to n groups for full-batch
+ * them onto its hardware queues (the process's history), so the engine MEASURES: per (caller stream, fits, block steps), after two
+ * warm-up calls, four such calls run as two groups and four as one, bracketed by events on the caller's stream; the faster form is
+ * kept, measured again after 24, 48, ... 256 calls (a context's first calls run on a part still coming out of idle, where both
+ * forms measure alike) and whenever three monitored calls in a row come out 1.3 x slower than the chosen form measured.  No call
+ * blocks for this: every decision is read with hipEventQuery (a call whose answer is not in yet runs as two groups), and a stream
+ * that is being captured into a hipGraph is never touched with a timing event (the call takes the form already decided, or two
+ * groups forked / joined with plain events, which the capture records as edges).  A caller that wants the form fixed passes n = 1
+ * or n = 2.  n = 1: always one group.  n = 2..8: up to n groups for full-batch
  * calls too (hundreds of fits gain nothing measurable).  Results do not depend on the setting (a fit's arithmetic is the
  * same in any group). */
 int cgp_set_streams(cgp_ctx *ctx, int n);
