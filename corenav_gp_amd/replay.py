@@ -149,6 +149,57 @@ class FilterCovariance:
         self.P_pred = self.P.copy()
 
 
+def batched_odometry_tick(covs, stopped, imus):
+    """FilterCovariance.odometry_tick for a whole ensemble at once (the per-trajectory form is 5 x 3 small matrix products and up to
+    six 15 x 15 Joseph updates per tick in Python: 64 trajectories x 600 ticks spent 2.5 of the replay's 3 s of wall clock there).
+    Stacked matmul / inv run the same routine per trajectory as the one-at-a-time form: the same numbers.  covs: FilterCovariance
+    objects; stopped: bools; imus: per trajectory the IMU_PER_ODO (f_b, w_b) samples, or None (fixed matrix)."""
+    n = len(covs)
+    if n == 0:
+        return
+    P = np.stack([c.P for c in covs])
+    Q = np.stack([c.Q for c in covs])
+    STM0 = np.stack([c.STM0 for c in covs])
+    STM = np.stack([c.STM for c in covs])
+    stopped = np.asarray(stopped, dtype=bool)
+    zu = np.array([c.zero_updates_enabled for c in covs], dtype=bool) & stopped
+    has_imu = np.array([im is not None for im in imus], dtype=bool)
+    dt = DT_ODO / IMU_PER_ODO
+    I15 = np.eye(15)
+
+    def skew(v):   # (m, 3) -> (m, 3, 3)
+        z = np.zeros(len(v))
+        return np.stack([np.stack([z, -v[:, 2], v[:, 1]], 1), np.stack([v[:, 2], z, -v[:, 0]], 1), np.stack([-v[:, 1], v[:, 0], z], 1)], 1)
+
+    def joseph(Pm, H, R):
+        Ht = np.swapaxes(H, -1, -2)
+        K = Pm @ Ht @ np.linalg.inv(H @ Pm @ Ht + R)
+        IKH = I15 - K @ H
+        return IKH @ Pm @ np.swapaxes(IKH, -1, -2) + K @ R @ np.swapaxes(K, -1, -2)
+
+    for j in range(IMU_PER_ODO):
+        if has_imu.any():
+            idx = np.nonzero(has_imu)[0]
+            f_b = np.stack([imus[i][j][0] for i in idx])
+            w_b = np.stack([imus[i][j][1] for i in idx])
+            S = STM0[idx].copy()
+            S[:, 0:3, 0:3] -= skew(w_b) * dt
+            S[:, 3:6, 0:3] -= skew(f_b) * dt
+            STM[idx] = S
+        P = STM @ P @ np.swapaxes(STM, -1, -2) + Q
+        if zu.any():
+            P[zu] = joseph(P[zu], _H_ZERO[None], _R_ZERO[None])
+    drv = ~stopped
+    if drv.any():
+        H = np.stack([covs[i].H for i in np.nonzero(drv)[0]])
+        P[drv] = joseph(P[drv], H, _R_ODO[None])
+    for i, c in enumerate(covs):
+        c.P = P[i]
+        c.STM = STM[i]
+        if zu[i]:
+            c.zero_updates += IMU_PER_ODO
+
+
 class Trajectory:
     def __init__(self, seed, evolve_filter=True, zero_updates=True, imu_stream=True):
         self.sim = RoverSim(seed)
@@ -163,15 +214,26 @@ class Trajectory:
         self._was_stopped = False
 
     def tick(self, now):
+        self.sense(now)
+        if self.cov is not None:
+            # the filter runs at the IMU rate: five 50 Hz samples per 10 Hz odometry tick, each with its own transition matrix
+            self.cov.odometry_tick(self._cmd == 0.0, self._imu)
+        return self.publish()
+
+    def sense(self, now):
+        """First half of a tick: the drive command, the wheel / INS speeds and the IMU samples of this odometry period."""
         cmd = self.drv.cmd(now)
         if cmd == 0.0 and not self._was_stopped:
             self.stops += 1
         self._was_stopped = cmd == 0.0
         self.rec.cmd_callback(cmd)
-        wheels, vlin = self.sim.step(cmd != 0.0)
-        if self.cov is not None:
-            # the filter runs at the IMU rate: five 50 Hz samples per 10 Hz odometry tick, each with its own transition matrix
-            self.cov.odometry_tick(cmd == 0.0, self.sim.imu(vlin) if self.imu_stream else None)
+        self._wheels, self._vlin = self.sim.step(cmd != 0.0)
+        self._cmd = cmd
+        self._imu = self.sim.imu(self._vlin) if (self.cov is not None and self.imu_stream) else None
+
+    def publish(self):
+        """Second half (after the covariance update of the tick): the recorder, and the snapshot a published window is served from."""
+        wheels, vlin, cmd = self._wheels, self._vlin, self._cmd
         win = self.rec.update(*wheels, vlin, cmd)
         if win is not None and self.cov is not None:
             # CoreNav.cpp:289-305: the snapshot is taken at the tick that publishes the window; setStopping_ (:652-676) serves
@@ -219,7 +281,11 @@ class ClosedLoopEnsemble:
 
     def step(self):
         self.now += DT_ODO
-        pubs = [(i, w) for i, tr in enumerate(self.traj) if (w := tr.tick(self.now)) is not None]
+        for tr in self.traj:
+            tr.sense(self.now)
+        live = [tr for tr in self.traj if tr.cov is not None]
+        batched_odometry_tick([tr.cov for tr in live], [tr._cmd == 0.0 for tr in live], [tr._imu for tr in live])   # the ensemble's filters in one go
+        pubs = [(i, w) for i, tr in enumerate(self.traj) if (w := tr.publish()) is not None]
         if not pubs:
             return 0
         outs = self._fit_windows([i for i, _ in pubs], [w for _, w in pubs])
