@@ -944,3 +944,31 @@ def test_fp32_refinement_of_a_long_window(engine):
     e, e0 = float(np.max(np.abs(mean[1] - omu))) / ms, float(np.max(np.abs(mean0[1] - omu))) / ms
     assert e < 2e-5 and e0 > 20 * e, (e, e0)
     assert releach(var[1], ovar) < TOL32 and abs(logml[1] - f.logml) <= TOL32 * abs(f.logml)
+
+
+def test_sweep_of_refined_fp32_windows(engine):
+    """cgp_sweep_fit_predict over three contexts on the one GPU with dense one-dimensional fp32 windows: every shard's context
+    refines its own fits (the default), a shard equals a single context given the same fits bitwise, the sweep's means agree
+    with a one-context call of the whole batch to 2e-5 (both are refined towards the same double-precision answer; the
+    factors differ with the call size) and with the oracle; Sweep.set_refine(0) switches every shard's refinement off."""
+    N, M, d, B = 520, 33, 1, 150
+    X, y, Xs, th = _dense_windows(B, N, d, M, 4321)
+    ctx = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=B, dtype=engine.F32)
+    rc, mean, var, logml, info = ctx.fit_predict_batch(X, y, Xs, th, 1)
+    assert rc == 0 and not info.any()
+    sw = engine.Sweep([0, 0, 0], N, M, d, B, dtype=engine.F32)
+    rc, m2, v2, l2, i2, summ = sw.fit_predict(X, y, Xs, th, 1)
+    assert rc == 0 and not i2.any()
+    scale = np.maximum(np.max(np.abs(mean), axis=1), 0.1 * np.max(np.abs(y), axis=1))
+    assert np.max(np.max(np.abs(m2 - mean), axis=1) / scale) < 2e-5
+    a, b = sw.shard(B, 2)
+    one = engine.Context(max_n=N, max_m=M, max_d=d, max_batch=b - a, dtype=engine.F32)
+    rc, m3, v3, l3, i3 = one.fit_predict_batch(X[a:b], y[a:b], Xs[a:b], th[a:b], 1)
+    assert rc == 0 and np.array_equal(m3, m2[a:b]) and np.array_equal(v3, v2[a:b]) and np.array_equal(l3, l2[a:b])
+    for bb in (0, 149):
+        f = go.fit(1, th[bb], X[bb], y[bb])
+        omu, _ = go.predict(f, Xs[bb])
+        assert float(np.max(np.abs(m2[bb] - omu))) / max(float(np.max(np.abs(omu))), 0.1 * float(np.max(np.abs(y[bb])))) < 2e-5
+    sw.set_refine(0)
+    rc, m4, v4, l4, i4, _ = sw.fit_predict(X, y, Xs, th, 1)
+    assert rc == 0 and np.array_equal(v4, v2) and np.array_equal(l4, l2) and not np.array_equal(m4, m2)
