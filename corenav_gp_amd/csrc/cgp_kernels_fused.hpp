@@ -191,7 +191,28 @@ __device__ __forceinline__ int bx_row_slot(int r) { return (r & ~31) | ((r & 1) 
 // eight floats (consecutive k of one row) -> three planes of eight bf16 each, written as 16-byte rows.  Split by truncation:
 // x0 = the top 16 bits of x, x1 = the top 16 bits of x - x0, x2 = those of x - x0 - x1 (both differences exact); v_perm_b32 packs
 // the high halves of two words.
+#ifndef CGP_BX_RNE
+#define CGP_BX_RNE 0
+#endif
+typedef __bf16 bxbf2 __attribute__((ext_vector_type(2)));
+typedef float bxf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void bx_split8(const float (&x)[8], bxu4 (&w)[3]) {
+#if CGP_BX_RNE
+  // split by rounding to nearest (v_cvt_pk_bf16_f32 rounds and packs a pair): the residuals are signed, x - x0 - x1 still has at
+  // most 8 significant bits, and the three products the 6-term form drops (x1 y2, x2 y1, x2 y2) are 8 x smaller and of either sign
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const bxf2 a = {x[i], x[i + 1]};
+    const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bxbf2));
+    const bxf2 ra = {a.x - __uint_as_float(p0 << 16), a.y - __uint_as_float(p0 & 0xffff0000u)};
+    const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(ra, bxbf2));
+    const bxf2 rb = {ra.x - __uint_as_float(p1 << 16), ra.y - __uint_as_float(p1 & 0xffff0000u)};
+    w[0][i >> 1] = p0;
+    w[1][i >> 1] = p1;
+    w[2][i >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(rb, bxbf2));
+  }
+  return;
+#endif
 #pragma unroll
   for (int i = 0; i < 8; i += 2) {
     unsigned hi[2][3];
