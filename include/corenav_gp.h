@@ -58,7 +58,8 @@ enum {
  *     one-dimensional inputs), where no single-precision factorisation holds 1e-3;
  *   - the reference's RBF x Brownian kernel on raw tick counts (cond(Ky) ~ 1e6, prior variance 1000 x the posterior one) is an
  *     fp64 path, as in the reference: in CGP_F32 its mean is refined like any d = 1 window, its variance is held to
- *     max(3e-3, 30 x that LAPACK error) only.  Use CGP_F64 for that kernel.
+ *     max(3e-3, 30 x that LAPACK error) only (its banded factor meets the bf16 matrix cores' truncating sums: a bias of
+ *     +1.6e-3 +- 5e-4 at a thousand samples, one sweep window at 3.29e-3).  Use CGP_F64 for that kernel.
  * Returns NULL on failure (device index out of range, device is not gfx950 -- the architecture name
  * is checked: the code object holds gfx950 kernels only -- or out of memory): no CPU fallback. */
 cgp_ctx *cgp_create(int device, int max_n, int max_m, int max_d, int max_batch, int dtype);
