@@ -71,13 +71,39 @@ __device__ __forceinline__ double win_cov(int kid, int d, const double *pr, cons
   return pr[9] * exp(-0.5 * rr * rr) * kb;
 }
 
+// 64-bit DPP row shift right by S lanes inside every 16-lane row, zero fill (prefix sums over a diagonal block's lanes)
+template <int S> __device__ __forceinline__ double win_row_shr(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + S, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + S, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// exclusive prefix sum over the 16 lanes of a row
+__device__ __forceinline__ double win_row_scan_excl(double x) {
+  double s = win_row_shr<1>(x);
+  s += win_row_shr<1>(s);
+  s += win_row_shr<2>(s);
+  s += win_row_shr<4>(s);
+  s += win_row_shr<8>(s);
+  return s;
+}
+
+// The single-tick kernel.  Round 6 (end): the rank-1 update is no longer a chain of rotations.  With w = L22^-1 v (v = the dropped
+// sample's column) and t_j = 1 + sum_{k<=j} w_k^2 the rotation that folds v_j into column j is c_j = sqrt(t_{j-1} / t_j),
+// s_j = w_j / sqrt(t_j), and the vector it acts on is the substitution's residual u^(j) = v - L[:, :j] w[:j] over sqrt(t_{j-1}):
+//   L'_ij = c_j L_ij + s'_j u^(j)_i,  s'_j = w_j / sqrt(t_j t_{j-1})            (i >= j; the diagonal comes out as L_jj / c_j)
+// and with L' = L22 G, G = chol(I + w w') (semiseparable: G_jj = 1 / c_j, G_ij = w_i s'_j) the append solve and the z row follow
+// from substitutions with the OLD factor, q = L22^-1 k, qy = L22^-1 y2 = z2 + w z0, and running sums:
+//   l_j = (q_j - w_j S_j / t_{j-1}) c_j,  S_j = sum_{k<j} w_k q_k               (the same with qy for z')
+// So the only serial work of a panel is a two-right-hand-side forward substitution of its 16 x 16 block (two DPP instructions per
+// step and right-hand side); sixteen rsqrt, the prefix sums and the new block are lane-parallel.  Measured (tools/window_host_tick.py,
+// one N = 512 window, T = 1 pushes): see DESIGN.md section 9.
 __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double *vv = reinterpret_cast<double *>(smem_raw);  // [N] rank-1 vector
-  double *kk = vv + p.N;                               // [N] right-hand side of the append solve
+  double *vv = reinterpret_cast<double *>(smem_raw);  // [N] residual u of the substitution with v (the rank-1 vector)
+  double *kk = vv + p.N;                               // [N] residual of the substitution with k (the append solve)
   double *ll = kk + p.N;                               // [N] solution l
-  double *cs = ll + p.N;                               // [2][2][WPB] c, s of a panel's rotations, double-buffered
-  double *xn = cs + 4 * WPB;                           // [MAXD] the incoming point
+  double *cs = ll + p.N;                               // [2][WPB][4] c, s', w, q of a panel's columns, double-buffered
+  double *xn = cs + 8 * WPB;                           // [MAXD] the incoming point
   double *red = xn + MAXD;                             // [8] scalars handed from wave 0 to the block
   const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,23 +141,23 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
       vv[i] = drop ? L[(size_t)o * CAP + o2 + i] : 0.0;
       kk[i] = win_cov(kid, d, pr, xw + o2 + i, CAP, xn, 1, false);
     }
-    double vz = drop ? z[o] : 0.0;  // the dropped sample's component of z (uniform)
-    double sl2 = 0, slz = 0, slog = 0, szz = 0;
+    const double z0 = drop ? z[o] : 0.0;  // the dropped sample's component of z (uniform)
+    double sl2 = 0, slz = 0, slog = 0, szz = 0;   // wave 0: per-lane partial sums over the panels (reduced once per tick)
     // sum of log(diag) without a log on the serial path: every lane of wave 0's first row keeps the running
     // product of its diagonal entries as (mantissa in [0.5, 1), exponent); ONE log per lane and tick at the end
     double pmant = 1.0;
     int pexp = 0;
     __syncthreads();
 
-    // Panel pipeline.  Per 16-column panel the work is  A(p): wave 0 rotates and solves the 16x16
-    // diagonal block (serial, in registers)  and  B(p): every row below takes the panel's 16
-    // rotations and the substitution update.  A(p+1) only needs B(p) on the 16 rows of the next
-    // diagonal block, so wave 0 applies B(p) to those rows itself and goes straight on to A(p+1) while
-    // waves 1-3 sweep the remaining rows: one barrier per panel, serial part and sweep side by side.
-    // (c, s) of a panel live in cs[panel & 1] (double buffer), l in ll[p0 ..].
+    // Panel pipeline.  Per 16-column panel the work is  A(p): wave 0 solves the 16x16 diagonal block for w and q
+    // (serial, in registers) and forms the panel's c, s', l, z' and the new block  and  B(p): every row below takes
+    // the panel's columns.  A(p+1) only needs B(p) on the 16 rows of the next diagonal block, so wave 0 applies B(p)
+    // to those rows itself and goes straight on to A(p+1) while waves 1-3 sweep the remaining rows: one barrier per
+    // panel, serial part and sweep side by side.  (c, s', w, q) of a panel live in cs[panel & 1], l in ll[p0 ..].
     const int i = lane & (WPB - 1);
     const int npan = (n2 + WPB - 1) / WPB;
-    double vi = 0, ki = 0, zi = 0;  // wave 0: the diagonal block's rows of v, k, z (registers across panels)
+    double ui = 0, ki = 0, zi = 0;  // wave 0: the diagonal block's rows of u, k, z (registers across panels)
+    double Tb = 1.0, Skb = 0.0, Syb = 0.0;   // wave 0: t, sum w q, sum w qy up to the panel's first column (uniform)
     // Addressing of the factor: a buffer descriptor on the window's slab + one 32-bit byte offset per lane
     // + one scalar offset per column, instead of 64-bit pointer arithmetic per entry (the sweep is bound by
     // instruction issue, not by HBM: DESIGN.md section 9).
@@ -148,122 +174,117 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
       __builtin_amdgcn_raw_buffer_store_b64(q, rsrc, off, soff, 0);
     };
     const int colb = CAP * (int)sizeof(double);  // bytes between columns
-    // the 16x16 diagonal block of panel p0 (lane = row), identity-padded; issued early by the caller
-    auto load_diag = [&](int p0, int nb, double (&a)[WPB]) {
+    // the 16x16 diagonal block of panel p0 (lane = row): strictly lower part in a[] (zero elsewhere), the lane's own
+    // diagonal entry in dg (1 on the padded rows); issued early by the caller
+    auto load_diag = [&](int p0, int nb, double (&a)[WPB], double &dg) {
       const unsigned off = (unsigned)(((o2 + p0) * CAP + o2 + p0 + i) * (int)sizeof(double));
 #pragma unroll
-      for (int j = 0; j < WPB; ++j) a[j] = (j <= i && i < nb && j < nb) ? ld64(off, j * colb) : (i == j ? 1.0 : 0.0);
+      for (int j = 0; j < WPB; ++j) a[j] = (j < i && i < nb) ? ld64(off, j * colb) : 0.0;
+      dg = i < nb ? ld64(off + (unsigned)(i * colb), 0) : 1.0;
       zi = i < nb ? z[o2 + p0 + i] : 0.0;
     };
-    auto phase_a = [&](int p0, int nb, double *csb, double (&a)[WPB]) {
-      // Givens rotation (c, s) = (l_jj, v_j) / sqrt(l_jj^2 + v_j^2) that folds v_j into the diagonal:
-      // one hardware-seeded rsqrt with a third-order step; this chain is the serial critical path
-      // of the tick.  Broadcasts of lane j's values are 64-bit DPP row_newbcast moves (the four
-      // 16-lane rows hold identical copies).
-      double idg = 1.0;  // 1 / (new diagonal entry of this lane's row): the rotation's own rsqrt, no division
-      double mine = 0.0;
-      // No guard on J < nb: beyond the window the block is identity-padded with v = z = k = 0, so those steps
-      // are exact no-ops (c = 1, s = 0) -- 32 fewer branches per panel on the serial path.
-      static_for<0, WPB>([&](auto jc) {
+    auto phase_a = [&](int p0, int nb, double *csb, double (&a)[WPB], double dg) {
+      // 1 / diagonal (off the chain: the block arrived a panel ago): hardware seed and two Newton steps
+      double idg = __builtin_amdgcn_rcp(dg);
+      idg = __builtin_fma(__builtin_fma(-dg, idg, 1.0), idg, idg);
+      idg = __builtin_fma(__builtin_fma(-dg, idg, 1.0), idg, idg);
+      // forward substitution of the block, both right-hand sides: after step J lane J's residual is final (its own
+      // diagonal is not in a[]), so w_J = u_J / L_JJ is lane J's product, broadcast and subtracted in ONE DPP instruction
+      static_for<0, WPB - 1>([&](auto jc) {
         constexpr int J = decltype(jc)::value;
-        {
-          const double ljj = mov_bcast<J>(a[J]), vj = mov_bcast<J>(vi), zj = mov_bcast<J>(zi);
-          const double r2 = __builtin_fma(vj, vj, ljj * ljj);
-          const double ri = rsqrt3(r2);
-          const double c = ljj * ri, sn = vj * ri;
-          const double aj = a[J];
-          const double tv = __builtin_fma(sn, vi, c * aj);
-          const double nv = __builtin_fma(c, vi, -(sn * aj));
-          if (i > J) {
-            a[J] = tv;
-            vi = nv;
-          } else if (i == J) {
-            a[J] = r2 * ri;  // sqrt(l_jj^2 + v_j^2)
-            idg = ri;
-          }
-          const double zn = __builtin_fma(sn, vz, c * zj);
-          vz = __builtin_fma(c, vz, -(sn * zj));
-          if (i == J) zi = zn;
-          szz += zn * zn;
-          csb[J] = c;           // every lane holds the same (c, s): one uniform-address LDS write, no exec mask dance
-          csb[WPB + J] = sn;
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        const double wv = ui * idg, qv = ki * idg;
+        fnmac_bcast<J, true>(ui, wv, a[J]);
+        fnmac_bcast<J, true>(ki, qv, a[J]);
       });
-      // diagonal of the finished block into the running product (off the critical path: nothing below reads it)
+      const double wm = ui * idg, qm = ki * idg;          // w_i, q_i of this lane's column
+      const double qy = __builtin_fma(wm, z0, zi);        // (L22^-1 y2)_i
+      const double w2 = wm * wm;
+      const double Tj = Tb + win_row_scan_excl(w2), Tj1 = Tj + w2;
+      const double Sk = Skb + win_row_scan_excl(wm * qm), Sy = Syb + win_row_scan_excl(wm * qy);
+      const double rj = rsqrt3(Tj), rj1 = rsqrt3(Tj1);
+      const double g = Tj * rj * rj1;                      // c_j = sqrt(t_{j-1} / t_j)
+      const double h = wm * (rj * rj);                     // w_j / t_{j-1}
+      const double sp = h * g;                             // s'_j
+      const double lj = __builtin_fma(-h, Sk, qm) * g;
+      const double zn = __builtin_fma(-h, Sy, qy) * g;
+      sl2 = __builtin_fma(lj, lj, sl2);
+      slz = __builtin_fma(lj, zn, slz);
+      szz = __builtin_fma(zn, zn, szz);
+      const double dnew = dg * (Tj1 * rj1 * rj);           // L_jj / c_j
+      if (lane < WPB) {
+        csb[4 * i + 0] = g;
+        csb[4 * i + 1] = sp;
+        csb[4 * i + 2] = wm;
+        csb[4 * i + 3] = qm;
+      }
       if (lane < nb) {
-        double dg = 1.0;
-#pragma unroll
-        for (int j = 0; j < WPB; ++j) dg = (i == j) ? a[j] : dg;
-        pmant *= dg;
+        pmant *= dnew;
         pexp += __builtin_amdgcn_frexp_exp(pmant);
         pmant = __builtin_amdgcn_frexp_mant(pmant);
+        ll[p0 + i] = lj;
+        z[o2 + p0 + i] = zn;
       }
-      // forward substitution inside the block for the incoming point
-      static_for<0, WPB>([&](auto qc) {
-        constexpr int Q = decltype(qc)::value;
-        {
-          const double lq = mov_bcast<Q>(ki * idg);   // 0 on the padded rows
-          if (i > Q) ki = __builtin_fma(-a[Q], lq, ki);
-          sl2 = __builtin_fma(lq, lq, sl2);
-          fmac_bcast<Q, true>(slz, zi, lq);
-          mine = (i == Q) ? lq : mine;   // lane q keeps l_q
-          __builtin_amdgcn_sched_barrier(0);
-        }
+      // the new block, column by column from the right: u^(k)_i = L_ii w_i + sum_{m=k}^{i-1} L_im w_m (the substitution's
+      // residual before column k, as a sum of what is left of it), L'_ik = c_k L_ik + s'_k u^(k)_i
+      double acc = dg * wm;
+      const unsigned off = (unsigned)(((o2 + p0) * CAP + o2 + p0 + i) * (int)sizeof(double));
+      static_for<0, WPB - 1>([&](auto kc) {
+        constexpr int K = WPB - 2 - decltype(kc)::value;   // 14 .. 0
+        fmac_bcast<K, true>(acc, wm, a[K]);
+        double out = 0.0;
+        fmac_bcast<K, true>(out, g, a[K]);
+        fmac_bcast<K, true>(out, sp, acc);
+        if (K < i && lane < nb) st64(out, off, K * colb);
       });
-      if (lane < nb) ll[p0 + i] = mine;  // l of the panel: one predicated LDS write instead of sixteen
-      if (lane < nb) {
-        const unsigned off = (unsigned)(((o2 + p0) * CAP + o2 + p0 + i) * (int)sizeof(double));
-#pragma unroll
-        for (int j = 0; j < WPB; ++j)
-          if (j <= i && j < nb) st64(a[j], off, j * colb);
-        z[o2 + p0 + i] = zi;
-      }
+      if (lane < nb) st64(dnew, off + (unsigned)(i * colb), 0);
+      // carry t and the running sums to the next panel (lane 15 of the row holds the block's totals)
+      Tb = mov_bcast<WPB - 1>(Tj1);
+      Skb = mov_bcast<WPB - 1>(__builtin_fma(wm, qm, Sk));
+      Syb = mov_bcast<WPB - 1>(__builtin_fma(wm, qy, Sy));
     };
-    // one row of the sweep: a[] = the row's 16 panel columns; returns the row's updated v and k
-    auto sweep_row = [&](double (&a)[WPB], double &v, double &k, const double *csb, int p0) {
+    // one row of the sweep: a[] = the row's 16 panel columns (old factor); u, k = the row's residuals
+    auto sweep_row = [&](double (&a)[WPB], double &u, double &k, const double *csb) {
 #pragma unroll
       for (int j = 0; j < WPB; ++j) {
-        const double c = csb[j], sn = csb[WPB + j], aj = a[j];
-        const double tv = __builtin_fma(sn, v, c * aj);
-        v = __builtin_fma(c, v, -(sn * aj));
-        a[j] = tv;
-        k = __builtin_fma(-tv, ll[p0 + j], k);
+        const double c = csb[4 * j], sp = csb[4 * j + 1], wj = csb[4 * j + 2], qj = csb[4 * j + 3], aj = a[j];
+        a[j] = __builtin_fma(sp, u, c * aj);
+        u = __builtin_fma(-aj, wj, u);
+        k = __builtin_fma(-aj, qj, k);
       }
     };
 
     if (wave == 0 && npan > 0) {
       const int nb = min(WPB, n2);
-      vi = i < nb ? vv[i] : 0.0;
+      ui = i < nb ? vv[i] : 0.0;
       ki = i < nb ? kk[i] : 0.0;
-      double ad[WPB];
-      load_diag(0, nb, ad);
-      phase_a(0, nb, cs, ad);
+      double ad[WPB], dg;
+      load_diag(0, nb, ad, dg);
+      phase_a(0, nb, cs, ad, dg);
     }
     for (int pi = 0; pi < npan; ++pi) {
       lds_barrier();  // A(pi) and B(pi-1) are complete.  LDS only: within a tick no thread reads factor entries another
                       // thread wrote (a panel's entries have one owner), so the sweep's HBM stores stay in flight
       const int p0 = pi * WPB;
-      const double *csb = cs + (pi & 1) * 2 * WPB;
+      const double *csb = cs + (pi & 1) * 4 * WPB;
       if (wave == 0) {
         if (pi + 1 < npan) {
-          // B(pi) on the rows of the next diagonal block, then A(pi + 1) with v, k still in registers
+          // B(pi) on the rows of the next diagonal block, then A(pi + 1) with u, k still in registers
           const int nb1 = min(WPB, n2 - (p0 + WPB));
           const int r = p0 + WPB + i;
-          double ad[WPB];
-          load_diag(p0 + WPB, nb1, ad);  // in flight while the 16 rows below take B(pi)
+          double ad[WPB], dg;
+          load_diag(p0 + WPB, nb1, ad, dg);  // in flight while the 16 rows below take B(pi)
           double a[WPB];
           const unsigned offr = (unsigned)(((o2 + p0) * CAP + o2 + r) * (int)sizeof(double));
 #pragma unroll
           for (int j = 0; j < WPB; ++j) a[j] = i < nb1 ? ld64(offr, j * colb) : 0.0;
-          vi = i < nb1 ? vv[r] : 0.0;
+          ui = i < nb1 ? vv[r] : 0.0;
           ki = i < nb1 ? kk[r] : 0.0;
-          sweep_row(a, vi, ki, csb, p0);
+          sweep_row(a, ui, ki, csb);
           if (lane < nb1) {
 #pragma unroll
             for (int j = 0; j < WPB; ++j) st64(a[j], offr, j * colb);
           }
-          phase_a(p0 + WPB, nb1, cs + ((pi + 1) & 1) * 2 * WPB, ad);
+          phase_a(p0 + WPB, nb1, cs + ((pi + 1) & 1) * 4 * WPB, ad, dg);
         }
       } else {
         // ---- B(pi): rows below the next diagonal block, three waves
@@ -273,11 +294,11 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
           double a[WPB];
 #pragma unroll
           for (int j = 0; j < WPB; ++j) a[j] = ld64(offr, j * colb);
-          double v = vv[r], k = kk[r];
-          sweep_row(a, v, k, csb, p0);
+          double u = vv[r], k = kk[r];
+          sweep_row(a, u, k, csb);
 #pragma unroll
           for (int j = 0; j < WPB; ++j) st64(a[j], offr, j * colb);
-          vv[r] = v;
+          vv[r] = u;
           kk[r] = k;
         }
       }
@@ -290,6 +311,12 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
       slog = lg;
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {   // the 16 lanes of a row (the four rows hold identical copies)
+        sl2 += __shfl_xor(sl2, off);
+        slz += __shfl_xor(slz, off);
+        szz += __shfl_xor(szz, off);
+      }
     }
     if (tid == 0) {
       red[0] = sl2; red[1] = slz; red[2] = slog; red[3] = szz;
