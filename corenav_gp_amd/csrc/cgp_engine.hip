@@ -248,7 +248,8 @@ constexpr size_t kOptPinIn = CGP_MAX_THETA + 8;   // doubles at the head of the 
 constexpr bool kWinPairs = CGP_WIN_PAIRS != 0;
 constexpr size_t kWinZeroCopyBytes = 16 * 1024;   // cgp_window_push blocks up to this size are read / written in pinned host memory by the kernels
 constexpr int kWinPackLds = 72 * 1024;       // pack windows into a workgroup only while two workgroups still fit a CU's LDS ...
-constexpr int kWinPackMinGroups = 512;       // ... and the chip still gets two workgroups per CU
+constexpr int kWinPackMinGroups = 512;
+constexpr int kWinWideMax = 256;            // single-tick kernel: up to this many windows 512 threads per window       // ... and the chip still gets two workgroups per CU
 // fp64 mid-size calls put their extra rows on a second stream when there is enough of them: fits x block steps >= this
 // (tools/r3_xs_n.sh, same box, with / without, ms per call: N = 2048 28 fits 3.77 / 3.70, 36 fits 4.25 / 4.45, 48 fits 5.01 / 5.70;
 // N = 1536 36 fits 2.37 / 2.38, 48 fits 2.71 / 3.01; N = 1024 36 fits 1.27 / 1.17, 48 fits 1.29 / 1.31; N = 512 28 fits 0.52 / 0.42)
@@ -2450,7 +2451,7 @@ int window_push_impl(cgp_ctx *c, int T, const double *dxs, const double *dys, in
   // pass over the factor (k_window_pairs), everything else -- filling, the tick that compacts the ring, an odd one out --
   // through the single-tick kernel.  Origin and size of the windows are deterministic and identical for every window of
   // the context, so the host mirrors them instead of reading them back.
-  const size_t lds1 = (size_t)(3 * a.N + 8 * WPB + MAXD + 8) * sizeof(double);
+  const size_t lds1 = (size_t)(3 * a.N + 8 * WPB + MAXD + 8 + 2 * WIN_STG) * sizeof(double);
   const size_t lds2 = (size_t)(6 * ((a.N + 3) & ~1) + 8 * WPB + 2 * MAXD + 16) * sizeof(double);   // per window
   // windows per workgroup of the paired kernel (rows of wave 0 per window: 4 / wpw)
   // measured (tools/r3_winpack.sh, N = 512): 1024 windows 2.20 / 2.65 / 2.03 M ticks/s at 1 / 2 / 4 per workgroup, 512 windows
@@ -2497,7 +2498,16 @@ int window_push_impl(cgp_ctx *c, int T, const double *dxs, const double *dys, in
       ++ns;
     } while (t + ns < T && !pair_ok(o, n, T - t - ns));
     a.nt = ns;
-    hipLaunchKernelGGL(k_window_ticks, dim3(c->nwin), dim3(256), lds1, ws, a);
+    // threads per window: with no more windows than CUs a workgroup sweeps with seven waves instead of three (1024 threads: 128 VGPRs
+    // per lane, the serial wave spills -- 251 us per host tick against 117)
+    int wth = c->nwin <= kWinWideMax ? 512 : 256;
+    if constexpr (kAbBuild) {
+      const char *e = getenv("CGP_WIN_THREADS");
+      const int v = e ? atoi(e) : 0;
+      if (v == 256 || v == 512) wth = v;
+    }
+    if (wth == 512) hipLaunchKernelGGL(k_window_ticks<512>, dim3(c->nwin), dim3(512), lds1, ws, a);
+    else hipLaunchKernelGGL(k_window_ticks<256>, dim3(c->nwin), dim3(256), lds1, ws, a);
     t += ns;
   }
   if (!hip_ok(c, hipGetLastError(), "window launches")) {

@@ -31,6 +31,9 @@ static_assert(WPB == 16, "phase A broadcasts with DPP row_newbcast: one 16-lane 
 #define WIN_OCC 2
 #endif
 
+#ifndef WIN_PROBE
+#define WIN_PROBE 0   // `make variant` measurement build (tools/window_tick_phases.py): k_window_ticks returns wave 0's per-phase clock sums instead of the tick's outputs
+#endif
 #ifndef WIN_BPREFETCH
 #define WIN_BPREFETCH 0  // sweep waves: next trip's row in flight during the current one (+32 VGPRs: measured)
 #endif
@@ -97,7 +100,9 @@ __device__ __forceinline__ double win_row_scan_excl(double x) {
 // So the only serial work of a panel is a two-right-hand-side forward substitution of its 16 x 16 block (two DPP instructions per
 // step and right-hand side); sixteen rsqrt, the prefix sums and the new block are lane-parallel.  Measured (tools/window_host_tick.py,
 // one N = 512 window, T = 1 pushes): see DESIGN.md section 9.
-__global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
+constexpr int WIN_STG = 2 * WPB * WPB + 2 * WPB;   // doubles of one staging buffer of wave 0's inputs: 16 rows of the panel, the next diagonal block, z
+template <int NTH>   // threads of the workgroup: 256 (two workgroups per CU, many windows) or 512 (no more windows than CUs: seven sweep waves per window)
+__global__ __launch_bounds__(NTH, NTH == 256 ? WIN_OCC : 1) void k_window_ticks(WindowArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *vv = reinterpret_cast<double *>(smem_raw);  // [N] residual u of the substitution with v (the rank-1 vector)
   double *kk = vv + p.N;                               // [N] residual of the substitution with k (the append solve)
@@ -105,6 +110,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
   double *cs = ll + p.N;                               // [2][WPB][4] c, s', w, q of a panel's columns, double-buffered
   double *xn = cs + 8 * WPB;                           // [MAXD] the incoming point
   double *red = xn + MAXD;                             // [8] scalars handed from wave 0 to the block
+  double *stg = red + 8;                               // [2][WIN_STG] wave 0's inputs of the next panel step, staged by wave 1 (LDS-DMA)
   const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = p.N, CAP = p.CAP, d = p.d, kid = p.kernel_id;
@@ -123,8 +129,8 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
     // ---- make room: move the window back to the origin when it reached the end of the buffer
     if (o + n >= CAP) {
       for (int c = 0; c < n; ++c)
-        for (int r = c + tid; r < n; r += 256) L[(size_t)c * CAP + r] = L[(size_t)(o + c) * CAP + o + r];
-      for (int i = tid; i < n; i += 256) {
+        for (int r = c + tid; r < n; r += NTH) L[(size_t)c * CAP + r] = L[(size_t)(o + c) * CAP + o + r];
+      for (int i = tid; i < n; i += NTH) {
         z[i] = z[o + i];
         yw[i] = yw[o + i];
         for (int q = 0; q < d; ++q) xw[q * CAP + i] = xw[q * CAP + o + i];
@@ -137,11 +143,15 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
     if (tid < d) xn[tid] = p.xs[((size_t)w * p.T + t) * d + tid];
     __syncthreads();
     const double ynew = p.ys[(size_t)w * p.T + t];
-    for (int i = tid; i < n2; i += 256) {
+    for (int i = tid; i < n2; i += NTH) {
       vv[i] = drop ? L[(size_t)o * CAP + o2 + i] : 0.0;
       kk[i] = win_cov(kid, d, pr, xw + o2 + i, CAP, xn, 1, false);
     }
-    const double z0 = drop ? z[o] : 0.0;  // the dropped sample's component of z (uniform)
+    // the dropped sample's component of z: uniform, moved to scalar registers HERE so that its load is known to have landed
+    // before the panel loop (left in a VGPR the compiler waits for it at its first use inside the loop with vmcnt(0), i.e.
+    // for every store wave 0 has in flight, once per panel)
+    const double z0v = drop ? z[o] : 0.0;
+    const double z0 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(z0v)), __builtin_amdgcn_readfirstlane(__double2loint(z0v)));
     double sl2 = 0, slz = 0, slog = 0, szz = 0;   // wave 0: per-lane partial sums over the panels (reduced once per tick)
     // sum of log(diag) without a log on the serial path: every lane of wave 0's first row keeps the running
     // product of its diagonal entries as (mantissa in [0.5, 1), exponent); ONE log per lane and tick at the end
@@ -158,6 +168,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
     const int npan = (n2 + WPB - 1) / WPB;
     double ui = 0, ki = 0, zi = 0;  // wave 0: the diagonal block's rows of u, k, z (registers across panels)
     double Tb = 1.0, Skb = 0.0, Syb = 0.0;   // wave 0: t, sum w q, sum w qy up to the panel's first column (uniform)
+    double cg = 1.0, csp = 0.0, cw = 0.0, cq = 0.0;   // wave 0: lane j keeps c_j, s'_j, w_j, q_j of the panel it solved last (its own sweep takes them by DPP)
     // Addressing of the factor: a buffer descriptor on the window's slab + one 32-bit byte offset per lane
     // + one scalar offset per column, instead of 64-bit pointer arithmetic per entry (the sweep is bound by
     // instruction issue, not by HBM: DESIGN.md section 9).
@@ -237,6 +248,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
         if (K < i && lane < nb) st64(out, off, K * colb);
       });
       if (lane < nb) st64(dnew, off + (unsigned)(i * colb), 0);
+      cg = g; csp = sp; cw = wm; cq = qm;
       // carry t and the running sums to the next panel (lane 15 of the row holds the block's totals)
       Tb = mov_bcast<WPB - 1>(Tj1);
       Skb = mov_bcast<WPB - 1>(__builtin_fma(wm, qm, Sk));
@@ -253,6 +265,49 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
       }
     };
 
+    // Wave 0's inputs of panel step q -- the 16 rows under panel q's diagonal block in panel q's columns, the diagonal block
+    // of panel q + 1 and its rows of z -- are this tick's OLD values until wave 0 itself rewrites them, so wave 1 requests them
+    // one step ahead straight into LDS (dword LDS-DMA: the rows are only 8-byte aligned; 64 lanes = two columns of 16 rows);
+    // rows / columns past the window are clamped (never used: wave 0 masks them).  Wave 0 then has no load on its path.
+    auto stage_inputs = [&](int q) {
+      typedef __attribute__((address_space(3))) void lds_void;
+      typedef const __attribute__((address_space(1))) void gbl_void;
+      const int p0q = q * WPB, r0 = p0q + WPB;
+      double *sb = stg + (q & 1) * WIN_STG;
+      const int rl = min(r0 + ((lane & 31) >> 1), n2 - 1), hf = lane & 1;
+#pragma unroll
+      for (int c2 = 0; c2 < WPB / 2; ++c2) {
+        const int col = p0q + 2 * c2 + (lane >> 5);
+        const char *g = reinterpret_cast<const char *>(L + (size_t)(o2 + col) * CAP + o2 + rl) + 4 * hf;
+        __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)(sb + c2 * 2 * WPB), 4, 0, 0);
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < WPB / 2; ++c2) {
+        const int col = min(r0 + 2 * c2 + (lane >> 5), n2 - 1);
+        const char *g = reinterpret_cast<const char *>(L + (size_t)(o2 + col) * CAP + o2 + rl) + 4 * hf;
+        __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)(sb + WPB * WPB + c2 * 2 * WPB), 4, 0, 0);
+      }
+      {
+        const char *g = reinterpret_cast<const char *>(z + o2 + rl) + 4 * hf;   // lanes 32 .. 63: the same 16 rows again
+        __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)(sb + 2 * WPB * WPB), 4, 0, 0);
+      }
+    };
+    // wave 0's own rows: the panel's c, s', w, q are still in its registers (lane j: column j) -- four DPP instructions per column, no LDS read
+    auto sweep_row_w0 = [&](double (&a)[WPB], double &u, double &k) {
+      static_for<0, WPB>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        double out = 0.0;
+        fmac_bcast<J, false>(out, cg, a[J]);
+        fmac_bcast<J, false>(out, csp, u);
+        fnmac_bcast<J, false>(u, cw, a[J]);
+        fnmac_bcast<J, false>(k, cq, a[J]);
+        a[J] = out;
+      });
+    };
+    if (wave == 1 && npan > 1) {
+      stage_inputs(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (wave == 0 && npan > 0) {
       const int nb = min(WPB, n2);
       ui = i < nb ? vv[i] : 0.0;
@@ -261,34 +316,52 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
       load_diag(0, nb, ad, dg);
       phase_a(0, nb, cs, ad, dg);
     }
+#if WIN_PROBE
+    long long wp[4] = {0, 0, 0, 0}, wpt = __builtin_amdgcn_s_memtime();
+    const long long wp0 = wpt;
+#define WIN_LAP(k) { const long long nn_ = __builtin_amdgcn_s_memtime(); wp[k] += nn_ - wpt; wpt = nn_; }
+#else
+#define WIN_LAP(k)
+#endif
     for (int pi = 0; pi < npan; ++pi) {
+      WIN_LAP(3)
       lds_barrier();  // A(pi) and B(pi-1) are complete.  LDS only: within a tick no thread reads factor entries another
                       // thread wrote (a panel's entries have one owner), so the sweep's HBM stores stay in flight
       const int p0 = pi * WPB;
       const double *csb = cs + (pi & 1) * 4 * WPB;
       if (wave == 0) {
+        WIN_LAP(0)
         if (pi + 1 < npan) {
           // B(pi) on the rows of the next diagonal block, then A(pi + 1) with u, k still in registers
           const int nb1 = min(WPB, n2 - (p0 + WPB));
           const int r = p0 + WPB + i;
-          double ad[WPB], dg;
-          load_diag(p0 + WPB, nb1, ad, dg);  // in flight while the 16 rows below take B(pi)
-          double a[WPB];
+          double ad[WPB], dg, a[WPB];
+          const double *sb = stg + (pi & 1) * WIN_STG;
           const unsigned offr = (unsigned)(((o2 + p0) * CAP + o2 + r) * (int)sizeof(double));
 #pragma unroll
-          for (int j = 0; j < WPB; ++j) a[j] = i < nb1 ? ld64(offr, j * colb) : 0.0;
+          for (int j = 0; j < WPB; ++j) a[j] = i < nb1 ? sb[j * WPB + i] : 0.0;
+#pragma unroll
+          for (int j = 0; j < WPB; ++j) ad[j] = (j < i && i < nb1) ? sb[WPB * WPB + j * WPB + i] : 0.0;
+          dg = i < nb1 ? sb[WPB * WPB + i * WPB + i] : 1.0;
+          zi = i < nb1 ? sb[2 * WPB * WPB + i] : 0.0;
           ui = i < nb1 ? vv[r] : 0.0;
           ki = i < nb1 ? kk[r] : 0.0;
-          sweep_row(a, ui, ki, csb);
+#if WIN_PROBE
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          WIN_LAP(1)
+#endif
+          sweep_row_w0(a, ui, ki);
           if (lane < nb1) {
 #pragma unroll
             for (int j = 0; j < WPB; ++j) st64(a[j], offr, j * colb);
           }
+          WIN_LAP(2)
           phase_a(p0 + WPB, nb1, cs + ((pi + 1) & 1) * 4 * WPB, ad, dg);
         }
       } else {
-        // ---- B(pi): rows below the next diagonal block, three waves
-        for (int r = p0 + 2 * WPB + (tid - 64); r < n2; r += 192) {
+        if (wave == 1 && pi + 2 < npan) stage_inputs(pi + 1);
+        // ---- B(pi): rows below the next diagonal block, the other waves
+        for (int r = p0 + 2 * WPB + (tid - 64); r < n2; r += NTH - 64) {
           asm volatile("" ::: "memory");  // keep the panel's LDS scalars from being hoisted across rows
           const unsigned offr = (unsigned)(((o2 + p0) * CAP + o2 + r) * (int)sizeof(double));
           double a[WPB];
@@ -301,6 +374,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
           vv[r] = u;
           kk[r] = k;
         }
+        if (wave == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staged inputs have landed before the barrier publishes them
       }
     }
     __syncthreads();
@@ -332,7 +406,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
     const double dd = sqrt(d2);
     const double znew = (ynew - slz) / dd;
     double *Lrow = L + (size_t)o2 * CAP + o2 + n2;  // row n2 of the window, column 0
-    for (int j = tid; j < n2; j += 256) Lrow[(size_t)j * CAP] = ll[j];
+    for (int j = tid; j < n2; j += NTH) Lrow[(size_t)j * CAP] = ll[j];
     if (tid == 0) {
       Lrow[(size_t)n2 * CAP] = dd;
       z[o2 + n2] = znew;
@@ -344,6 +418,11 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_ticks(WindowArgs p) {
       p.pred_mean[oi] = slz;
       p.pred_var[oi] = p.include_noise ? pv + noise : pv;
       p.logml[oi] = -0.5 * (szz + znew * znew) - (slog + log(dd)) - 0.5 * (double)(n2 + 1) * 1.8378770664093453;
+#if WIN_PROBE   // measurement build: the tick's outputs are wave 0's clock sums (barrier wait, inputs read, row sweep + stores, serial block)
+      p.logml[oi] = (double)wp[0] * 67108864.0 + (double)wp[1];
+      p.pred_mean[oi] = (double)wp[2] * 67108864.0 + (double)wp[3];
+      p.pred_var[oi] = (double)(__builtin_amdgcn_s_memtime() - wp0);
+#endif
     }
     o = o2;
     n = n2 + 1;
