@@ -237,17 +237,25 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? WIN_OCC : 1) void k_window_ticks(
       }
       // the new block, column by column from the right: u^(k)_i = L_ii w_i + sum_{m=k}^{i-1} L_im w_m (the substitution's
       // residual before column k, as a sum of what is left of it), L'_ik = c_k L_ik + s'_k u^(k)_i
+      // (all lanes active for the DPP reads; the broadcast operands wm, g, sp were written long before: no hazard nop.  Columns right
+      // of a lane's diagonal get s'_k u_i -- they land in the strict upper triangle of the slab, which nothing reads -- so the sixteen
+      // stores need one predicate, the lane's, not one each)
       double acc = dg * wm;
       const unsigned off = (unsigned)(((o2 + p0) * CAP + o2 + p0 + i) * (int)sizeof(double));
+      double nw[WPB - 1];
       static_for<0, WPB - 1>([&](auto kc) {
         constexpr int K = WPB - 2 - decltype(kc)::value;   // 14 .. 0
-        fmac_bcast<K, true>(acc, wm, a[K]);
-        double out = 0.0;
-        fmac_bcast<K, true>(out, g, a[K]);
-        fmac_bcast<K, true>(out, sp, acc);
-        if (K < i && lane < nb) st64(out, off, K * colb);
+        fmac_bcast<K, false>(acc, wm, a[K]);
+        nw[K] = 0.0;
+        fmac_bcast<K, false>(nw[K], g, a[K]);
+        fmac_bcast<K, false>(nw[K], sp, acc);
       });
-      if (lane < nb) st64(dnew, off + (unsigned)(i * colb), 0);
+      if (lane < nb) {
+#pragma unroll
+        for (int K = 0; K < WPB - 1; ++K)
+          if (K < nb) st64(nw[K], off, K * colb);   // (uniform: a column past the window may lie past the slab)
+        st64(dnew, off + (unsigned)(i * colb), 0);
+      }
       cg = g; csp = sp; cw = wm; cq = qm;
       // carry t and the running sums to the next panel (lane 15 of the row holds the block's totals)
       Tb = mov_bcast<WPB - 1>(Tj1);
