@@ -2452,7 +2452,7 @@ int window_push_impl(cgp_ctx *c, int T, const double *dxs, const double *dys, in
   // through the single-tick kernel.  Origin and size of the windows are deterministic and identical for every window of
   // the context, so the host mirrors them instead of reading them back.
   const size_t lds1 = (size_t)(3 * a.N + 8 * WPB + MAXD + 8 + 2 * WIN_STG) * sizeof(double);
-  const size_t lds2 = (size_t)(6 * ((a.N + 3) & ~1) + 8 * WPB + 2 * MAXD + 16) * sizeof(double);   // per window
+  const size_t lds2 = (size_t)(6 * ((a.N + 3) & ~1) + 16 * WPB + 2 * MAXD + 16) * sizeof(double);   // per window
   // windows per workgroup of the paired kernel (rows of wave 0 per window: 4 / wpw)
   // measured (tools/r3_winpack.sh, N = 512): 1024 windows 2.20 / 2.65 / 2.03 M ticks/s at 1 / 2 / 4 per workgroup, 512 windows
   // 2.18 / 1.81 / 1.20 -- two per workgroup once that still leaves two workgroups per CU, four never

@@ -245,10 +245,10 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? WIN_OCC : 1) void k_window_ticks(
       double nw[WPB - 1];
       static_for<0, WPB - 1>([&](auto kc) {
         constexpr int K = WPB - 2 - decltype(kc)::value;   // 14 .. 0
-        fmac_bcast<K, false>(acc, wm, a[K]);
+        fmac_bcast<K, K == WPB - 2>(acc, wm, a[K]);
         nw[K] = 0.0;
-        fmac_bcast<K, false>(nw[K], g, a[K]);
-        fmac_bcast<K, false>(nw[K], sp, acc);
+        fmac_bcast<K, K == WPB - 2>(nw[K], g, a[K]);
+        fmac_bcast<K, K == WPB - 2>(nw[K], sp, acc);
       });
       if (lane < nb) {
 #pragma unroll
@@ -305,10 +305,10 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? WIN_OCC : 1) void k_window_ticks(
       static_for<0, WPB>([&](auto jc) {
         constexpr int J = decltype(jc)::value;
         double out = 0.0;
-        fmac_bcast<J, false>(out, cg, a[J]);
-        fmac_bcast<J, false>(out, csp, u);
-        fnmac_bcast<J, false>(u, cw, a[J]);
-        fnmac_bcast<J, false>(k, cq, a[J]);
+        fmac_bcast<J, J == 0>(out, cg, a[J]);
+        fmac_bcast<J, J == 0>(out, csp, u);
+        fnmac_bcast<J, J == 0>(u, cw, a[J]);
+        fnmac_bcast<J, J == 0>(k, cq, a[J]);
         a[J] = out;
       });
     };
@@ -472,14 +472,14 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int N = p.N, CAP = p.CAP, d = p.d, kid = p.kernel_id;
   const int NS = (N + 2 + 1) & ~1;                       // per-vector LDS stride (rows 0 .. m + 1)
-  const int WS = 6 * NS + 8 * WPB + 2 * MAXD + 16;       // LDS doubles per window
+  const int WS = 6 * NS + 16 * WPB + 2 * MAXD + 16;      // LDS doubles per window
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4;
   const int wl0 = (g * WPW) >> 2;                        // wave 0: the window this lane's row serves
   const bool lead = (g & (4 / WPW - 1)) == 0;            // first row of its window (the others hold copies)
   double *lds = reinterpret_cast<double *>(smem_raw);
-  // per-window LDS blocks: vv1 kk1 ll1 vv2 kk2 ll2 [NS each] | cs1 cs2 [2][2 WPB] | xn [2][MAXD] | red [16]
+  // per-window LDS blocks: vv1 kk1 ll1 vv2 kk2 ll2 [NS each] | cs1 cs2 [2][WPB][4] (c, s', w, q per column) | xn [2][MAXD] | red [16]
   auto blk = [&](int wl) { return lds + wl * WS; };
   const int w0 = blockIdx.x * WPW;
   const size_t LWs = (size_t)CAP * CAP;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
   const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
   // wave 0: this lane's window
   double *vv1 = blk(wl0), *kk1 = vv1 + NS, *ll1 = kk1 + NS, *vv2 = ll1 + NS, *kk2 = vv2 + NS, *ll2 = kk2 + NS;
-  double *cs1 = ll2 + NS, *cs2 = cs1 + 4 * WPB, *xn = cs2 + 4 * WPB, *red = xn + 2 * MAXD;
+  double *cs1 = ll2 + NS, *cs2 = cs1 + 8 * WPB, *xn = cs2 + 8 * WPB, *red = xn + 2 * MAXD;
   double *z = p.z + (size_t)(w0 + wl0) * CAP;
   const double *pr = p.prep + (size_t)(w0 + wl0) * PREP_N;
   const double noise = p.theta[(size_t)(w0 + wl0) * MAX_THETA + nth - 1];
@@ -522,13 +522,13 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
     const int o1 = o + 1;
     if (tid < 2 * d * WPW) {
       const int wl = tid / (2 * d), r2 = tid - wl * 2 * d, tk = r2 / d, q = r2 - tk * d;
-      (blk(wl) + 6 * NS + 8 * WPB)[tk * MAXD + q] = p.xs[((size_t)(w0 + wl) * p.T + t + tk) * d + q];
+      (blk(wl) + 6 * NS + 16 * WPB)[tk * MAXD + q] = p.xs[((size_t)(w0 + wl) * p.T + t + tk) * d + q];
     }
     __syncthreads();
     for (int idx = tid; idx < WPW * (m + 1); idx += 256) {
       const int wl = idx / (m + 1), rr = idx - wl * (m + 1);
       double *b = blk(wl);
-      const double *xnw = b + 6 * NS + 8 * WPB, *prw = p.prep + (size_t)(w0 + wl) * PREP_N;
+      const double *xnw = b + 6 * NS + 16 * WPB, *prw = p.prep + (size_t)(w0 + wl) * PREP_N;
       const double *xww = p.xw + (size_t)(w0 + wl) * d * CAP;
       if (rr < m) {
         b[rr] = Lg[wl * LWs + (size_t)o * CAP + o1 + rr];                                      // vv1
@@ -551,70 +551,79 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
 
     // element (row rr, column cc) of the factor, both counted from o1
     auto eoff = [&](int rr, int cc) { return (unsigned)(((o1 + cc) * CAP + o1 + rr) * (int)sizeof(double)); };   // + the window's slab
-    // rotations of one diagonal block (lane = row), branch-free, (c, s) to csb; skip0: step 0 is not part of this tick
-    auto rotate_block = [&](double (&a)[WPB], double &vi, double &zi, double &vz, double &szz, double &idg, double *csb, bool skip0) {
-      static_for<0, WPB>([&](auto jc) {
+    // One tick's work on a diagonal block (lane = row), the substitution form of k_window_ticks: a[] = the block's strictly
+    // lower part (zero elsewhere), dg = the lane's diagonal entry (1 on padded rows), u / k = the rows' residuals of the rank-1
+    // vector and of the incoming point, zi = the rows' z, z0 = the dropped sample's z.  Leaves the new block in a[] / dg, the new
+    // z in zi, the lane's column values (c, s', w, q) in co[], its l in lj, and carries t / the running sums on.
+    auto solve_block = [&](double (&a)[WPB], double &dg, double &u, double &k, double &zi, const double z0, double (&car)[3],
+                           double &sl2, double &slz, double &szz, double (&co)[4], double &lj) {
+      double idg = __builtin_amdgcn_rcp(dg);
+      idg = __builtin_fma(__builtin_fma(-dg, idg, 1.0), idg, idg);
+      idg = __builtin_fma(__builtin_fma(-dg, idg, 1.0), idg, idg);
+      static_for<0, WPB - 1>([&](auto jc) {
         constexpr int J = decltype(jc)::value;
-        if (J == 0 && skip0) {
-          csb[0] = 1.0;
-          csb[WPB] = 0.0;
-        } else {
-          const double ljj = mov_bcast<J>(a[J]), vj = mov_bcast<J>(vi), zj = mov_bcast<J>(zi);
-          const double r2 = __builtin_fma(vj, vj, ljj * ljj);
-          const double ri = rsqrt3(r2);
-          const double c = ljj * ri, sn = vj * ri;
-          const double aj = a[J];
-          a[J] = __builtin_fma(sn, vi, c * aj);
-          vi = __builtin_fma(c, vi, -(sn * aj));
-          const bool me = i == J;
-          idg = me ? ri : idg;
-          const double zn = __builtin_fma(sn, vz, c * zj);
-          vz = __builtin_fma(c, vz, -(sn * zj));
-          zi = me ? zn : zi;
-          szz += zn * zn;
-          csb[J] = c;
-          csb[WPB + J] = sn;
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        const double wv = u * idg, qv = k * idg;
+        fnmac_bcast<J, true>(u, wv, a[J]);
+        fnmac_bcast<J, true>(k, qv, a[J]);
       });
-    };
-    // forward substitution of the incoming point inside the block; lane q keeps l_q
-    auto substitute_block = [&](const double (&a)[WPB], double &ki, const double &zi, const double &idg, double &sl2, double &slz, double &mine) {
-      static_for<0, WPB>([&](auto qc) {
-        constexpr int Q = decltype(qc)::value;
-        const double lq = mov_bcast<Q>(ki * idg);
-        ki = __builtin_fma(-a[Q], lq, ki);
-        sl2 = __builtin_fma(lq, lq, sl2);
-        fmac_bcast<Q, true>(slz, zi, lq);
-        mine = (i == Q) ? lq : mine;
-        __builtin_amdgcn_sched_barrier(0);
+      const double wm = u * idg, qm = k * idg;
+      const double qy = __builtin_fma(wm, z0, zi);
+      const double w2 = wm * wm;
+      const double Tj = car[0] + win_row_scan_excl(w2), Tj1 = Tj + w2;
+      const double Sk = car[1] + win_row_scan_excl(wm * qm), Sy = car[2] + win_row_scan_excl(wm * qy);
+      const double rj = rsqrt3(Tj), rj1 = rsqrt3(Tj1);
+      const double g = Tj * rj * rj1;
+      const double h = wm * (rj * rj);
+      const double sp = h * g;
+      lj = __builtin_fma(-h, Sk, qm) * g;
+      const double zn = __builtin_fma(-h, Sy, qy) * g;
+      sl2 = __builtin_fma(lj, lj, sl2);
+      slz = __builtin_fma(lj, zn, slz);
+      szz = __builtin_fma(zn, zn, szz);
+      double acc = dg * wm;
+      dg = dg * (Tj1 * rj1 * rj);
+      zi = zn;
+      static_for<0, WPB - 1>([&](auto kc) {
+        constexpr int K = WPB - 2 - decltype(kc)::value;   // 14 .. 0
+        fmac_bcast<K, K == WPB - 2>(acc, wm, a[K]);
+        double nw = 0.0;
+        fmac_bcast<K, K == WPB - 2>(nw, g, a[K]);
+        fmac_bcast<K, K == WPB - 2>(nw, sp, acc);
+        a[K] = (K < i) ? nw : 0.0;
       });
+      co[0] = g; co[1] = sp; co[2] = wm; co[3] = qm;
+      car[0] = mov_bcast<WPB - 1>(Tj1);
+      car[1] = mov_bcast<WPB - 1>(__builtin_fma(wm, qm, Sk));
+      car[2] = mov_bcast<WPB - 1>(__builtin_fma(wm, qy, Sy));
     };
-    auto diag_product = [&](const double (&a)[WPB], double &pm, int &pe) {
-      double dg = 1.0;
-#pragma unroll
-      for (int j = 0; j < WPB; ++j) dg = (i == j) ? a[j] : dg;
-      pm *= dg;
-      pe += __builtin_amdgcn_frexp_exp(pm);
-      pm = __builtin_amdgcn_frexp_mant(pm);
-    };
-    // one row of the sweep with one tick's rotations
-    auto sweep_row = [&](double (&a)[WPB], double &v, double &k, const double *csb, const double *lp) {
+    // one row of the sweep with one tick's columns (c, s', w, q from LDS)
+    auto sweep_row = [&](double (&a)[WPB], double &u, double &k, const double *csb) {
 #pragma unroll
       for (int j = 0; j < WPB; ++j) {
-        const double c = csb[j], sn = csb[WPB + j], aj = a[j];
-        const double tv = __builtin_fma(sn, v, c * aj);
-        v = __builtin_fma(c, v, -(sn * aj));
-        a[j] = tv;
-        k = __builtin_fma(-tv, lp[j], k);
+        const double c = csb[4 * j], sp = csb[4 * j + 1], wj = csb[4 * j + 2], qj = csb[4 * j + 3], aj = a[j];
+        a[j] = __builtin_fma(sp, u, c * aj);
+        u = __builtin_fma(-aj, wj, u);
+        k = __builtin_fma(-aj, qj, k);
       }
+    };
+    // wave 0's own rows: the columns' values are in its registers (lane j of the row: column j), four DPP instructions per column
+    auto sweep_row_w0 = [&](double (&a)[WPB], double &u, double &k, const double (&co)[4]) {
+      static_for<0, WPB>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        double out = 0.0;
+        fmac_bcast<J, J == 0>(out, co[0], a[J]);
+        fmac_bcast<J, J == 0>(out, co[1], u);
+        fnmac_bcast<J, J == 0>(u, co[2], a[J]);
+        fnmac_bcast<J, J == 0>(k, co[3], a[J]);
+        a[J] = out;
+      });
     };
     // a row below the diagonal block of panel pi through both ticks: tick t (rows < m), then tick t + 1
     auto both_ticks = [&](double (&a)[WPB], int rr, int pi, double &v1, double &k1, double &v2, double &k2, const double *b) {
-      const int p0 = pi * WPB, cso = (pi & 1) * 2 * WPB;
-      if (rr < m) sweep_row(a, v1, k1, b + 6 * NS + cso, b + 2 * NS + p0);                 // cs1, ll1
+      const int cso = (pi & 1) * 4 * WPB;
+      if (rr < m) sweep_row(a, v1, k1, b + 6 * NS + cso);                 // cs1
       if (pi == 0) v2 = a[0];   // column 0 after tick t: this row's entry of tick t + 1's rank-1 vector
-      sweep_row(a, v2, k2, b + 6 * NS + 4 * WPB + cso, b + 5 * NS + p0);                   // cs2, ll2
+      sweep_row(a, v2, k2, b + 6 * NS + 8 * WPB + cso);                   // cs2
     };
     // the 16 panel entries of row rr: memory, or -- tick t's new row m, which exists only as l1 so far -- LDS
     auto load_row = [&](double (&a)[WPB], int rr, int p0, bool live, unsigned wo, const double *b) {
@@ -626,35 +635,50 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
       }
     };
 
-    // ---- wave 0 state: the diagonal block's rows of v, k, z for both ticks (registers across panels)
+    // ---- wave 0 state: the diagonal block's rows of u, k, z for both ticks (registers across panels)
     double v1i = 0, k1i = 0, v2i = 0, k2i = 0, zi = 0;
-    auto block_ab = [&](int pi, double (&a)[WPB]) {   // A1 then A2 on the diagonal block of panel pi (a[], zi, v1i .. k2i loaded)
+    double car1[3] = {1.0, 0.0, 0.0}, car2[3] = {1.0, 0.0, 0.0};   // t, sum w q, sum w qy up to the panel, per tick
+    double co1[4] = {1.0, 0.0, 0.0, 0.0}, co2[4] = {1.0, 0.0, 0.0, 0.0};   // lane j: c, s', w, q of column j of the panel solved last
+    auto row_sum = [&](double x) {   // over the 16 lanes of a row
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off);
+      return x;
+    };
+    auto block_ab = [&](int pi, double (&a)[WPB], double dg) {   // A1 then A2 on the diagonal block of panel pi (a[], dg, zi, v1i .. k2i loaded)
       const int p0 = pi * WPB;
       const int nb1 = max(0, min(WPB, m - p0));        // rows / columns of tick t in this block
       const int nb2 = min(WPB, m + 1 - p0);            // of tick t + 1 (the block's last row may be row m)
-      double *c1 = cs1 + (pi & 1) * 2 * WPB, *c2 = cs2 + (pi & 1) * 2 * WPB;
+      double *c1 = cs1 + (pi & 1) * 4 * WPB, *c2 = cs2 + (pi & 1) * 4 * WPB;
       // ---- A1
       {
-        double idg = 1.0, mine = 0.0;
-        rotate_block(a, v1i, zi, vz1, szza, idg, c1, false);
-        if (lead && i < nb1) diag_product(a, pma, pea);
-        substitute_block(a, k1i, zi, idg, sl2a, slza, mine);
-        if (lead && i < nb1) ll1[p0 + i] = mine;
+        double lj;
+        solve_block(a, dg, v1i, k1i, zi, vz1, car1, sl2a, slza, szza, co1, lj);
+        if (lead) {
+          c1[4 * i + 0] = co1[0]; c1[4 * i + 1] = co1[1]; c1[4 * i + 2] = co1[2]; c1[4 * i + 3] = co1[3];
+          if (i < nb1) {
+            pma *= dg;
+            pea += __builtin_amdgcn_frexp_exp(pma);
+            pma = __builtin_amdgcn_frexp_mant(pma);
+            ll1[p0 + i] = lj;
+          }
+        }
       }
       if (p0 + WPB > m) {
         // the last panel: tick t's new row m = (l1, d1) joins the block as row m - p0, with its z
         const double kss1 = (kid == K_RBF_BROWNIAN) ? pr[9] * pr[10] * fabs(xn[0]) : pr[9];
-        double dd = kss1 + noise + 1e-8 - sl2a;
+        const double s2 = row_sum(sl2a), sz = row_sum(slza);
+        double dd = kss1 + noise + 1e-8 - s2;
         if (!(dd > 0.0)) {
           bad1 = t + 1;
           dd = 1e-300;
         }
         d1 = sqrt(dd);
-        znew1 = (p.ys[(size_t)(w0 + wl0) * p.T + t] - slza) / d1;
+        znew1 = (p.ys[(size_t)(w0 + wl0) * p.T + t] - sz) / d1;
         const int im = m - p0;
         if (i == im) {
 #pragma unroll
-          for (int j = 0; j < WPB; ++j) a[j] = j < im ? ll1[p0 + j] : (j == im ? d1 : 0.0);
+          for (int j = 0; j < WPB; ++j) a[j] = j < im ? ll1[p0 + j] : 0.0;
+          dg = d1;
           zi = znew1;
         }
       }
@@ -666,35 +690,49 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
           v2i = i == 0 ? 0.0 : a[0];        // column 0 after tick t; row 0 itself is inert from here on
           zi = i == 0 ? 0.0 : zi;
           k2i = i == 0 ? 0.0 : k2i;
+          dg = i == 0 ? 1.0 : dg;
+          a[0] = 0.0;                       // column 0 is not part of tick t + 1
         }
-        double idg = 1.0, mine = 0.0;
-        rotate_block(a, v2i, zi, vz2, szzb, idg, c2, first);
-        if (lead && i < nb2 && !(first && i == 0)) diag_product(a, pmb, peb);
-        substitute_block(a, k2i, zi, idg, sl2b, slzb, mine);
-        if (lead && i < nb2) ll2[p0 + i] = (first && i == 0) ? 0.0 : mine;
+        double lj;
+        solve_block(a, dg, v2i, k2i, zi, vz2, car2, sl2b, slzb, szzb, co2, lj);
+        if (lead) {
+          c2[4 * i + 0] = co2[0]; c2[4 * i + 1] = co2[1]; c2[4 * i + 2] = co2[2]; c2[4 * i + 3] = co2[3];
+          if (i < nb2) {
+            if (!(first && i == 0)) {
+              pmb *= dg;
+              peb += __builtin_amdgcn_frexp_exp(pmb);
+              pmb = __builtin_amdgcn_frexp_mant(pmb);
+            }
+            ll2[p0 + i] = (first && i == 0) ? 0.0 : lj;
+          }
+        }
       }
       if (lead && i < nb2) {
+        // columns right of the diagonal hold zeros: they land in the strict upper triangle of the slab, which nothing reads
         const unsigned off = woff + eoff(p0 + i, p0);
 #pragma unroll
-        for (int j = 0; j < WPB; ++j)
-          if (j <= i && j < nb2) st64(a[j], off, j * colb);
+        for (int j = 0; j < WPB - 1; ++j)
+          if (j < nb2) st64(a[j], off, j * colb);
+        st64(dg, off + (unsigned)(i * colb), 0);
         z[o1 + p0 + i] = zi;
       }
     };
 
     if (wave == 0) {
-      double ad[WPB];
+      double ad[WPB], dg;
       {
         const int nb = min(WPB, m + 1);
         const unsigned off = woff + eoff(i, 0);
+        const bool in = i < nb && i < m;
 #pragma unroll
-        for (int j = 0; j < WPB; ++j) ad[j] = (j <= i && i < nb && j < nb && i < m) ? ld64(off, j * colb) : (i == j ? 1.0 : 0.0);
-        zi = (i < nb && i < m) ? z[o1 + i] : 0.0;
+        for (int j = 0; j < WPB; ++j) ad[j] = (j < i && in) ? ld64(off, j * colb) : 0.0;
+        dg = in ? ld64(off + (unsigned)(i * colb), 0) : 1.0;
+        zi = in ? z[o1 + i] : 0.0;
         v1i = i < nb ? vv1[i] : 0.0;
         k1i = i < nb ? kk1[i] : 0.0;
         k2i = i < nb ? kk2[i] : 0.0;
       }
-      block_ab(0, ad);
+      block_ab(0, ad, dg);
     }
     for (int pi = 0; pi < npan; ++pi) {
       lds_barrier();  // A1 / A2 of panel pi and the sweep of panel pi - 1 are complete
@@ -704,32 +742,48 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
           // the rows of the next diagonal block through panel pi, then A1 / A2 of panel pi + 1
           const int nbn = min(WPB, m + 1 - (p0 + WPB));   // rows of the next block (row m may be its last)
           const int rr = p0 + WPB + i;
-          const bool live = i < nbn;
-          double ad[WPB];
+          const bool live = i < nbn, old = live && rr < m;   // old: a row of the factor (not tick t's new row)
+          double ad[WPB], dg;
           {
-            const unsigned off = woff + eoff(live && rr < m ? rr : 0, p0 + WPB);
+            const unsigned off = woff + eoff(old ? rr : 0, p0 + WPB);
 #pragma unroll
             for (int j = 0; j < WPB; ++j) {
               const double x = ld64(off, j * colb);
-              ad[j] = (j <= i && live && rr < m && p0 + WPB + j < m) ? x : (i == j ? 1.0 : 0.0);
+              ad[j] = (j < i && old) ? x : 0.0;
+            }
+            const double xd = ld64(woff + eoff(old ? rr : 0, old ? rr : 0), 0);
+            dg = old ? xd : 1.0;
+          }
+          const double zn = old ? z[o1 + rr] : 0.0;
+          double a[WPB];
+          {
+            const unsigned off = woff + eoff(old ? rr : 0, p0);
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) {
+              const double x = ld64(off, j * colb);
+              a[j] = old ? x : 0.0;
             }
           }
-          const double zn = (live && rr < m) ? z[o1 + rr] : 0.0;
-          double a[WPB];
-          load_row(a, rr, p0, live, woff, blk(wl0));
-          v1i = (live && rr < m) ? vv1[rr] : 0.0;
-          k1i = (live && rr < m) ? kk1[rr] : 0.0;
+          v1i = old ? vv1[rr] : 0.0;
+          k1i = old ? kk1[rr] : 0.0;
           v2i = (live && pi > 0) ? vv2[rr] : 0.0;
           k2i = live ? kk2[rr] : 0.0;
-          both_ticks(a, rr, pi, v1i, k1i, v2i, k2i, blk(wl0));
-          if (!live) v2i = 0.0;
+          // every lane takes both sweeps (the DPP reads need the whole row active): rows past the factor carry zeros through tick
+          // t; tick t's new row m, which exists only as l1 so far, gets its entries from LDS between the two
+          sweep_row_w0(a, v1i, k1i, co1);
+          if (p0 + 2 * WPB > m) {
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) a[j] = (live && rr == m) ? ll1[p0 + j] : a[j];
+          }
+          if (pi == 0) v2i = live ? a[0] : 0.0;
+          sweep_row_w0(a, v2i, k2i, co2);
           if (lead && i < nbn) {
             const unsigned off = woff + eoff(rr, p0);
 #pragma unroll
             for (int j = 0; j < WPB; ++j) st64(a[j], off, j * colb);
           }
           zi = zn;
-          block_ab(pi + 1, ad);
+          block_ab(pi + 1, ad, dg);
         }
       } else {
         const int R = m + 1 - (p0 + 2 * WPB);   // rows per window below the next diagonal block (may be <= 0)
@@ -763,6 +817,8 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
         la += __shfl_xor(la, off);
         lb += __shfl_xor(lb, off);
       }
+      sl2a = row_sum(sl2a); slza = row_sum(slza); szza = row_sum(szza);   // per-lane partial sums over the panels
+      sl2b = row_sum(sl2b); slzb = row_sum(slzb); szzb = row_sum(szzb);
       if (lead && i == 0) {
         red[0] = sl2a; red[1] = slza; red[2] = la; red[3] = szza; red[4] = d1; red[5] = znew1; red[6] = (double)bad1;
         red[8] = sl2b; red[9] = slzb; red[10] = lb; red[11] = szzb;
@@ -776,7 +832,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
     if (tid < WPW) {
       const int wl = tid, w = w0 + wl;
       double *b = blk(wl);
-      const double *xn = b + 6 * NS + 8 * WPB, *red = xn + 2 * MAXD;
+      const double *xn = b + 6 * NS + 16 * WPB, *red = xn + 2 * MAXD;
       const double *pr = p.prep + (size_t)w * PREP_N;
       const double noise = p.theta[(size_t)w * MAX_THETA + nth - 1];
       double *L = Lg + wl * LWs, *z = p.z + (size_t)w * CAP, *yw = p.yw + (size_t)w * CAP, *xw = p.xw + (size_t)w * d * CAP;
