@@ -248,6 +248,7 @@ constexpr size_t kOptPinIn = CGP_MAX_THETA + 8;   // doubles at the head of the 
 constexpr bool kWinPairs = CGP_WIN_PAIRS != 0;
 constexpr size_t kWinZeroCopyBytes = 16 * 1024;   // cgp_window_push blocks up to this size are read / written in pinned host memory by the kernels
 constexpr int kWinPackLds = 72 * 1024;       // pack windows into a workgroup only while two workgroups still fit a CU's LDS ...
+constexpr size_t kWinPairStage = 3 * WPB * 64 * sizeof(double);   // k_window_pairs: the three sweep waves' staged trips (24 KB)
 constexpr int kWinPackMinGroups = 512;
 constexpr int kWinWideMax = 256;            // single-tick kernel: up to this many windows 512 threads per window       // ... and the chip still gets two workgroups per CU
 // fp64 mid-size calls put their extra rows on a second stream when there is enough of them: fits x block steps >= this
@@ -2374,7 +2375,10 @@ extern "C" int cgp_window_init(cgp_ctx *c, int nwin, int N, int d, int kid, cons
     }
   };
   drop();
-  const int CAP = 2 * N;
+#ifndef CGP_WIN_CAP_PAD
+#define CGP_WIN_CAP_PAD 0
+#endif
+  const int CAP = 2 * N + CGP_WIN_CAP_PAD;   // ring capacity = leading dimension of the windows' slabs
   const size_t W = nwin;
   size_t sizes[6] = {W * CAP * CAP * 8, W * CAP * 8, W * d * CAP * 8, W * CAP * 8, W * 4 * sizeof(int),
                      W * (PREP_N + MAX_THETA) * 8};
@@ -2457,11 +2461,11 @@ int window_push_impl(cgp_ctx *c, int T, const double *dxs, const double *dys, in
   // measured (tools/r3_winpack.sh, N = 512): 1024 windows 2.20 / 2.65 / 2.03 M ticks/s at 1 / 2 / 4 per workgroup, 512 windows
   // 2.18 / 1.81 / 1.20 -- two per workgroup once that still leaves two workgroups per CU, four never
   int wpw = 1;
-  if (c->nwin % 2 == 0 && 2 * lds2 <= (size_t)kWinPackLds && c->nwin / 2 >= kWinPackMinGroups) wpw = 2;
+  if (c->nwin % 2 == 0 && 2 * lds2 + kWinPairStage <= (size_t)kWinPackLds + 8 * 1024 && c->nwin / 2 >= kWinPackMinGroups) wpw = 2;
   if constexpr (kAbBuild) {
     const char *e = getenv("CGP_WIN_WPW");
     const int v = e ? atoi(e) : 0;
-    if ((v == 1 || v == 2 || v == 4) && c->nwin % v == 0 && v * lds2 <= 150 * 1024) wpw = v;
+    if ((v == 1 || v == 2 || v == 4) && c->nwin % v == 0 && v * lds2 + kWinPairStage <= 150 * 1024) wpw = v;
   }
   const int N = a.N, CAP = a.CAP;
   if (c->win_o < 0) {   // the mirror was invalidated by a failed push: read the windows' state back (they advance in lock-step)
@@ -2485,9 +2489,9 @@ int window_push_impl(cgp_ctx *c, int T, const double *dxs, const double *dys, in
     for (int oo = o; pair_ok(oo, n, T - t - 2 * np); oo += 2) ++np;
     if (np > 0) {
       a.nt = 2 * np;
-      if (wpw == 4) hipLaunchKernelGGL(k_window_pairs<4>, dim3(c->nwin / 4), dim3(256), 4 * lds2, ws, a);
-      else if (wpw == 2) hipLaunchKernelGGL(k_window_pairs<2>, dim3(c->nwin / 2), dim3(256), 2 * lds2, ws, a);
-      else hipLaunchKernelGGL(k_window_pairs<1>, dim3(c->nwin), dim3(256), lds2, ws, a);
+      if (wpw == 4) hipLaunchKernelGGL(k_window_pairs<4>, dim3(c->nwin / 4), dim3(256), 4 * lds2 + kWinPairStage, ws, a);
+      else if (wpw == 2) hipLaunchKernelGGL(k_window_pairs<2>, dim3(c->nwin / 2), dim3(256), 2 * lds2 + kWinPairStage, ws, a);
+      else hipLaunchKernelGGL(k_window_pairs<1>, dim3(c->nwin), dim3(256), lds2 + kWinPairStage, ws, a);
       o += 2 * np;
       t += 2 * np;
       continue;

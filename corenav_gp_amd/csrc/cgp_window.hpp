@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
   double *lds = reinterpret_cast<double *>(smem_raw);
   // per-window LDS blocks: vv1 kk1 ll1 vv2 kk2 ll2 [NS each] | cs1 cs2 [2][WPB][4] (c, s', w, q per column) | xn [2][MAXD] | red [16]
   auto blk = [&](int wl) { return lds + wl * WS; };
+  double *stg = lds + WPW * WS + (wave > 0 ? wave - 1 : 0) * (WPB * 64);   // sweep waves: the next trip's 64 rows x 16 columns, staged by LDS-DMA
   const int w0 = blockIdx.x * WPW;
   const size_t LWs = (size_t)CAP * CAP;
   double *Lg = p.L + (size_t)w0 * LWs;
@@ -718,6 +719,37 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
       }
     };
 
+    // sweep waves: trips of a panel (wave-uniform), the (window, row) of a trip's slot, and the request of a trip's entries
+    auto trips_of = [&](int pi) {
+      const int tot = WPW * (m + 1 - (pi * WPB + 2 * WPB)) - (wave - 1) * 64;
+      return tot > 0 ? (tot + 191) / 192 : 0;
+    };
+    auto slot_row = [&](int pi, int n, int r, int &wl, int &rr, bool &ok) {
+      const int R = m + 1 - (pi * WPB + 2 * WPB);
+      const int idx = (wave - 1) * 64 + r + 192 * n;
+      ok = idx < WPW * R;
+      wl = (WPW == 1 || !ok) ? 0 : idx / R;
+      rr = pi * WPB + 2 * WPB + (ok ? idx - wl * R : 0);   // a slot past the rows: any row of the slab (never used)
+    };
+    auto issue_stage = [&](int pi, int n) {
+      typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {   // lane l: dword l & 1 of row slot 32 h + (l >> 1)
+        int wl, rr;
+        bool ok;
+        slot_row(pi, n, 32 * h + (lane >> 1), wl, rr, ok);
+        const unsigned vo = (unsigned)(wl * (int)(LWs * sizeof(double))) + eoff(rr, pi * WPB) + 4u * (lane & 1);
+#pragma unroll
+        for (int c = 0; c < WPB; ++c)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(stg + c * 64 + 32 * h), 4, vo, c * colb, 0, 0);
+      }
+    };
+    bool first_trip = true;
+    if (wave > 0) {
+      int pi0 = 0;
+      while (pi0 < npan && trips_of(pi0) == 0) ++pi0;
+      if (pi0 < npan) issue_stage(pi0, 0);
+    }
     if (wave == 0) {
       double ad[WPB], dg;
       {
@@ -786,24 +818,48 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
           block_ab(pi + 1, ad, dg);
         }
       } else {
-        const int R = m + 1 - (p0 + 2 * WPB);   // rows per window below the next diagonal block (may be <= 0)
-        for (int idx = tid - 64; idx < WPW * R; idx += 192) {
-          asm volatile("" ::: "memory");
-          const int wl = WPW == 1 ? 0 : idx / R;
-          const int rr = p0 + 2 * WPB + (idx - wl * R);
+        // ---- the rows below the next diagonal block, three waves.  A trip = 64 rows x the panel's 16 columns per wave.  Its entries
+        // were requested ONE TRIP AGO, in front of that trip's stores, straight into LDS (dword LDS-DMA through the buffer descriptor:
+        // the rows are only 8-byte aligned): vmcnt counts loads and stores in one sequence, so a load issued after a trip's stores
+        // could only be waited for together with them -- the store round trip on every trip's path (measured: 3.2 M ticks/s without
+        // the arithmetic, 4.8 M without the stores).  Requested first, the wait leaves exactly the sixteen stores outstanding.
+        const int nt = trips_of(pi);
+        for (int n = 0; n < nt; ++n) {
+          if (first_trip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          first_trip = false;
+          int wl, rr;
+          bool ok;
+          slot_row(pi, n, lane, wl, rr, ok);
           double *b = blk(wl);
           const unsigned wo = (unsigned)(wl * (int)(LWs * sizeof(double)));
           double a[WPB];
-          load_row(a, rr, p0, true, wo, b);
-          double v1 = b[rr], k1 = b[NS + rr], v2 = pi > 0 ? b[3 * NS + rr] : 0.0, k2 = b[4 * NS + rr];
-          both_ticks(a, rr, pi, v1, k1, v2, k2, b);
-          const unsigned off = wo + eoff(rr, p0);
 #pragma unroll
-          for (int j = 0; j < WPB; ++j) st64(a[j], off, j * colb);
-          b[rr] = v1;
-          b[NS + rr] = k1;
-          b[3 * NS + rr] = v2;
-          b[4 * NS + rr] = k2;
+          for (int j = 0; j < WPB; ++j) a[j] = stg[j * 64 + lane];
+          if (rr == m) {   // tick t's new row exists only as l1 so far
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) a[j] = b[2 * NS + p0 + j];
+          }
+          double v1 = b[rr], k1 = b[NS + rr], v2 = pi > 0 ? b[3 * NS + rr] : 0.0, k2 = b[4 * NS + rr];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage has been read: the next trip may land in it
+          {
+            int npi = pi, nn = n + 1;
+            if (nn >= nt) {
+              nn = 0;
+              do ++npi; while (npi < npan && trips_of(npi) == 0);
+            }
+            if (npi < npan) issue_stage(npi, nn);
+          }
+          if (ok) {
+            both_ticks(a, rr, pi, v1, k1, v2, k2, b);
+            const unsigned off = wo + eoff(rr, p0);
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) st64(a[j], off, j * colb);
+            b[rr] = v1;
+            b[NS + rr] = k1;
+            b[3 * NS + rr] = v2;
+            b[4 * NS + rr] = k2;
+          }
         }
       }
     }
