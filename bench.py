@@ -843,15 +843,15 @@ def window_line(engine, torch, dev, local, W=1024, N=512, d=3, T=200):
     for i in range(5, 5 + nt):
         c1.window_push(X[:1, N + i:N + i + 1], y[:1, N + i:N + i + 1])
     host_tick_us = (time.perf_counter() - t1) / nt * 1e6
-    # counter traffic of the same command (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, profiles/r05_window_pmc_summary.json): 275.9 GB for
-    # 430 GB algorithmic -- the HBM pipe itself is at 0.64 of the algorithmic fraction
-    kCounterOverAlgorithmic = 275.9 / 429.5
+    # counter traffic of the same command (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, profiles/r06_window_pmc_summary.json, the round's final
+    # kernels): 2 x 6.309e7 KB fetched + 1.186e8 KB written = 250.7 GB for the 429.5 GB algorithmic of 200 ticks x 1024 windows
+    kCounterOverAlgorithmic = 250.7 / 429.5
     return {"window_ticks_per_s": W * T / el, "window_hbm_frac": gbps / HBM_PEAK_GBPS,
             "window_hbm_frac_counter_traffic_projected": gbps / HBM_PEAK_GBPS * kCounterOverAlgorithmic, "window_host_tick_us": host_tick_us,
-            "window_counter_over_algorithmic": {"ratio": kCounterOverAlgorithmic, "from": "profiles/r05_window_pmc_summary.json (commit 1910133's kernels: "
-                                                "unchanged since), NOT measured in this run"},
+            "window_counter_over_algorithmic": {"ratio": kCounterOverAlgorithmic, "from": "profiles/r06_window_pmc_summary.json (the final round-6 "
+                                                "window kernels), NOT measured in this run"},
             "window_traffic_note": "window_hbm_frac = ALGORITHMIC bytes per tick (factor read + written once) x ticks/s / 8 TB/s, measured in this run; the "
-                                   "kernel takes steady-state ticks two per pass, so the traffic the PMC counters saw is 0.64 of that: "
+                                   "kernel takes steady-state ticks two per pass, so the traffic the PMC counters saw is 0.58 of that: "
                                    "window_hbm_frac_counter_traffic_projected = this run's rate x that committed ratio, a projection (tools/pmc_window.sh "
                                    "re-measures the ratio)",
             "window_workload": f"BASELINE configs[3]: {W} windows x N={N} d={d} fp64, {T} ticks, algorithmic {gbps:.0f} GB/s of {HBM_PEAK_GBPS:.0f}"}

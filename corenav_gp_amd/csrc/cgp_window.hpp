@@ -5,18 +5,21 @@
 //
 // One workgroup owns one window and walks a whole block of ticks inside ONE launch (state lives in
 // HBM: no per-tick launch, no host round trip).  Per tick, with the window [x_0 .. x_{n-1}]:
-//   drop x_0 :  Ky = [[a, b'],[b, C]] = L L'  ->  chol(C) = chol(L22 L22' + l21 l21')   rank-1 UPDATE
-//               by Givens-like rotations (c_j, s_j) column by column; z = L^-1 y rides along as one
-//               more row.
+//   drop x_0 :  Ky = [[a, b'],[b, C]] = L L'  ->  chol(C) = chol(L22 L22' + l21 l21')   rank-1 UPDATE;
+//               z = L^-1 y is updated with it.
 //   add x_new:  l = L^-1 k(X, x_new) (forward substitution), d = sqrt(k** + noise - |l|^2),
 //               z_new = (y_new - l'z)/d.  l'z and k** - |l|^2 are also the one-step-ahead
 //               predictive mean / variance of y_new BEFORE it is added, so they are the tick's output.
+// Since the end of round 6 the update is NOT a chain of rotations: with w = L22^-1 l21 and t_j = 1 + sum_{k<=j} w_k^2 the
+// rotation of column j is c_j = sqrt(t_{j-1}/t_j), s_j = w_j/sqrt(t_j), so the only serial work is a forward substitution
+// with the OLD factor -- two right-hand sides, l21 and k(X, x_new) -- and everything else (c, s, the new l and z, the new
+// diagonal block) follows from prefix sums, lane-parallel (k_window_ticks, solve_block of k_window_pairs).
 // Both sweeps are fused into one pass over L in 16-column panels: wave 0 does the sequential part
-// of a panel (16x16 diagonal block in registers, DPP row_newbcast broadcasts), then every thread applies
-// the panel's 16 rotations and the substitution update to its own rows below.  L is read and
-// written exactly once per tick: ~ n^2/2 * 8 B * 2 of HBM/L2 traffic, the bound of this kernel.
+// of a panel (16x16 diagonal block in registers, DPP row_newbcast), then every thread takes the panel's columns
+// (c, s', w, q) into its own rows below.  L is read and written exactly once per tick (once per TWO ticks in
+// k_window_pairs): n^2/2 * 8 B * 2 of HBM traffic per pass, the bound of these kernels.
 // Storage: column-major, capacity 2N x 2N; the window origin slides down the diagonal and is moved
-// back every N ticks.
+// back every N ticks.  The strict upper triangle of the slab is never read (the kernels store zeros / by-products there).
 #pragma once
 #include "cgp_kernels.hpp"
 
