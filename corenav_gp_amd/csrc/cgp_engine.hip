@@ -248,6 +248,11 @@ constexpr size_t kOptPinIn = CGP_MAX_THETA + 8;   // doubles at the head of the 
 constexpr bool kWinPairs = CGP_WIN_PAIRS != 0;
 constexpr size_t kWinZeroCopyBytes = 16 * 1024;   // cgp_window_push blocks up to this size are read / written in pinned host memory by the kernels
 constexpr int kWinPackLds = 72 * 1024;       // pack windows into a workgroup only while two workgroups still fit a CU's LDS ...
+#ifndef CGP_WIN_MULTI
+#define CGP_WIN_MULTI 4   // steady-state ticks per pass over the factor where the window is long enough (k_window_multi); 0 = pairs only
+#endif
+constexpr int kWinMulti = CGP_WIN_MULTI > 2 ? CGP_WIN_MULTI : 4;
+constexpr bool kWinUseMulti = CGP_WIN_MULTI > 2;
 constexpr size_t kWinPairStage = 3 * WPB * 64 * sizeof(double);   // k_window_pairs: the three sweep waves' staged trips (24 KB)
 constexpr int kWinPackMinGroups = 512;
 constexpr int kWinWideMax = 256;            // single-tick kernel: up to this many windows 512 threads per window       // ... and the chip still gets two workgroups per CU
@@ -2362,7 +2367,8 @@ extern "C" int cgp_window_init(cgp_ctx *c, int nwin, int N, int d, int kid, cons
   // the two-ticks-per-pass kernel keeps six window-length vectors in LDS: 98 KB at N = 2048
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_window_pairs<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
       hipFuncSetAttribute(reinterpret_cast<const void *>(&k_window_pairs<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void *>(&k_window_pairs<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&k_window_pairs<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&k_window_multi<kWinMulti>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
     return CGP_EHIP;
   // the old windows are gone from here on: a failure below must leave the context without windows,
   // not with stale pointers (cgp_window_push checks nwin)
@@ -2483,8 +2489,22 @@ int window_push_impl(cgp_ctx *c, int T, const double *dxs, const double *dys, in
     nn = (drop ? nn - 1 : nn) + 1;
   };
   auto pair_ok = [&](int oo, int nn, int left) { return kWinPairs && N >= 2 * WPB && nn == N && left >= 2 && oo + N + 1 < CAP; };
+  const int NSm = (N + kWinMulti + 3) & ~1;
+  const size_t ldsm = (size_t)(3 * kWinMulti * NSm + kWinMulti * (8 * WPB + MAXD + 8)) * sizeof(double) + kWinPairStage;
+  auto multi_ok = [&](int oo, int nn, int left) {
+    return kWinUseMulti && kWinPairs && N >= 4 * WPB && ldsm <= 80 * 1024 && nn == N && left >= kWinMulti && oo + N + kWinMulti - 1 < CAP;
+  };
   for (int t = 0; t < T;) {
     a.t0 = t;
+    int nm = 0;
+    for (int oo = o; multi_ok(oo, n, T - t - kWinMulti * nm); oo += kWinMulti) ++nm;
+    if (nm > 0) {
+      a.nt = kWinMulti * nm;
+      hipLaunchKernelGGL(k_window_multi<kWinMulti>, dim3(c->nwin), dim3(256), ldsm, ws, a);
+      o += kWinMulti * nm;
+      t += kWinMulti * nm;
+      continue;
+    }
     int np = 0;
     for (int oo = o; pair_ok(oo, n, T - t - 2 * np); oo += 2) ++np;
     if (np > 0) {

@@ -938,4 +938,422 @@ __global__ __launch_bounds__(256, WIN_OCC) void k_window_pairs(WindowArgs p) {
   }
 }
 
+// --------------------------------------------------------------------------------------------------
+// k_window_multi<TK>: TK ticks per pass over the factor (TK = 4 ships), the paired kernel's scheme carried on.  With the
+// substitution form a tick's serial part is short (solve_block), the pass is bound by the factor's bytes, and TK ticks read
+// and write them once.  Rows / columns counted from o1 = o + 1, m = N - 1, tick q = 0 .. TK - 1:
+//   drops row q - 1; its rank-1 vector is column q - 1 AFTER ticks < q (tick 0: column -1 from memory); its window is rows and
+//   columns [q, m + q); its new row is m + q = (l_q, d_q).
+// Rows m .. m + TK - 2 are born inside the pass: row m + q exists only as l_q (LDS) until tick q + 1 takes it, is swept by ticks
+// > q only, and is stored like any other row; row m + TK - 1 is written at the end.  In panel 0 lane q - 1 of the diagonal block
+// goes inert before tick q and column q - 1 leaves the block.  One window per workgroup (four lane rows of wave 0 hold copies).
+// --------------------------------------------------------------------------------------------------
+template <int TK>
+__global__ __launch_bounds__(256, WIN_OCC) void k_window_multi(WindowArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int N = p.N, CAP = p.CAP, d = p.d, kid = p.kernel_id;
+  const int NS = (N + TK + 3) & ~1;                       // per-vector LDS stride (rows 0 .. m + TK - 1)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool lead = (lane >> 4) == 0;
+  const int i = lane & (WPB - 1);
+  double *lds = reinterpret_cast<double *>(smem_raw);
+  // LDS: vv[TK] kk[TK] ll[TK] (NS each) | cs[TK][2][WPB][4] | xn[TK][MAXD] | red[TK][8] | the sweep waves' stages 3 x [16][64]
+  double *VV = lds, *KK = VV + TK * NS, *LL = KK + TK * NS, *CS = LL + TK * NS, *XN = CS + TK * 8 * WPB, *RED = XN + TK * MAXD;
+  double *stg = RED + TK * 8 + (wave > 0 ? wave - 1 : 0) * (WPB * 64);
+  const int w = blockIdx.x;
+  double *Lg = p.L + (size_t)w * CAP * CAP;
+  double *z = p.z + (size_t)w * CAP, *xw = p.xw + (size_t)w * d * CAP, *yw = p.yw + (size_t)w * CAP;
+  const double *pr = p.prep + (size_t)w * PREP_N;
+  const int nth = (kid == K_SE_ISO) ? 3 : (kid == K_SE_ARD ? d + 2 : 4);
+  const double noise = p.theta[(size_t)w * MAX_THETA + nth - 1];
+  int o = p.state[w * 4], bad = p.state[w * 4 + 2];
+  // only correct for full windows with room for TK more rows (the host cuts a push from its mirror; see k_window_pairs)
+  if (p.state[w * 4 + 1] != N || o + N + TK - 1 >= CAP) {
+    if (tid == 0 && p.state[w * 4 + 2] == 0) p.state[w * 4 + 2] = -1;
+    if (tid == 0 && p.info_out) p.info_out[w] = p.state[w * 4 + 2];
+    return;
+  }
+  const int m = N - 1;
+  const int nrow = m + TK - 1;                 // rows 0 .. nrow - 1 pass through the sweeps (old rows and the rows born by ticks < TK - 1)
+  const int npan = (nrow + WPB - 1) / WPB;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Lg, 0, (int)((size_t)CAP * CAP * sizeof(double)), 0x00020000);
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  auto ld64 = [&](unsigned off, int soff) {
+    const u2 q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, soff, 0);
+    return __hiloint2double((int)q[1], (int)q[0]);
+  };
+  auto st64 = [&](double x, unsigned off, int soff) {
+    u2 q;
+    q[0] = (unsigned)__double2loint(x);
+    q[1] = (unsigned)__double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(q, rsrc, off, soff, 0);
+  };
+  const int colb = CAP * (int)sizeof(double);
+
+  for (int t = p.t0; t < p.t0 + p.nt; t += TK) {
+    const int o1 = o + 1;
+    if (tid < TK * d) XN[(tid / d) * MAXD + tid % d] = p.xs[((size_t)w * p.T + t + tid / d) * d + tid % d];
+    __syncthreads();
+    for (int rr = tid; rr < nrow; rr += 256) {
+#pragma unroll
+      for (int q = 0; q < TK; ++q) {
+        double kv = 0.0;
+        if (rr < m) kv = win_cov(kid, d, pr, xw + o1 + rr, CAP, XN + q * MAXD, 1, false);
+        else if (rr - m < q) kv = win_cov(kid, d, pr, XN + (rr - m) * MAXD, 1, XN + q * MAXD, 1, false);   // two incoming points
+        KK[q * NS + rr] = kv;
+        VV[q * NS + rr] = (q == 0 && rr < m) ? Lg[(size_t)o * CAP + o1 + rr] : 0.0;
+        LL[q * NS + rr] = 0.0;
+      }
+    }
+    double z0q[TK], uq[TK], kq[TK], car[TK][3], co[TK][4], sl2[TK], slz[TK], szz[TK], pm[TK], dq[TK], znq[TK];
+    int pe[TK], badq = 0;
+#pragma unroll
+    for (int q = 0; q < TK; ++q) {
+      z0q[q] = 0.0; uq[q] = 0.0; kq[q] = 0.0; car[q][0] = 1.0; car[q][1] = 0.0; car[q][2] = 0.0;
+      co[q][0] = 1.0; co[q][1] = 0.0; co[q][2] = 0.0; co[q][3] = 0.0;
+      sl2[q] = 0.0; slz[q] = 0.0; szz[q] = 0.0; pm[q] = 1.0; pe[q] = 0; dq[q] = 1.0; znq[q] = 0.0;
+    }
+    z0q[0] = z[o];
+    __syncthreads();
+
+    auto eoff = [&](int rr, int cc) { return (unsigned)(((o1 + cc) * CAP + o1 + rr) * (int)sizeof(double)); };
+    auto solve_block = [&](double (&a)[WPB], double &dg, double &u, double &k, double &zi, const double z0, double (&cr)[3],
+                           double &s2, double &sz, double &szq, double (&cq)[4], double &lj) {
+      double idg = __builtin_amdgcn_rcp(dg);
+      idg = __builtin_fma(__builtin_fma(-dg, idg, 1.0), idg, idg);
+      idg = __builtin_fma(__builtin_fma(-dg, idg, 1.0), idg, idg);
+      static_for<0, WPB - 1>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        const double wv = u * idg, qv = k * idg;
+        fnmac_bcast<J, true>(u, wv, a[J]);
+        fnmac_bcast<J, true>(k, qv, a[J]);
+      });
+      const double wm = u * idg, qm = k * idg;
+      const double qy = __builtin_fma(wm, z0, zi);
+      const double w2 = wm * wm;
+      const double Tj = cr[0] + win_row_scan_excl(w2), Tj1 = Tj + w2;
+      const double Sk = cr[1] + win_row_scan_excl(wm * qm), Sy = cr[2] + win_row_scan_excl(wm * qy);
+      const double rj = rsqrt3(Tj), rj1 = rsqrt3(Tj1);
+      const double g = Tj * rj * rj1;
+      const double h = wm * (rj * rj);
+      const double sp = h * g;
+      lj = __builtin_fma(-h, Sk, qm) * g;
+      const double zn = __builtin_fma(-h, Sy, qy) * g;
+      s2 = __builtin_fma(lj, lj, s2);
+      sz = __builtin_fma(lj, zn, sz);
+      szq = __builtin_fma(zn, zn, szq);
+      double acc = dg * wm;
+      dg = dg * (Tj1 * rj1 * rj);
+      zi = zn;
+      static_for<0, WPB - 1>([&](auto kc) {
+        constexpr int K = WPB - 2 - decltype(kc)::value;   // 14 .. 0
+        fmac_bcast<K, K == WPB - 2>(acc, wm, a[K]);
+        double nw = 0.0;
+        fmac_bcast<K, K == WPB - 2>(nw, g, a[K]);
+        fmac_bcast<K, K == WPB - 2>(nw, sp, acc);
+        a[K] = (K < i) ? nw : 0.0;
+      });
+      cq[0] = g; cq[1] = sp; cq[2] = wm; cq[3] = qm;
+      cr[0] = mov_bcast<WPB - 1>(Tj1);
+      cr[1] = mov_bcast<WPB - 1>(__builtin_fma(wm, qm, Sk));
+      cr[2] = mov_bcast<WPB - 1>(__builtin_fma(wm, qy, Sy));
+    };
+    auto sweep_row = [&](double (&a)[WPB], double &u, double &k, const double *csb) {
+#pragma unroll
+      for (int j = 0; j < WPB; ++j) {
+        const double c = csb[4 * j], sp = csb[4 * j + 1], wj = csb[4 * j + 2], qj = csb[4 * j + 3], aj = a[j];
+        a[j] = __builtin_fma(sp, u, c * aj);
+        u = __builtin_fma(-aj, wj, u);
+        k = __builtin_fma(-aj, qj, k);
+      }
+    };
+    auto sweep_row_w0 = [&](double (&a)[WPB], double &u, double &k, const double (&cq)[4]) {
+      static_for<0, WPB>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        double out = 0.0;
+        fmac_bcast<J, J == 0>(out, cq[0], a[J]);
+        fmac_bcast<J, J == 0>(out, cq[1], u);
+        fnmac_bcast<J, J == 0>(u, cq[2], a[J]);
+        fnmac_bcast<J, J == 0>(k, cq[3], a[J]);
+        a[J] = out;
+      });
+    };
+    auto row_sum = [&](double x) {
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off);
+      return x;
+    };
+    double zi = 0.0;
+    // A_0 .. A_{TK-1} on the diagonal block of panel pi (a[] strictly lower, dg, zi, uq[], kq[] loaded)
+    auto block_all = [&](int pi, double (&a)[WPB], double dg) {
+      const int p0 = pi * WPB, col = p0 + i;
+      static_for<0, TK>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        if constexpr (Q >= 1) {
+          if (pi == 0) {   // row Q - 1 leaves: its z is what tick Q drops, column Q - 1 (after ticks < Q) is tick Q's rank-1 vector
+            z0q[Q] = mov_bcast<Q - 1>(zi);
+            uq[Q] = i >= Q ? a[Q - 1] : 0.0;
+            kq[Q] = i >= Q ? kq[Q] : 0.0;
+            zi = i == Q - 1 ? 0.0 : zi;
+            dg = i == Q - 1 ? 1.0 : dg;
+            a[Q - 1] = 0.0;
+          }
+        }
+        double lj;
+        solve_block(a, dg, uq[Q], kq[Q], zi, z0q[Q], car[Q], sl2[Q], slz[Q], szz[Q], co[Q], lj);
+        if (lead) {
+          double *c = CS + Q * 8 * WPB + (pi & 1) * 4 * WPB;
+          c[4 * i + 0] = co[Q][0]; c[4 * i + 1] = co[Q][1]; c[4 * i + 2] = co[Q][2]; c[4 * i + 3] = co[Q][3];
+          if (col >= Q && col < m + Q) {
+            pm[Q] *= dg;
+            pe[Q] += __builtin_amdgcn_frexp_exp(pm[Q]);
+            pm[Q] = __builtin_amdgcn_frexp_mant(pm[Q]);
+            LL[Q * NS + col] = lj;
+          }
+        }
+        if constexpr (Q + 1 < TK) {
+          const int im = m + Q - p0;
+          if (im >= 0 && im < WPB) {   // tick Q's new row m + Q = (l_Q, d_Q) joins the block, with its z
+            const double kss = (kid == K_RBF_BROWNIAN) ? pr[9] * pr[10] * fabs(XN[Q * MAXD]) : pr[9];
+            const double s2 = row_sum(sl2[Q]), sz = row_sum(slz[Q]);
+            double dd = kss + noise + 1e-8 - s2;
+            if (!(dd > 0.0)) {
+              if (badq == 0) badq = t + Q + 1;
+              dd = 1e-300;
+            }
+            dq[Q] = sqrt(dd);
+            znq[Q] = (p.ys[(size_t)w * p.T + t + Q] - sz) / dq[Q];
+            if (i == im) {
+#pragma unroll
+              for (int j = 0; j < WPB; ++j) a[j] = j < im ? LL[Q * NS + p0 + j] : 0.0;
+              dg = dq[Q];
+              zi = znq[Q];
+            }
+          }
+        }
+      });
+      if (lead && col < nrow) {
+        const unsigned off = eoff(col, p0);
+#pragma unroll
+        for (int j = 0; j < WPB - 1; ++j)
+          if (p0 + j < nrow) st64(a[j], off, j * colb);
+        st64(dg, off + (unsigned)(i * colb), 0);
+        z[o1 + col] = zi;
+      }
+    };
+    // sweep waves: trips of a panel (wave-uniform), a slot's row, the request of a trip
+    auto trips_of = [&](int pi) {
+      const int tot = nrow - (pi * WPB + 2 * WPB) - (wave - 1) * 64;
+      return tot > 0 ? (tot + 191) / 192 : 0;
+    };
+    auto slot_row = [&](int pi, int n, int r, int &rr, bool &ok) {
+      const int R = nrow - (pi * WPB + 2 * WPB);
+      const int idx = (wave - 1) * 64 + r + 192 * n;
+      ok = idx < R;
+      rr = pi * WPB + 2 * WPB + (ok ? idx : 0);
+    };
+    auto issue_stage = [&](int pi, int n) {
+      typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int rr;
+        bool ok;
+        slot_row(pi, n, 32 * h + (lane >> 1), rr, ok);
+        const unsigned vo = eoff(rr, pi * WPB) + 4u * (lane & 1);
+#pragma unroll
+        for (int c = 0; c < WPB; ++c)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(stg + c * 64 + 32 * h), 4, vo, c * colb, 0, 0);
+      }
+    };
+    bool first_trip = true;
+    if (wave > 0) {
+      int pi0 = 0;
+      while (pi0 < npan && trips_of(pi0) == 0) ++pi0;
+      if (pi0 < npan) issue_stage(pi0, 0);
+    }
+    if (wave == 0) {
+      double ad[WPB], dg;
+      {
+        const unsigned off = eoff(i, 0);
+        const bool in = i < m;
+#pragma unroll
+        for (int j = 0; j < WPB; ++j) ad[j] = (j < i && in) ? ld64(off, j * colb) : 0.0;
+        dg = in ? ld64(off + (unsigned)(i * colb), 0) : 1.0;
+        zi = in ? z[o1 + i] : 0.0;
+        uq[0] = in ? VV[i] : 0.0;
+#pragma unroll
+        for (int q = 0; q < TK; ++q) kq[q] = in ? KK[q * NS + i] : 0.0;
+      }
+      block_all(0, ad, dg);
+    }
+    for (int pi = 0; pi < npan; ++pi) {
+      lds_barrier();
+      const int p0 = pi * WPB;
+      if (wave == 0) {
+        if (pi + 1 < npan) {
+          const int rr = p0 + WPB + i;
+          const bool old = rr < m;
+          double ad[WPB], dg, a[WPB];
+          {
+            const unsigned off = eoff(old ? rr : 0, p0 + WPB);
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) {
+              const double x = ld64(off, j * colb);
+              ad[j] = (j < i && old) ? x : 0.0;
+            }
+            const double xd = ld64(eoff(old ? rr : 0, old ? rr : 0), 0);
+            dg = old ? xd : 1.0;
+          }
+          const double zn = old ? z[o1 + rr] : 0.0;
+          {
+            const unsigned off = eoff(old ? rr : 0, p0);
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) {
+              const double x = ld64(off, j * colb);
+              a[j] = old ? x : 0.0;
+            }
+          }
+          // residuals of the rows that exist for a tick (row rr takes part in tick q while rr < m + q)
+#pragma unroll
+          for (int q = 0; q < TK; ++q) {
+            uq[q] = (rr < m + q && (q == 0 || pi > 0)) ? VV[q * NS + rr] : 0.0;
+            kq[q] = rr < m + q ? KK[q * NS + rr] : 0.0;
+          }
+          // every lane takes every tick's sweep (the DPP reads need the whole row active): rows that do not exist yet carry zeros;
+          // a born row's entries come from LDS in front of the first tick that takes it
+          static_for<0, TK>([&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+            sweep_row_w0(a, uq[Q], kq[Q], co[Q]);
+            if constexpr (Q + 1 < TK) {
+              if (p0 + 2 * WPB > m + Q && p0 + WPB <= m + Q) {   // the row tick Q bears is one of these sixteen
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) a[j] = rr == m + Q ? LL[Q * NS + p0 + j] : a[j];
+              }
+              if (pi == 0) uq[Q + 1] = rr < m + Q + 1 ? a[Q] : 0.0;
+            }
+          });
+          if (lead && rr < nrow) {
+            const unsigned off = eoff(rr, p0);
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) st64(a[j], off, j * colb);
+          }
+          zi = zn;
+          block_all(pi + 1, ad, dg);
+        }
+      } else {
+        const int nt = trips_of(pi);
+        for (int n = 0; n < nt; ++n) {
+          if (first_trip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          first_trip = false;
+          int rr;
+          bool ok;
+          slot_row(pi, n, lane, rr, ok);
+          double a[WPB];
+#pragma unroll
+          for (int j = 0; j < WPB; ++j) a[j] = stg[j * 64 + lane];
+          if (rr >= m) {   // a row born inside the pass has no memory yet
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) a[j] = 0.0;
+          }
+          double u[TK], k[TK];
+#pragma unroll
+          for (int q = 0; q < TK; ++q) {
+            u[q] = (q == 0 || pi > 0) ? VV[q * NS + rr] : 0.0;
+            k[q] = KK[q * NS + rr];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage has been read: the next trip may land in it
+          {
+            int npi = pi, nn = n + 1;
+            if (nn >= nt) {
+              nn = 0;
+              do ++npi; while (npi < npan && trips_of(npi) == 0);
+            }
+            if (npi < npan) issue_stage(npi, nn);
+          }
+          if (ok) {
+#pragma unroll
+            for (int q = 0; q < TK; ++q) {
+              if (rr < m + q) sweep_row(a, u[q], k[q], CS + q * 8 * WPB + (pi & 1) * 4 * WPB);
+              if (q + 1 < TK && rr == m + q) {   // the row tick q bears: its entries are l_q, in front of the first tick that takes it
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) a[j] = LL[q * NS + p0 + j];
+              }
+              if (pi == 0 && q + 1 < TK) u[q + 1] = a[q];
+            }
+            const unsigned off = eoff(rr, p0);
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) st64(a[j], off, j * colb);
+#pragma unroll
+            for (int q = 0; q < TK; ++q) {
+              VV[q * NS + rr] = u[q];
+              KK[q * NS + rr] = k[q];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- outputs of the TK ticks; the last tick's new row
+    if (wave == 0) {
+#pragma unroll
+      for (int q = 0; q < TK; ++q) {
+        double la = log(pm[q]) + (double)pe[q] * 0.6931471805599453;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) la += __shfl_xor(la, off);
+        const double s2 = row_sum(sl2[q]), sz = row_sum(slz[q]), szq = row_sum(szz[q]);
+        if (tid == 0) {
+          double *r = RED + q * 8;
+          r[0] = s2; r[1] = sz; r[2] = la; r[3] = szq; r[4] = dq[q]; r[5] = znq[q];
+        }
+      }
+    }
+    __syncthreads();
+    for (int cc = TK - 1 + tid; cc < nrow; cc += 256)
+      Lg[(size_t)(o1 + cc) * CAP + o1 + nrow] = LL[(TK - 1) * NS + cc];
+    if (tid == 0) {
+      if (bad == 0 && badq != 0) bad = badq;
+#pragma unroll
+      for (int q = 0; q < TK; ++q) {
+        const double *r = RED + q * 8;
+        const double kss = (kid == K_RBF_BROWNIAN) ? pr[9] * pr[10] * fabs(XN[q * MAXD]) : pr[9];
+        const double yq = p.ys[(size_t)w * p.T + t + q];
+        const size_t oi = (size_t)w * p.T + t + q;
+        double dd = r[4], zn = r[5];
+        if (q == TK - 1) {
+          double d2 = kss + noise + 1e-8 - r[0];
+          if (!(d2 > 0.0)) {
+            if (bad == 0) bad = t + q + 1;
+            d2 = 1e-300;
+          }
+          dd = sqrt(d2);
+          zn = (yq - r[1]) / dd;
+          Lg[(size_t)(o1 + nrow) * CAP + o1 + nrow] = dd;
+          z[o1 + nrow] = zn;
+        }
+        double pv = kss - r[0];
+        pv = pv < 1e-15 ? 1e-15 : pv;
+        p.pred_mean[oi] = r[1];
+        p.pred_var[oi] = p.include_noise ? pv + noise : pv;
+        p.logml[oi] = -0.5 * (r[3] + zn * zn) - (r[2] + log(dd)) - 0.5 * (double)N * 1.8378770664093453;
+        yw[o1 + m + q] = yq;
+        for (int c = 0; c < d; ++c) xw[c * CAP + o1 + m + q] = XN[q * MAXD + c];
+      }
+    }
+    o += TK;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int *st = p.state + w * 4;
+    st[0] = o;
+    st[1] = N;
+    st[2] = bad;
+    st[3] += p.nt;
+    if (p.info_out) p.info_out[w] = bad;
+  }
+}
+
+
 }  // namespace cgp
