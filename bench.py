@@ -844,14 +844,18 @@ def window_line(engine, torch, dev, local, W=1024, N=512, d=3, T=200):
         c1.window_push(X[:1, N + i:N + i + 1], y[:1, N + i:N + i + 1])
     host_tick_us = (time.perf_counter() - t1) / nt * 1e6
     # counter traffic of the same command (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, profiles/r06_window_pmc_summary.json, the round's final
-    # kernels): 2 x 6.309e7 KB fetched + 1.186e8 KB written = 250.7 GB for the 429.5 GB algorithmic of 200 ticks x 1024 windows
-    kCounterOverAlgorithmic = 250.7 / 429.5
-    return {"window_ticks_per_s": W * T / el, "window_hbm_frac": gbps / HBM_PEAK_GBPS,
+    # kernels: k_window_multi<4> takes the steady-state ticks): 2 x FETCH_SIZE KB + WRITE_SIZE KB = 143.8 GB for the 429.5 GB algorithmic of
+    # 200 ticks x 1024 windows
+    kCounterOverAlgorithmic = 143.8 / 429.5
+    tpp = 4 if (W >= 512 and N >= 64) else 2      # steady-state ticks per pass over the factor (k_window_multi<4> from 512 windows, k_window_pairs below)
+    return {"window_ticks_per_s": W * T / el, "window_hbm_frac": gbps / tpp / HBM_PEAK_GBPS, "window_ticks_per_pass": tpp,
+            "window_hbm_frac_one_pass_per_tick_equivalent": gbps / HBM_PEAK_GBPS,
             "window_hbm_frac_counter_traffic_projected": gbps / HBM_PEAK_GBPS * kCounterOverAlgorithmic, "window_host_tick_us": host_tick_us,
             "window_counter_over_algorithmic": {"ratio": kCounterOverAlgorithmic, "from": "profiles/r06_window_pmc_summary.json (the final round-6 "
                                                 "window kernels), NOT measured in this run"},
-            "window_traffic_note": "window_hbm_frac = ALGORITHMIC bytes per tick (factor read + written once) x ticks/s / 8 TB/s, measured in this run; the "
-                                   "kernel takes steady-state ticks two per pass, so the traffic the PMC counters saw is 0.58 of that: "
+            "window_traffic_note": "a pass over the factor reads and writes it once (n^2/2 x 8 B x 2) and advances window_ticks_per_pass ticks: "
+                                   "window_hbm_frac = those bytes x passes/s / 8 TB/s, measured in this run; _one_pass_per_tick_equivalent = the same rate priced "
+                                   "at one pass per tick (what rounds 1-5 reported; above 1 now); the PMC counters saw 0.33 of the per-tick bytes: "
                                    "window_hbm_frac_counter_traffic_projected = this run's rate x that committed ratio, a projection (tools/pmc_window.sh "
                                    "re-measures the ratio)",
             "window_workload": f"BASELINE configs[3]: {W} windows x N={N} d={d} fp64, {T} ticks, algorithmic {gbps:.0f} GB/s of {HBM_PEAK_GBPS:.0f}"}

@@ -17,7 +17,7 @@
 // Both sweeps are fused into one pass over L in 16-column panels: wave 0 does the sequential part
 // of a panel (16x16 diagonal block in registers, DPP row_newbcast), then every thread takes the panel's columns
 // (c, s', w, q) into its own rows below.  L is read and written exactly once per tick (once per TWO ticks in
-// k_window_pairs): n^2/2 * 8 B * 2 of HBM traffic per pass, the bound of these kernels.
+// k_window_pairs, once per FOUR in k_window_multi<4>): n^2/2 * 8 B * 2 of HBM traffic per pass.
 // Storage: column-major, capacity 2N x 2N; the window origin slides down the diagonal and is moved
 // back every N ticks.  The strict upper triangle of the slab is never read (the kernels store zeros / by-products there).
 #pragma once

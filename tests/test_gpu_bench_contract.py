@@ -49,6 +49,7 @@ def test_bench_extra_lines():
     assert ex["cfg3_fits_per_s"] > 0 and 0 < ex["cfg3_roofline_frac"] < 1 and ex["cfg3_max_rel_err_vs_oracle"] < 1e-3
     assert ex["cfg3_cpu_baseline"]["value"] > 0 and ex["cfg3_cpu_baseline"]["kind"] == "port" and "_cpu_leg" not in ex
     assert ex["window_ticks_per_s"] > 0 and 0 < ex["window_hbm_frac"] < 1 and ex["lookahead_traj_per_s"] > 0
+    assert ex["window_ticks_per_pass"] == 4 and ex["window_hbm_frac_one_pass_per_tick_equivalent"] == pytest.approx(4 * ex["window_hbm_frac"])
     assert 0 < ex["window_host_tick_us"] < 2000
     assert 0 < ex["node_callback_us"] < 5000 and 0 < ex["node_callback_opt_ms"] < 500   # the reference node's own work item
     # configs[2] as written (64 fits per GPU at 8 GPUs): the 64-fit call rate and the projection from this GPU's two rates

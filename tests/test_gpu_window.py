@@ -163,3 +163,31 @@ def test_growing_pushes_of_a_fresh_context_under_load(engine):
     finally:
         for p in load:
             p.wait(timeout=120)
+
+
+def test_many_windows_take_four_ticks_per_pass_and_match_single_ticks(engine):
+    """From 512 windows the steady-state ticks go four per pass over the factor (k_window_multi; rows born inside the pass, three
+    inert lanes in the first panel): the same stream pushed tick by tick (k_window_ticks only) gives the same outputs to rounding,
+    and window 0 matches the refit oracle.  Window lengths either side of a panel boundary; a block length that is no multiple of four."""
+    for N, d, T2 in ((64, 2, 23), (81, 3, 38)):
+        nwin, kid = 512, 1
+        rng = np.random.default_rng(N)
+        T = N + 6 + T2
+        t = np.arange(11, 11 + T, dtype=np.float64)
+        X = np.empty((nwin, T, d)); X[:, :, 0] = (t - t.mean()) / t.std(); X[:, :, 1:] = rng.normal(size=(nwin, T, d - 1))
+        y = 0.1 * np.sin(2 * np.pi * t / 40.0)[None] + rng.normal(0, 0.03, (nwin, T))
+        theta = np.concatenate([[0.02], np.linspace(0.8, 1.6, d), [1e-3]])
+        A = engine.Context(max_n=8, max_m=8, max_d=d); A.window_init(nwin, N, d, kid, theta)
+        B = engine.Context(max_n=8, max_m=8, max_d=d); B.window_init(nwin, N, d, kid, theta)
+        n0 = N + 6
+        A.window_push(X[:, :n0], y[:, :n0]); B.window_push(X[:, :n0], y[:, :n0])
+        pa = A.window_push(X[:, n0:], y[:, n0:])                      # one block: four ticks per pass, then the odd ones
+        pb = [np.concatenate(c, 1) for c in zip(*[B.window_push(X[:, j:j + 1], y[:, j:j + 1]) for j in range(n0, T)])]
+        for a, b in zip(pa, pb):
+            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) < 1e-9
+        opm, opv, olm = go.sliding_window_stream(kid, theta, N, X[0], y[0])
+        assert np.max(np.abs(pa[0][0] - opm[n0:])) <= TOL * np.max(np.abs(opm))
+        assert np.max(np.abs(pa[1][0] - opv[n0:]) / opv[n0:]) < TOL
+        assert np.max(np.abs(pa[2][0] - olm[n0:]) / np.maximum(np.abs(olm[n0:]), 1.0)) < TOL
+        assert A.window_state(0) == (N, 0) and A.window_state(nwin - 1) == (N, 0)
+
