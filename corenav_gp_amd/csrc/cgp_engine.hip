@@ -14,6 +14,8 @@
 #include "slip_recorder.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <climits>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -2573,10 +2575,27 @@ extern "C" int cgp_window_push(cgp_ctx *c, int T, const double *xs, const double
     // samples where they were staged (pinned host memory is device-visible at its host address) and write the tick's
     // outputs and every window's status word back there; one synchronisation.  (Round 4: one H2D, two D2H, 176 us per tick of
     // one N = 512 window, ~30 us of it the three copy commands; the tick itself is 147 us of one workgroup's serial chains.)
-    for (size_t w = 0; w < W; ++w) hst[w] = 0;
+    // T = 1 is ONE launch of the single-tick kernel, whose last store is the window's status word (after a system-scope fence): the host
+    // polls those words in the pinned block instead of synchronising the stream (a few microseconds of the runtime's wake-up), and
+    // falls back to the synchronisation if they do not arrive (which is also where a faulting kernel's error surfaces)
+    constexpr int kPending = INT_MIN;
+    const bool poll = T == 1;
+    for (size_t w = 0; w < W; ++w) hst[w] = poll ? kPending : 0;
     int rc0 = window_push_impl(c, T, h, h + nx, include_noise, h + nx + ny, h + nx + 2 * ny, h + nx + 3 * ny, hst, s);
     if (rc0 != CGP_OK) return rc0;
-    HIP_TRY(c, hipStreamSynchronize(s));
+    bool done = false;
+    if (poll) {
+      volatile int *v = hst;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int spin = 0;; ++spin) {
+        size_t w = 0;
+        while (w < W && v[w] != kPending) ++w;
+        if (w == W) { done = true; break; }
+        if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!done) HIP_TRY(c, hipStreamSynchronize(s));
     memcpy(pm, h + nx + ny, ny * 8);
     memcpy(pv, h + nx + 2 * ny, ny * 8);
     memcpy(logml, h + nx + 3 * ny, ny * 8);

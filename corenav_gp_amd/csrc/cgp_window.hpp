@@ -444,7 +444,10 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? WIN_OCC : 1) void k_window_ticks(
     st[1] = n;
     st[2] = bad;
     st[3] += p.nt;
-    if (p.info_out) p.info_out[w] = bad;
+    if (p.info_out) {
+      __threadfence_system();   // the tick's outputs (this thread's stores, possibly to pinned host memory) are visible before the status word:
+      p.info_out[w] = bad;      // a one-launch host push polls that word instead of synchronising the stream
+    }
   }
 }
 
