@@ -349,14 +349,25 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? WIN_OCC : 1) void k_window_ticks(
           double ad[WPB], dg, a[WPB];
           const double *sb = stg + (pi & 1) * WIN_STG;
           const unsigned offr = (unsigned)(((o2 + p0) * CAP + o2 + r) * (int)sizeof(double));
+          if (nb1 == WPB) {   // every panel but the last: no row of the block lies past the window
 #pragma unroll
-          for (int j = 0; j < WPB; ++j) a[j] = i < nb1 ? sb[j * WPB + i] : 0.0;
+            for (int j = 0; j < WPB; ++j) a[j] = sb[j * WPB + i];
 #pragma unroll
-          for (int j = 0; j < WPB; ++j) ad[j] = (j < i && i < nb1) ? sb[WPB * WPB + j * WPB + i] : 0.0;
-          dg = i < nb1 ? sb[WPB * WPB + i * WPB + i] : 1.0;
-          zi = i < nb1 ? sb[2 * WPB * WPB + i] : 0.0;
-          ui = i < nb1 ? vv[r] : 0.0;
-          ki = i < nb1 ? kk[r] : 0.0;
+            for (int j = 0; j < WPB; ++j) ad[j] = j < i ? sb[WPB * WPB + j * WPB + i] : 0.0;
+            dg = sb[WPB * WPB + i * WPB + i];
+            zi = sb[2 * WPB * WPB + i];
+            ui = vv[r];
+            ki = kk[r];
+          } else {
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) a[j] = i < nb1 ? sb[j * WPB + i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) ad[j] = (j < i && i < nb1) ? sb[WPB * WPB + j * WPB + i] : 0.0;
+            dg = i < nb1 ? sb[WPB * WPB + i * WPB + i] : 1.0;
+            zi = i < nb1 ? sb[2 * WPB * WPB + i] : 0.0;
+            ui = i < nb1 ? vv[r] : 0.0;
+            ki = i < nb1 ? kk[r] : 0.0;
+          }
 #if WIN_PROBE
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           WIN_LAP(1)
