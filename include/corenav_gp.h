@@ -282,7 +282,10 @@ int cgp_debug_buffers(cgp_ctx *ctx, unsigned long long out[2 * CGP_DEBUG_BUFFERS
  * one-step-ahead predictive mean / variance of the incoming y BEFORE it is added, and the log
  * marginal likelihood of the window after it.  theta (nwin, theta_stride) is fixed per window.
  * xs (nwin, T, d), ys (nwin, T); outputs (nwin, T).  Returns 0, or the 1-based tick at which a window
- * lost positive definiteness. */
+ * lost positive definiteness.  cgp_window_push blocks until the outputs are in the caller's arrays (a small push is read and
+ * written by the kernels in pinned host memory; a one-tick push waits on the windows' status words there rather than on the
+ * stream: 74 us per tick of one N = 512 window from a C caller).  Steady-state ticks of a longer push go two per pass over the
+ * factors, four from 512 windows: the outputs are those of the tick-by-tick stream to rounding. */
 int cgp_window_init(cgp_ctx *ctx, int nwin, int N, int d, int kernel_id, const double *theta, int theta_stride);
 int cgp_window_push(cgp_ctx *ctx, int T, const double *xs, const double *ys, int include_noise,
                     double *pred_mean, double *pred_var, double *logml);
