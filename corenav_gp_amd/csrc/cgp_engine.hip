@@ -127,6 +127,8 @@ struct cgp_ctx {
   int *dinfo = nullptr;
   double *dsmall = nullptr;   // [max_batch][SM_OUT] results of the one-launch short-window kernel (k_small, fp64 contexts)
   unsigned short *dsmdeal = nullptr;   // k_small's helper work lists (sm_build_deal) of every NB <= SM_MAX_NB, at smdeal_off[NB]
+  int *dsmdone = nullptr;              // k_small_predict's count of finished workgroups (the node callback polls a pinned word the last one writes)
+  int small_seq = 0;
   size_t smdeal_off[SM_MAX_NB + 1] = {0};
   std::vector<double> lazy_win;   // [X (N, d) | y] of the window a short-window kernel evaluated in place (ensure_fitted uploads it)
   int pending_tab = 0;               // tick-grid table size cgp_fit_predict_batch found for the batch it is about to submit (0: none)
@@ -163,7 +165,8 @@ struct SmallDev {   // a batch resident in the caller's device buffers (cgp_fit_
   int *info;
 };
 int small_predict_launch(cgp_ctx *c, int batch, int N, int d, int M, int kid, int include_noise, double *dmean, double *dvar, double *dout,
-                         hipStream_t s, const SmallRaw *raw = nullptr, const SmallDev *dev = nullptr, int tab_n = 0);
+                         hipStream_t s, const SmallRaw *raw = nullptr, const SmallDev *dev = nullptr, int tab_n = 0, int *done_flag = nullptr,
+                         int done_seq = 0);
 int node_callback_small(cgp_ctx *c, const double *time_array, const double *slip_array, int n, int kid, double *theta, int max_evals,
                         double *mean, double *sigma, int cap, int *m_out);
 bool grow_pinned(void *&p, size_t &cap, size_t bytes);
@@ -1292,6 +1295,7 @@ cgp_ctx *cgp_create_ex(int device, int max_n, int max_m, int max_d, int max_batc
       }
       ok = ok && hipMalloc((void **)&c->dsmdeal, tab.size() * sizeof(unsigned short)) == hipSuccess;
       ok = ok && hipMemcpy(c->dsmdeal, tab.data(), tab.size() * sizeof(unsigned short), hipMemcpyHostToDevice) == hipSuccess;
+      ok = ok && hipMalloc((void **)&c->dsmdone, sizeof(int)) == hipSuccess && hipMemset(c->dsmdone, 0, sizeof(int)) == hipSuccess;
     }
     ok = ok && set_small_attr(device) == 0;
   }
@@ -1315,7 +1319,7 @@ void cgp_destroy(cgp_ctx *c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg, c->dpanimg, c->dsmall, c->dsmdeal, c->dref_r, c->dref_a, c->dref_flag, c->Lp};
+  void *bufs[] = {c->Lw, c->Winv, c->dX, c->dXs, c->dy, c->dmean, c->dvar, c->dalpha, c->dtheta, c->djitter, c->dlogml, c->dinfo, c->dprep, c->ddbg, c->dgpart, c->dpart, c->dticket, c->dwready, c->dlatimg, c->la_buf, c->la_ibuf, c->dmacc, c->ddiagimg, c->dpanimg, c->dsmall, c->dsmdeal, c->dsmdone, c->dref_r, c->dref_a, c->dref_flag, c->Lp};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < cgp_ctx::kMaxStreams; ++i) {
@@ -2058,9 +2062,12 @@ bool small_batch_predict_ok(const cgp_ctx *c, int batch, int N, int d, int M) {
   return !off && batch <= c->max_batch && small_predict_ok(c, N, d, M);
 }
 int small_predict_launch(cgp_ctx *c, int batch, int N, int d, int M, int kid, int include_noise, double *dmean, double *dvar, double *dout,
-                         hipStream_t s, const SmallRaw *raw, const SmallDev *dev, int tab_n) {
+                         hipStream_t s, const SmallRaw *raw, const SmallDev *dev, int tab_n, int *done_flag, int done_seq) {
   SmallArgs a{};
   a.ladder = 1;
+  a.done_flag = (done_flag && c->dsmdone) ? done_flag : nullptr;
+  a.done_count = c->dsmdone;
+  a.done_seq = done_seq;
   a.X = raw ? raw->X : static_cast<const double *>(c->dX);
   a.y = raw ? raw->y : static_cast<const double *>(c->dy);
   a.theta = raw ? raw->theta : c->dtheta;
@@ -2302,7 +2309,7 @@ int node_callback_small(cgp_ctx *c, const double *time_array, const double *slip
   if (m_out) *m_out = (int)mo;
   HIP_TRY(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
-  const size_t nout = 2 * (size_t)M + 2 * SM_OUT, out_bytes = nout * sizeof(double);   // mean, var, the two kernels' records
+  const size_t nout = 2 * (size_t)M + 2 * SM_OUT, out_bytes = (nout + 1) * sizeof(double);   // mean, var, the two kernels' records, the completion word
   if (!grow_pinned(c->pin_in, c->pin_in_cap, (2 * (size_t)ntr + M + CGP_MAX_THETA) * sizeof(double)) ||
       !grow_pinned(c->pin_out, c->pin_out_cap, out_bytes))
     return CGP_ENOMEM;
@@ -2324,9 +2331,25 @@ int node_callback_small(cgp_ctx *c, const double *time_array, const double *slip
     rc = small_launch(c, 1, ntr, 1, kid, SM_MODE_OPT, max_evals, s, opt, &raw, tick_table_entries(kid, 1, time_array, ntr, nullptr, 0));
     if (rc != CGP_OK) return rc;
   }
-  rc = small_predict_launch(c, 1, ntr, 1, M, kid, 1, hout, hout + M, rec, s, &raw, nullptr, tick_table_entries(kid, 1, time_array, ntr, raw.Xs, M));
+  // the last workgroup of the prediction launch stores the call's sequence number to a word of the pinned block (behind a system-scope
+  // fence): the host polls it instead of synchronising the stream, and falls back to the synchronisation after 2 ms (a long
+  // optimisation, a faulting kernel)
+  volatile int *flag = reinterpret_cast<volatile int *>(hout + nout);
+  const int seq = (c->small_seq = c->small_seq % 1000000 + 1);
+  *flag = 0;
+  rc = small_predict_launch(c, 1, ntr, 1, M, kid, 1, hout, hout + M, rec, s, &raw, nullptr, tick_table_entries(kid, 1, time_array, ntr, raw.Xs, M),
+                            const_cast<int *>(reinterpret_cast<volatile int *>(flag)), seq);
   if (rc != CGP_OK) return rc;
-  HIP_TRY(c, hipStreamSynchronize(s));
+  bool done = false;
+  if (c->dsmdone) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spin = 0;; ++spin) {
+      if (*flag == seq) { done = true; break; }
+      if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!done) HIP_TRY(c, hipStreamSynchronize(s));
   memcpy(c->last_small, max_evals > 0 ? opt : rec, SM_OUT * sizeof(double));
   if (max_evals > 0) {
     if (opt[SMO_INFO] != 0.0) {   // the start values themselves are not positive definite even with the jitter ladder

@@ -78,6 +78,10 @@ struct SmallArgs {
   int ladder;             // 1: GPy's jitchol ladder inside the launch; 0: one attempt at the given jitter, the pivot reported
   double *logml;          // per window or NULL (beside the record)
   int *info;
+  // k_small_predict, the node callback: the LAST workgroup to finish (done_count, device, returns to 0) stores done_seq to done_flag
+  // (pinned host memory) behind a system-scope fence -- the host polls that word instead of synchronising the stream.  NULL: off.
+  int *done_count, *done_flag;
+  int done_seq;
 };
 
 // Block rows of k_small_predict's V = W K* phase -> waves: row bi costs bi + 1 products.  The two waves of a SIMD (w and w + 4) share
@@ -1260,6 +1264,17 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_predict(SmallArgs p) {
   if (part == 0 && tid == 0)
     for (int i = 0; i < 16; ++i) ob[32 + i] = s.sc[48 + i];
 #endif
+  if (p.done_flag) {
+    __syncthreads();   // every thread's stores of this workgroup have been issued and waited for
+    if (tid == 0) {
+      __threadfence_system();
+      if (atomicAdd(p.done_count, 1) == (int)gridDim.x - 1) {
+        *p.done_count = 0;
+        __threadfence_system();
+        *reinterpret_cast<volatile int *>(p.done_flag) = p.done_seq;
+      }
+    }
+  }
 }
 
 }  // namespace cgp
