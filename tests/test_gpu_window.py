@@ -168,8 +168,9 @@ def test_growing_pushes_of_a_fresh_context_under_load(engine):
 def test_many_windows_take_four_ticks_per_pass_and_match_single_ticks(engine):
     """From 512 windows the steady-state ticks go four per pass over the factor (k_window_multi; rows born inside the pass, three
     inert lanes in the first panel): the same stream pushed tick by tick (k_window_ticks only) gives the same outputs to rounding,
-    and window 0 matches the refit oracle.  Window lengths either side of a panel boundary; a block length that is no multiple of four."""
-    for N, d, T2 in ((64, 2, 23), (81, 3, 38)):
+    and window 0 matches the refit oracle.  Window lengths either side of a panel boundary; block lengths that are no multiple of four; one block
+    longer than the ring (the compacting tick goes through the single-tick kernel in the middle of it)."""
+    for N, d, T2 in ((64, 2, 23), (81, 3, 38), (64, 1, 150)):   # the last one runs through a ring compaction inside the block
         nwin, kid = 512, 1
         rng = np.random.default_rng(N)
         T = N + 6 + T2
@@ -184,7 +185,8 @@ def test_many_windows_take_four_ticks_per_pass_and_match_single_ticks(engine):
         pa = A.window_push(X[:, n0:], y[:, n0:])                      # one block: four ticks per pass, then the odd ones
         pb = [np.concatenate(c, 1) for c in zip(*[B.window_push(X[:, j:j + 1], y[:, j:j + 1]) for j in range(n0, T)])]
         for a, b in zip(pa, pb):
-            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) < 1e-9
+            # two orders of the same updates: rounding apart, growing with the number of chained ticks (1.8e-9 after 150 on the dense d = 1 window)
+            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) < (1e-9 if T2 < 64 else 1e-7)
         opm, opv, olm = go.sliding_window_stream(kid, theta, N, X[0], y[0])
         assert np.max(np.abs(pa[0][0] - opm[n0:])) <= TOL * np.max(np.abs(opm))
         assert np.max(np.abs(pa[1][0] - opv[n0:]) / opv[n0:]) < TOL
